@@ -1,0 +1,355 @@
+/*
+ * lia_oracle.c -- CPU restatement of the LIA cooperative-decoder hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product path (isca-2025-lia_amd/) never links or calls it.
+ *
+ * Parity status: the reference has no test that exercises any LIA flag, so this
+ * restatement is pinned against outputs of the reference's own functions executed in the build
+ * container (tests/golden/make_golden.py -> the .npz fixtures beside it), not against reference-held vectors.
+ *
+ * Every function cites the reference code it restates.  Paths are relative to /root/reference;
+ *   decoder.py    = intel_extension_for_pytorch/transformers/models/reference/modules/decoder.py
+ *   attentions.py = intel_extension_for_pytorch/transformers/models/reference/modules/attentions.py
+ *   Krnl.cpp      = csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp
+ *
+ * Numerics: storage is bf16 (uint16 bit patterns), every reduction accumulates in fp32, and a bf16
+ * round-to-nearest-even is applied at exactly the points where the reference materialises a bf16
+ * tensor ("rounding points").  Summation ORDER is this file's own
+ * (sequential over k); cuBLAS / oneDNN / MFMA orders differ, so comparisons against it are
+ * tolerance-based for values and exact for token ids.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#if defined(__AVX512F__)
+#include <immintrin.h>
+#endif
+
+typedef uint16_t bf16_t;
+
+static inline float bf2f(bf16_t v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static inline bf16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40); /* NaN stays NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+static inline float rbf(float f) { return bf2f(f2bf(f)); } /* one bf16 rounding point */
+
+int lia_oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+void lia_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+/* F.layer_norm on a bf16 tensor: statistics and affine in fp32, one rounding at the output.
+ * decoder.py:107-119 (gpu_ln_compute_self_attn / gpu_ln_compute_final); the CPU policy uses
+ * nn.LayerNorm on the same data (decoder.py:206, :276) with the same rounding point. */
+void lia_oracle_layernorm(const bf16_t* x, const bf16_t* g, const bf16_t* b, bf16_t* y, long rows, int H,
+                          float eps) {
+#pragma omp parallel for schedule(static)
+  for (long r = 0; r < rows; ++r) {
+    const bf16_t* xr = x + r * (long)H;
+    bf16_t* yr = y + r * (long)H;
+    float mean = 0.f;
+    for (int i = 0; i < H; ++i) mean += bf2f(xr[i]);
+    mean /= (float)H;
+    float var = 0.f;
+    for (int i = 0; i < H; ++i) {
+      float d = bf2f(xr[i]) - mean;
+      var += d * d;
+    }
+    var /= (float)H;
+    float rstd = 1.0f / sqrtf(var + eps);
+    for (int i = 0; i < H; ++i) yr[i] = f2bf((bf2f(xr[i]) - mean) * rstd * bf2f(g[i]) + bf2f(b[i]));
+  }
+}
+
+/* dot products of MB x-rows against NB w-rows, all fp32 accumulate, k sequential per lane. */
+#define MB 4
+#define NB 4
+static void dot_block(const float* xf, long ldx, const float* wf, long ldw, int K, int mb, int nb,
+                      float acc[MB][NB]) {
+#if defined(__AVX512F__)
+  if (mb == MB && nb == NB && (K % 16) == 0) {
+    __m512 a[MB][NB];
+    for (int i = 0; i < MB; ++i)
+      for (int j = 0; j < NB; ++j) a[i][j] = _mm512_setzero_ps();
+    for (int k = 0; k < K; k += 16) {
+      __m512 xv[MB], wv[NB];
+      for (int i = 0; i < MB; ++i) xv[i] = _mm512_loadu_ps(xf + i * ldx + k);
+      for (int j = 0; j < NB; ++j) wv[j] = _mm512_loadu_ps(wf + j * ldw + k);
+      for (int i = 0; i < MB; ++i)
+        for (int j = 0; j < NB; ++j) a[i][j] = _mm512_fmadd_ps(xv[i], wv[j], a[i][j]);
+    }
+    for (int i = 0; i < MB; ++i)
+      for (int j = 0; j < NB; ++j) acc[i][j] = _mm512_reduce_add_ps(a[i][j]);
+    return;
+  }
+#endif
+  for (int i = 0; i < mb; ++i)
+    for (int j = 0; j < nb; ++j) {
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s += xf[i * ldx + k] * wf[j * ldw + k];
+      acc[i][j] = s;
+    }
+}
+
+/* y[M,N] = epilogue( x[M,K] @ w[N,K]^T ), row-major weights.
+ *
+ * split_bias = 1: the GPU sub-layer semantics, decoder.py:79-105 / attentions.py:393-394,418 --
+ *     t = bf16(matmul);  t = bf16(t + bias);  [relu];  [y = bf16(residual + t)]   (decoder.py:229,310)
+ * split_bias = 0: the CPU (policy 1) semantics -- nn.Linear / tpp_linear_bias fuse the bias into the
+ *     fp32 accumulator before the single rounding (csrc/cpu/tpp/kernels/TPPGEMMKrnl.h:89-176), then
+ *     relu, then "+ residual" as a second bf16 op (_IPEXlinearAddRef, reference/fusions/linear_fusion.py:17-24).
+ * bias / residual may be NULL. */
+void lia_oracle_linear(const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* residual, bf16_t* y,
+                       long M, int N, int K, int relu, int split_bias) {
+  float* xf = (float*)malloc((size_t)M * K * sizeof(float));
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < M * (long)K; ++i) xf[i] = bf2f(x[i]);
+#pragma omp parallel
+  {
+    float* wf = (float*)malloc((size_t)NB * K * sizeof(float));
+#pragma omp for schedule(static)
+    for (int n0 = 0; n0 < N; n0 += NB) {
+      int nb = N - n0 < NB ? N - n0 : NB;
+      for (int j = 0; j < nb; ++j)
+        for (int k = 0; k < K; ++k) wf[j * (long)K + k] = bf2f(w[(long)(n0 + j) * K + k]);
+      for (long m0 = 0; m0 < M; m0 += MB) {
+        int mb = M - m0 < MB ? (int)(M - m0) : MB;
+        float acc[MB][NB];
+        dot_block(xf + m0 * K, K, wf, K, K, mb, nb, acc);
+        for (int i = 0; i < mb; ++i)
+          for (int j = 0; j < nb; ++j) {
+            float t = acc[i][j];
+            float bv = bias ? bf2f(bias[n0 + j]) : 0.f;
+            if (split_bias) {
+              t = rbf(t);
+              if (bias) t = rbf(t + bv);
+            } else {
+              t = rbf(t + bv);
+            }
+            if (relu && t < 0.f) t = 0.f;
+            if (residual) t = rbf(bf2f(residual[(m0 + i) * N + n0 + j]) + t);
+            y[(m0 + i) * N + n0 + j] = f2bf(t);
+          }
+      }
+    }
+    free(wf);
+  }
+  free(xf);
+}
+
+/* Rows of a fresh K or V projection [B,T,h,d] written into the seq-major cache [Smax,B,h,d] at
+ * positions pos0..pos0+T-1: key.permute(1,0,2,3) then cache[:T] = ... (attentions.py:457-458,475-476)
+ * and cache[cur_len] = new row in decode (attentions.py:490-491). */
+void lia_oracle_kv_store(const bf16_t* kv, bf16_t* cache, int B, int T, int hd, int pos0) {
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t)
+      memcpy(cache + ((long)(pos0 + t) * B + b) * hd, kv + ((long)b * T + t) * hd, (size_t)hd * sizeof(bf16_t));
+}
+
+/* Attention with the GPU-policy rounding points (policy 0 / 3), attentions.py:443-536:
+ *   q  = bf16(q * scaling)                                   (:456)
+ *   s  = bf16(q . k)            torch.bmm output             (:499)
+ *   prefill only: s + causal mask in fp32, clamp, cast bf16 -> masked entries become -inf (:500-509)
+ *   p  = bf16(softmax(s)), fp32 inside                       (:512)
+ *   o  = bf16(p . v)            torch.bmm output             (:529)
+ * q is [B,T,h,d]; K/V are read from the seq-major cache [Smax,B,h,d] rows 0..S-1 (for decode the
+ * reference concatenates cache rows with the new row (:397-399) -- same values as reading the cache
+ * after the row has been stored).  Query t attends to keys j <= S-T+t when causal.  out is [B,T,h*d]. */
+void lia_oracle_attn_gpu(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* out, int B, int T, int S,
+                         int h, int d, float scaling, int causal) {
+  const long hd = (long)h * d;
+#pragma omp parallel
+  {
+    float* s = (float*)malloc((size_t)S * sizeof(float));
+    float* qs = (float*)malloc((size_t)d * sizeof(float));
+    float* o = (float*)malloc((size_t)d * sizeof(float));
+#pragma omp for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+      for (int hh = 0; hh < h; ++hh)
+        for (int t = 0; t < T; ++t) {
+          const bf16_t* qp = q + ((long)b * T + t) * hd + (long)hh * d;
+          for (int i = 0; i < d; ++i) qs[i] = rbf(bf2f(qp[i]) * scaling);
+          int lim = causal ? S - T + t : S - 1;
+          float mx = -INFINITY;
+          for (int j = 0; j <= lim; ++j) {
+            const bf16_t* kp = kc + ((long)j * B + b) * hd + (long)hh * d;
+            float a = 0.f;
+            for (int i = 0; i < d; ++i) a += qs[i] * bf2f(kp[i]);
+            s[j] = rbf(a);
+            if (s[j] > mx) mx = s[j];
+          }
+          float sum = 0.f;
+          for (int j = 0; j <= lim; ++j) {
+            s[j] = expf(s[j] - mx);
+            sum += s[j];
+          }
+          for (int i = 0; i < d; ++i) o[i] = 0.f;
+          for (int j = 0; j <= lim; ++j) {
+            float p = rbf(s[j] / sum);
+            const bf16_t* vp = vc + ((long)j * B + b) * hd + (long)hh * d;
+            for (int i = 0; i < d; ++i) o[i] += p * bf2f(vp[i]);
+          }
+          bf16_t* op = out + ((long)b * T + t) * hd + (long)hh * d;
+          for (int i = 0; i < d; ++i) op[i] = f2bf(o[i]);
+        }
+    free(s);
+    free(qs);
+    free(o);
+  }
+}
+
+/* Attention with the CPU-policy arithmetic (policy 1 / 2): the indirect-access-KV masked MHA kernel,
+ * Krnl.cpp:513-842 (decode) and its first-token flash path :1257-1345.  Scores, softmax and the
+ * weighted V sum stay in fp32 (reduce_head / mul_attenion_weights_and_value_of_head convert bf16 inputs
+ * to fp32 and never round in between); score = q.k / scale_factor + mask (:676-691, mask is zero for
+ * equal-length prompts); one rounding at the output (move_ker :826-828).  The kernel also WRITES the new
+ * K/V rows into the cache (:588-613,:740-764) -- lia_oracle_kv_store before this call does the same.
+ * beam_idx indirection is the identity for greedy search (Krnl.cpp:1393-1402). */
+void lia_oracle_attn_cpu(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* out, int B, int T, int S,
+                         int h, int d, float scale_factor, int causal) {
+  const long hd = (long)h * d;
+#pragma omp parallel
+  {
+    float* s = (float*)malloc((size_t)S * sizeof(float));
+    float* o = (float*)malloc((size_t)d * sizeof(float));
+#pragma omp for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+      for (int hh = 0; hh < h; ++hh)
+        for (int t = 0; t < T; ++t) {
+          const bf16_t* qp = q + ((long)b * T + t) * hd + (long)hh * d;
+          int lim = causal ? S - T + t : S - 1;
+          float mx = -INFINITY;
+          for (int j = 0; j <= lim; ++j) {
+            const bf16_t* kp = kc + ((long)j * B + b) * hd + (long)hh * d;
+            float a = 0.f;
+            for (int i = 0; i < d; ++i) a += bf2f(qp[i]) * bf2f(kp[i]);
+            s[j] = a / scale_factor;
+            if (s[j] > mx) mx = s[j];
+          }
+          float sum = 0.f;
+          for (int j = 0; j <= lim; ++j) {
+            s[j] = expf(s[j] - mx);
+            sum += s[j];
+          }
+          for (int i = 0; i < d; ++i) o[i] = 0.f;
+          for (int j = 0; j <= lim; ++j) {
+            float p = s[j] / sum;
+            const bf16_t* vp = vc + ((long)j * B + b) * hd + (long)hh * d;
+            for (int i = 0; i < d; ++i) o[i] += p * bf2f(vp[i]);
+          }
+          bf16_t* op = out + ((long)b * T + t) * hd + (long)hh * d;
+          for (int i = 0; i < d; ++i) op[i] = f2bf(o[i]);
+        }
+    free(s);
+    free(o);
+  }
+}
+
+/* One OPT decoder layer, OPTDecoderLayer_forward (decoder.py:172-335) + _OPTAttention_forward
+ * (attentions.py:312-557), do_layer_norm_before = True (all sizes but 350m).
+ *
+ *   policy 0 : linears + attention with GPU rounding points; K/V rows land in a host-side cache
+ *   policy 3 : same arithmetic, cache lives on the device            (policy table modeling_opt.py:1167-1176)
+ *   policy 2 : linears with GPU rounding points, attention with CPU arithmetic
+ *   policy 1 : everything with CPU arithmetic (fused-bias linears)
+ *
+ * weights[16] in create_buffer order (lia/modeling_opt.py:90-126), linears row-major [N,K].
+ * x,y: [B,T,H].  kc/vc: [Smax,B,h,d]; rows pos0..pos0+T-1 are written, rows 0..pos0+T-1 attended.
+ * Prefill: pos0 = 0, T = prompt length (causal).  Decode: T = 1, pos0 = tokens already cached. */
+void lia_oracle_layer_forward(int policy, const bf16_t* const* weights, const bf16_t* x, bf16_t* y, bf16_t* kc,
+                              bf16_t* vc, int B, int T, int pos0, int H, int heads, int F, float eps) {
+  const int d = H / heads;
+  const long M = (long)B * T;
+  const int gpu_linear = (policy == 0 || policy == 2 || policy == 3);
+  const int gpu_attn = (policy == 0 || policy == 3);
+  const int S = pos0 + T;
+  bf16_t* ln = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* qb = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* kb = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* vb = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* ao = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* h1 = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* f1 = (bf16_t*)malloc((size_t)M * F * 2);
+
+  lia_oracle_layernorm(x, weights[0], weights[1], ln, M, H, eps);
+  lia_oracle_linear(ln, weights[4], weights[5], NULL, kb, M, H, H, 0, gpu_linear);
+  lia_oracle_linear(ln, weights[6], weights[7], NULL, vb, M, H, H, 0, gpu_linear);
+  lia_oracle_linear(ln, weights[2], weights[3], NULL, qb, M, H, H, 0, gpu_linear);
+  lia_oracle_kv_store(kb, kc, B, T, H, pos0);
+  lia_oracle_kv_store(vb, vc, B, T, H, pos0);
+  if (gpu_attn)
+    lia_oracle_attn_gpu(qb, kc, vc, ao, B, T, S, heads, d, 1.0f / sqrtf((float)d), T > 1);
+  else
+    lia_oracle_attn_cpu(qb, kc, vc, ao, B, T, S, heads, d, sqrtf((float)d), T > 1);
+  lia_oracle_linear(ao, weights[8], weights[9], x, h1, M, H, H, 0, gpu_linear);
+  lia_oracle_layernorm(h1, weights[10], weights[11], ln, M, H, eps);
+  lia_oracle_linear(ln, weights[12], weights[13], NULL, f1, M, F, H, 1, gpu_linear);
+  lia_oracle_linear(f1, weights[14], weights[15], h1, y, M, H, F, 0, gpu_linear);
+
+  free(ln); free(qb); free(kb); free(vb); free(ao); free(h1); free(f1);
+}
+
+/* hidden = embed_tokens[ids] + embed_positions[pos + 2], one bf16 add.
+ * lia/modeling_opt.py:1108 (token embedding), :357-378 (OPTLearnedPositionalEmbedding: positions =
+ * cumsum(mask)*mask - 1, cut to the last T, + offset 2), :1142 (sum).  Mask is all ones. */
+void lia_oracle_embed(const int64_t* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* y, int B, int T,
+                      int past_len, int H) {
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t) {
+      const bf16_t* te = tok + ids[(long)b * T + t] * (long)H;
+      const bf16_t* pe = pos + (long)(past_len + t + 2) * H;
+      bf16_t* yo = y + ((long)b * T + t) * H;
+      for (int i = 0; i < H; ++i) yo[i] = f2bf(bf2f(te[i]) + bf2f(pe[i]));
+    }
+}
+
+/* Final LN on the last position only + tied lm_head (no bias) + greedy argmax.
+ * modeling_opt.py:1563 (final_layer_norm), models.py:424-431 (hidden[:, -1:, :] then lm_head),
+ * greedy_search.py:367,395 (argmax of logits[:, -1, :]; first maximal index on ties).
+ * hidden: [B,T,H]; logits out: [B,vocab] bf16; next: [B]. */
+void lia_oracle_lm_head(const bf16_t* hidden, const bf16_t* lnw, const bf16_t* lnb, const bf16_t* emb,
+                        bf16_t* logits, int64_t* next, int B, int T, int H, int vocab, float eps) {
+  bf16_t* last = (bf16_t*)malloc((size_t)B * H * 2);
+  bf16_t* lno = (bf16_t*)malloc((size_t)B * H * 2);
+  for (int b = 0; b < B; ++b) memcpy(last + (long)b * H, hidden + ((long)b * T + T - 1) * H, (size_t)H * 2);
+  lia_oracle_layernorm(last, lnw, lnb, lno, B, H, eps);
+  lia_oracle_linear(lno, emb, NULL, NULL, logits, B, vocab, H, 0, 1);
+  for (int b = 0; b < B; ++b) {
+    int best = 0;
+    float bv = bf2f(logits[(long)b * vocab]);
+    for (int v = 1; v < vocab; ++v) {
+      float f = bf2f(logits[(long)b * vocab + v]);
+      if (f > bv) { bv = f; best = v; }
+    }
+    next[b] = best;
+  }
+  free(last);
+  free(lno);
+}
