@@ -1,0 +1,178 @@
+/*
+ * lia_hip.h -- C ABI of liblia_hip.so: the MI355X-native replacement for the GPU side and the
+ * host-memory tiers of LIA's weight-offloaded cooperative decoder.
+ *
+ * Plain pointers and sizes only; no torch / HIP types in any signature (streams travel as void*,
+ * which is a hipStream_t).  Every function returns 0 (LIA_OK) or a negative LIA_ERR_* code and never
+ * throws; lia_last_error() gives the text.  The caller owns every buffer it passes in; the library
+ * owns only its context, streams, events and workspace.  A context is re-entrant across contexts, not
+ * thread-safe within one (the reference drives everything from one Python thread,
+ * lia/modeling_opt.py:1208-1212).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference tree;
+ *   decoder.py    = intel_extension_for_pytorch/transformers/models/reference/modules/decoder.py
+ *   attentions.py = intel_extension_for_pytorch/transformers/models/reference/modules/attentions.py
+ *   modeling_opt.py = lia/modeling_opt.py).
+ * INTEGRATION.md shows the ctypes stubs a reference maintainer would add.
+ *
+ * All activations / weights are bf16 (uint16 bit patterns).  Linear weights are ROW-MAJOR [N, K]
+ * (the reference's TPP-blocked [N/16,K/64,32,16,2] wire format, _weight_prepack.py:19-63, is converted
+ * once on the host by lia_tpp_unblock, not on every use as attentions.py:381-382 does).
+ */
+#ifndef LIA_HIP_H
+#define LIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIA_OK 0
+#define LIA_ERR_INVALID (-1) /* bad shape / argument           -> Python ValueError  (attentions.py:503,516,532) */
+#define LIA_ERR_MEMORY (-2)  /* allocation / pinning failed    -> Python MemoryError (modeling_opt.py:175)       */
+#define LIA_ERR_HIP (-3)     /* HIP runtime error              -> Python RuntimeError                            */
+#define LIA_ERR_MISSING (-4) /* a required tensor is NULL      -> Python AttributeError (modeling_opt.py:110,126) */
+
+typedef uint16_t lia_bf16;
+typedef struct lia_ctx lia_ctx;
+typedef struct lia_streamer lia_streamer;
+
+const char* lia_last_error(void);
+const char* lia_version(void);
+
+/* ---- context ----------------------------------------------------------------------------------
+ * Replaces the per-forward stream/buffer setup of OPTDecoder.forward (modeling_opt.py:1178-1220).
+ * workspace_bytes: device scratch for one layer call (see lia_layer_workspace_bytes). */
+int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out);
+void lia_ctx_destroy(lia_ctx* ctx);
+void* lia_ctx_compute_stream(lia_ctx* ctx); /* hipStream_t created by the context */
+int lia_ctx_synchronize(lia_ctx* ctx);
+int lia_ctx_set_host_threads(lia_ctx* ctx, int n); /* OpenMP threads of the policy-2 host attention */
+
+/* ---- layer description and the 16-tensor weight set --------------------------------------------
+ * Order fixed by create_buffer (modeling_opt.py:90-126) and consumed by index in decoder.py /
+ * attentions.py:  0 ln1.w 1 ln1.b 2 q.w 3 q.b 4 k.w 5 k.b 6 v.w 7 v.b 8 out.w 9 out.b
+ *                10 ln2.w 11 ln2.b 12 fc1.w 13 fc1.b 14 fc2.w 15 fc2.b                        */
+typedef struct {
+  int hidden; /* H */
+  int heads;  /* h, head_dim = H / h in {32, 64, 128} */
+  int ffn;    /* F */
+  float ln_eps;
+} lia_layer_desc;
+
+/* Byte offsets of the 16 tensors inside one packed, 256-byte-aligned flat layer buffer -- the unit
+ * the weight streamer moves (replaces 16 separate copy_ calls of load_layer, modeling_opt.py:270-293).
+ * q.w|k.w|v.w and q.b|k.b|v.b are adjacent so the projection runs as one [3H,H] GEMM. */
+int lia_layer_pack_offsets(const lia_layer_desc* d, size_t offsets[16], size_t* total_bytes);
+size_t lia_layer_workspace_bytes(const lia_layer_desc* d, int max_rows /* B*T of one call */);
+
+/* KV cache of one layer: seq-major [smax][batch][heads][head_dim] exactly like the reference's
+ * past_key_value[1], [2] (attentions.py:462-476); the length is an explicit int instead of the shape of
+ * a dummy tensor (attentions.py:464-470). */
+typedef struct {
+  lia_bf16* k;
+  lia_bf16* v;
+  int smax;
+  int batch;     /* batch rows of the cache (row pitch) */
+  int on_device; /* 1: k/v are device pointers (policy 3); 0: host pointers (policy 0 / 2)  */
+} lia_kv;
+
+/* ---- the operator boundary ----------------------------------------------------------------------
+ * One decoder layer = decoder_layer(hidden, attention_mask=, past_key_value=, gpu_layer=, policy=,
+ * max_new_tokens=) i.e. _IPEXDecoderLayerRef.forward -> OPTDecoderLayer_forward (decoder.py:172-335)
+ * + _OPTAttention_forward (attentions.py:312-557).
+ *
+ *   policy 0 : everything on the GPU, K/V rows delivered to a HOST cache (prefill: rows [0,T) of batch
+ *              rows [b0, b0+B) via the context's D2H stream; completion = lia_ctx_kv_store_wait)
+ *   policy 3 : everything on the GPU, cache on the device (resident layers)
+ *   policy 2 : LN + linears on the GPU, attention on the host over the host cache (decode only)
+ *   policy 1 : not a GPU policy -- LIA_ERR_INVALID (the all-CPU path lives in lia_host_*)
+ *
+ * weights[16]: DEVICE pointers (resident copy or a streamer slot).  x, y: device [B, T, H], may not
+ * alias.  pos0 = tokens already in the cache; rows pos0..pos0+T-1 are written, 0..pos0+T-1 attended
+ * (causal inside the new block).  b0 = first cache batch row served by this call (minibatch offset,
+ * modeling_opt.py:1283-1339).  Asynchronous on `stream` except policy 2, which blocks the caller while
+ * the host attends. */
+int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
+                      const lia_bf16* x, lia_bf16* y, lia_kv* kv, int B, int T, int pos0, int b0, void* stream);
+int lia_ctx_kv_store_wait(lia_ctx* ctx); /* host-blocks until every policy-0 K/V delivery has landed */
+
+/* ---- individual sub-layer ops (same kernels the layer call uses; exposed for parity tests) ------ */
+/* F.layer_norm, decoder.py:107-119 */
+int lia_layernorm(const lia_bf16* x, long ldx, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long ldy, long rows,
+                  int H, float eps, void* stream);
+/* torch.matmul(x, w.t()) + bias [relu] [residual + .], decoder.py:79-105,229,310; attentions.py:393-394,418.
+ * y[M,N] row-major with leading dimension ldy.  bias / residual may be NULL.  split_k: 0 = heuristic. */
+int lia_linear(lia_ctx* ctx, const lia_bf16* x, long ldx, const lia_bf16* w, const lia_bf16* bias,
+               const lia_bf16* residual, long ldr, lia_bf16* y, long ldy, int M, int N, int K, int relu, int split_k,
+               void* stream);
+/* fused q|k|v projection: q -> qout [M,H]; k,v rows scattered into the seq-major cache slab
+ * (attentions.py:393-394,418,457-458,475-476,490-491).  w = [3H,H], bias = [3H]. */
+int lia_qkv_project(lia_ctx* ctx, const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, lia_bf16* qout,
+                    lia_bf16* kcache, lia_bf16* vcache, int B, int T, int H, int cache_batch, int b0, int pos0,
+                    void* stream);
+/* GPU attention, attentions.py:443-536.  q [B,T,H] (ldq elements per token row); cache [S][cache_batch][h][d]. */
+int lia_attention(const lia_bf16* q, long ldq, const lia_bf16* kcache, const lia_bf16* vcache, lia_bf16* out, long ldo,
+                  int B, int T, int S, int heads, int head_dim, int cache_batch, int b0, void* stream);
+/* embed_tokens + embed_positions, modeling_opt.py:1108,357-378,1142 */
+int lia_embed(const int64_t* ids, const lia_bf16* tok, const lia_bf16* pos, lia_bf16* y, int B, int T, int past_len, int H,
+              void* stream);
+/* final LN on the last position + tied lm_head + greedy argmax: modeling_opt.py:1563, models.py:424-431,
+ * greedy_search.py:367,395.  scratch: device, >= 2*B*H bf16.  logits [B,vocab], next_ids [B] (device). */
+int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* lnw, const lia_bf16* lnb,
+                const lia_bf16* emb, int vocab, float eps, lia_bf16* logits, int64_t* next_ids, void* stream);
+
+/* ---- host side of the cooperative policies -------------------------------------------------------
+ * Indirect-access-KV masked MHA, csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp:513-842: fp32
+ * scores / softmax / weighted sum over a host cache, new K/V rows written in place.  q,k,v: [B,T,h*d]
+ * host; cache [smax][cache_batch][h][d] host; rows pos0.. written, 0..pos0+T-1 attended. */
+int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const lia_bf16* v, lia_bf16* kcache, lia_bf16* vcache,
+                       lia_bf16* out, int B, int T, int pos0, int heads, int head_dim, int cache_batch, int b0,
+                       int n_threads);
+
+/* ---- weight streamer ------------------------------------------------------------------------------
+ * Replaces load_layer / layer_copy under torch.cuda.stream(load_weight_stream) + device-wide syncs
+ * (modeling_opt.py:270-318,1287-1312,1508-1515): n_slots HBM slots, one pinned hipMemcpyAsync per packed
+ * layer on a dedicated copy stream, event handshakes with the compute stream. */
+int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, lia_streamer** out);
+void lia_stream_destroy(lia_streamer* s);
+void* lia_stream_slot_ptr(lia_streamer* s, int slot);
+/* enqueue host -> slot; first waits (on the copy stream) until the slot's last consumer released it.
+ * pinned = 0 stages through the streamer's pinned bounce buffer (the reference's cpu_buff path,
+ * modeling_opt.py:1219-1220, 1289-1292). */
+int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t bytes, int pinned);
+int lia_stream_wait(lia_streamer* s, int slot, void* compute_stream);    /* compute waits for the copy  */
+int lia_stream_release(lia_streamer* s, int slot, void* compute_stream); /* slot reusable after this    */
+/* bytes copied and copy-engine busy milliseconds since the last reset (hipEvent timing on the copy stream) */
+int lia_stream_stats(lia_streamer* s, double* bytes, double* busy_ms, int reset);
+void* lia_stream_copy_stream(lia_streamer* s);
+
+/* ---- host memory tiers ------------------------------------------------------------------------------
+ * The four exports of the reference's libnuma shim, lia/cxl/numa_alloc.c:7,25,66,108 (same names, same
+ * NULL-on-failure + stderr behaviour), with the interleave node set configurable instead of hard-coded
+ * {2,3} (numa_alloc.c:80-81): lia_numa_set_interleave_nodes or env LIA_CXL_NODES="2,3". */
+void* numa_alloc_node(size_t size, int node);
+void* numa_alloc_interleave(size_t size);
+void numa_free_node(void* memory, size_t size);
+void check_memory_node(void* memory, int num);
+int lia_numa_set_interleave_nodes(const int* nodes, int n);
+int lia_numa_available(void);
+/* make a host range DMA-able by the copy engine (hipHostRegister); the reference leaves CXL tensors
+ * pageable (numa_alloc.py:49) so its copies degrade to staged synchronous ones */
+int lia_numa_register(void* ptr, size_t size);
+int lia_numa_unregister(void* ptr);
+/* pinned host memory (Tensor.pin_memory(), modeling_opt.py:207-227) */
+void* lia_host_alloc_pinned(size_t size);
+void lia_host_free_pinned(void* p);
+
+/* TPP-blocked [N/16,K/64,32,16,2] <-> row-major [N,K] on the host (_weight_prepack.py:19-63;
+ * attentions.py:381-382) */
+int lia_tpp_unblock(const lia_bf16* blocked, lia_bf16* plain, int N, int K);
+int lia_tpp_block(const lia_bf16* plain, lia_bf16* blocked, int N, int K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIA_HIP_H */

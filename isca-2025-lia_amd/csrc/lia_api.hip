@@ -1,0 +1,633 @@
+// C ABI of liblia_hip.so (include/lia_hip.h): context, the decoder-layer operator, the sub-layer ops,
+// the weight streamer and pinned host memory.  Kernels live in lia_gemm.hip / lia_attention.hip /
+// lia_elementwise.hip, host-side cooperative code in lia_host.cpp.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/lia_hip.h"
+#include "lia_common.h"
+
+// kernels' host launchers
+extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
+                               const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
+                               int force_split, hipStream_t st);
+extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
+                                     long rows, int H, float eps, hipStream_t st);
+extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* y, int B, int T,
+                                 int past_len, int H, hipStream_t st);
+extern "C" void lia_argmax_launch(const bf16_t* logits, int64_t* out, int B, int vocab, hipStream_t st);
+extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
+                                       int B, int T, int heads, int d, int Bc, int b0, hipStream_t st);
+extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
+                                      int B, int S, int heads, int d, int Bc, int b0, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+extern "C" void lia_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* lia_last_error(void) { return g_err; }
+extern "C" const char* lia_version(void) { return "lia_hip 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      lia_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return _e == hipErrorOutOfMemory ? LIA_ERR_MEMORY : LIA_ERR_HIP;                      \
+    }                                                                                        \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct lia_ctx {
+  int device;
+  hipStream_t compute;
+  hipStream_t d2h;           // K/V delivery to the host cache (policy 0)
+  char* ws;
+  size_t ws_bytes;
+  hipEvent_t slab_ready[2];  // recorded on compute when a K/V slab may be copied out
+  hipEvent_t slab_done[2];   // recorded on d2h when the slab has been delivered
+  bool slab_used[2];
+  int slab_next;
+  char* host_stage;          // pinned: q|k|v and attention output of the policy-2 round trip
+  size_t host_stage_bytes;
+  int host_threads;
+  long last_rows, last_slab_rows;  // workspace layout of the previous layer call
+};
+
+extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out) {
+  if (!out) return LIA_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) {
+    lia_set_error("lia_ctx_create: device %d not present (%d devices)", device, n);
+    return LIA_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(device));
+  lia_ctx* c = new lia_ctx();
+  memset(c, 0, sizeof(*c));
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&c->slab_ready[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->slab_done[i], hipEventDisableTiming));
+  }
+  c->ws_bytes = workspace_bytes;
+  if (workspace_bytes) HIP_TRY(hipMalloc((void**)&c->ws, workspace_bytes));
+  *out = c;
+  return LIA_OK;
+}
+
+extern "C" void lia_ctx_destroy(lia_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->compute);
+  (void)hipStreamSynchronize(c->d2h);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipEventDestroy(c->slab_ready[i]);
+    (void)hipEventDestroy(c->slab_done[i]);
+  }
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->host_stage) (void)hipHostFree(c->host_stage);
+  (void)hipStreamDestroy(c->compute);
+  (void)hipStreamDestroy(c->d2h);
+  delete c;
+}
+
+extern "C" void* lia_ctx_compute_stream(lia_ctx* c) { return c ? (void*)c->compute : nullptr; }
+
+extern "C" int lia_ctx_synchronize(lia_ctx* c) {
+  if (!c) return LIA_ERR_INVALID;
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  HIP_TRY(hipStreamSynchronize(c->d2h));
+  return LIA_OK;
+}
+
+extern "C" int lia_ctx_set_host_threads(lia_ctx* c, int n) {
+  if (!c || n < 0) return LIA_ERR_INVALID;
+  c->host_threads = n;
+  return LIA_OK;
+}
+
+extern "C" int lia_ctx_kv_store_wait(lia_ctx* c) {
+  if (!c) return LIA_ERR_INVALID;
+  HIP_TRY(hipStreamSynchronize(c->d2h));
+  return LIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed layer layout / workspace sizing
+// ------------------------------------------------------------------------------------------------
+static int check_desc(const lia_layer_desc* d) {
+  if (!d) return LIA_ERR_INVALID;
+  if (d->hidden <= 0 || d->heads <= 0 || d->ffn <= 0 || d->hidden % d->heads) {
+    lia_set_error("layer desc: hidden=%d heads=%d ffn=%d", d->hidden, d->heads, d->ffn);
+    return LIA_ERR_INVALID;
+  }
+  int hd = d->hidden / d->heads;
+  if (!(hd == 32 || hd == 64 || hd == 128) || d->hidden % 64 || d->ffn % 64) {
+    lia_set_error("layer desc: head_dim %d must be 32/64/128 and hidden, ffn multiples of 64", hd);
+    return LIA_ERR_INVALID;
+  }
+  return LIA_OK;
+}
+
+extern "C" int lia_layer_pack_offsets(const lia_layer_desc* d, size_t off[16], size_t* total) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  const size_t H = d->hidden, F = d->ffn;
+  size_t p = 0;
+  auto put = [&](int idx, size_t elems, bool align) {
+    if (align) p = align_up(p, 256);
+    off[idx] = p;
+    p += elems * 2;
+  };
+  // q.w | k.w | v.w contiguous = one [3H,H] operand; q.b | k.b | v.b contiguous = one [3H] bias
+  put(2, H * H, true);  put(4, H * H, false);  put(6, H * H, false);
+  put(3, H, true);      put(5, H, false);      put(7, H, false);
+  put(8, H * H, true);  put(9, H, true);
+  put(12, F * H, true); put(13, F, true);
+  put(14, H * F, true); put(15, H, true);
+  put(0, H, true);      put(1, H, true);
+  put(10, H, true);     put(11, H, true);
+  if (total) *total = align_up(p, 256);
+  return LIA_OK;
+}
+
+struct WsLayout {
+  size_t ln, q, k, v, attn, h1, f1, slab[2], gemm, total;
+  size_t gemm_bytes;
+};
+
+static WsLayout ws_layout(const lia_layer_desc* d, long rows, long slab_rows) {
+  WsLayout w;
+  const size_t H = d->hidden, F = d->ffn, R = (size_t)rows;
+  size_t p = 0;
+  auto take = [&](size_t bytes) { size_t o = p; p = align_up(p + bytes, 256); return o; };
+  w.ln = take(R * H * 2);
+  w.q = take(R * H * 2);   // q | k | v contiguous: the policy-2 round trip moves them in one copy
+  w.k = take(R * H * 2);
+  w.v = take(R * H * 2);
+  w.attn = take(R * H * 2);
+  w.h1 = take(R * H * 2);
+  w.f1 = take(R * F * 2);
+  w.slab[0] = take(2 * (size_t)slab_rows * H * 2);
+  w.slab[1] = take(2 * (size_t)slab_rows * H * 2);
+  w.gemm_bytes = rows <= 256 ? (size_t)8 * R * std::max(3 * H, F) * 4 : 0;
+  w.gemm = take(w.gemm_bytes);
+  w.total = p;
+  return w;
+}
+
+extern "C" size_t lia_layer_workspace_bytes(const lia_layer_desc* d, int max_rows) {
+  if (check_desc(d) || max_rows <= 0) return 0;
+  return ws_layout(d, max_rows, max_rows).total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sub-layer ops
+// ------------------------------------------------------------------------------------------------
+static LiaOutMap plain_out(bf16_t* y, long ldy, int N) {
+  LiaOutMap om;
+  memset(&om, 0, sizeof(om));
+  om.base[0] = y;
+  om.ld[0] = ldy;
+  om.seg_n = N;
+  om.T = 1;
+  return om;
+}
+
+extern "C" int lia_layernorm(const lia_bf16* x, long ldx, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long ldy,
+                             long rows, int H, float eps, void* stream) {
+  if (!x || !g || !b || !y) { lia_set_error("lia_layernorm: NULL tensor"); return LIA_ERR_MISSING; }
+  if (rows < 0 || H <= 0 || H % 8) { lia_set_error("lia_layernorm: rows=%ld H=%d (H %% 8)", rows, H); return LIA_ERR_INVALID; }
+  lia_layernorm_launch(x, ldx, g, b, y, ldy, rows, H, eps, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+static int gemm_checked(lia_ctx* ctx, const bf16_t* x, long ldx, const bf16_t* w, int M, int N, int K,
+                        const LiaEpilogue& ep, const LiaOutMap& om, float* ws, size_t ws_bytes, int split, hipStream_t st) {
+  (void)ctx;
+  if (N % 16 || K % 64) {
+    lia_set_error("linear: N=%d must be a multiple of 16 and K=%d of 64", N, K);
+    return LIA_ERR_INVALID;
+  }
+  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, split, st);
+  if (rc) { lia_set_error("linear: unsupported shape M=%d N=%d K=%d", M, N, K); return LIA_ERR_INVALID; }
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+extern "C" int lia_linear(lia_ctx* ctx, const lia_bf16* x, long ldx, const lia_bf16* w, const lia_bf16* bias,
+                          const lia_bf16* residual, long ldr, lia_bf16* y, long ldy, int M, int N, int K, int relu,
+                          int split_k, void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  if (!x || !w || !y) { lia_set_error("lia_linear: NULL tensor"); return LIA_ERR_MISSING; }
+  if (M < 0 || N <= 0 || K <= 0) { lia_set_error("lia_linear: M=%d N=%d K=%d", M, N, K); return LIA_ERR_INVALID; }
+  LiaEpilogue ep{bias, residual, ldr, relu};
+  LiaOutMap om = plain_out(y, ldy, N);
+  size_t need = M <= 256 ? (size_t)8 * M * N * 4 : 0;
+  size_t have = std::min(need, ctx->ws_bytes);
+  return gemm_checked(ctx, x, ldx, w, M, N, K, ep, om, (float*)ctx->ws, have, split_k, (hipStream_t)stream);
+}
+
+static int qkv_project(lia_ctx* ctx, const bf16_t* x, const bf16_t* w, const bf16_t* bias, bf16_t* qout, bf16_t* kdst,
+                       bf16_t* vdst, bool kv_cache_mode, int B, int T, int H, int cache_batch, int b0, int pos0,
+                       float* ws, size_t ws_bytes, hipStream_t st) {
+  LiaEpilogue ep{bias, nullptr, 0, 0};
+  LiaOutMap om;
+  memset(&om, 0, sizeof(om));
+  om.base[0] = qout; om.base[1] = kdst; om.base[2] = vdst;
+  om.ld[0] = om.ld[1] = om.ld[2] = H;
+  om.cache_mode[1] = om.cache_mode[2] = kv_cache_mode ? 1 : 0;
+  om.seg_n = H; om.T = T; om.Bc = cache_batch; om.b0 = b0; om.pos0 = pos0;
+  return gemm_checked(ctx, x, H, w, B * T, 3 * H, H, ep, om, ws, ws_bytes, 0, st);
+}
+
+extern "C" int lia_qkv_project(lia_ctx* ctx, const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, lia_bf16* qout,
+                               lia_bf16* kcache, lia_bf16* vcache, int B, int T, int H, int cache_batch, int b0, int pos0,
+                               void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  if (!x || !w || !qout || !kcache || !vcache) { lia_set_error("lia_qkv_project: NULL tensor"); return LIA_ERR_MISSING; }
+  if (B <= 0 || T <= 0 || b0 < 0 || b0 + B > cache_batch || pos0 < 0) {
+    lia_set_error("lia_qkv_project: B=%d T=%d cache_batch=%d b0=%d pos0=%d", B, T, cache_batch, b0, pos0);
+    return LIA_ERR_INVALID;
+  }
+  size_t need = (size_t)B * T <= 256 ? (size_t)8 * B * T * 3 * H * 4 : 0;
+  return qkv_project(ctx, x, w, bias, qout, kcache, vcache, true, B, T, H, cache_batch, b0, pos0, (float*)ctx->ws,
+                     std::min(need, ctx->ws_bytes), (hipStream_t)stream);
+}
+
+extern "C" int lia_attention(const lia_bf16* q, long ldq, const lia_bf16* kcache, const lia_bf16* vcache, lia_bf16* out,
+                             long ldo, int B, int T, int S, int heads, int head_dim, int cache_batch, int b0, void* stream) {
+  if (!q || !kcache || !vcache || !out) { lia_set_error("lia_attention: NULL tensor"); return LIA_ERR_MISSING; }
+  if (B <= 0 || T <= 0 || S < T || b0 < 0 || b0 + B > cache_batch) {
+    lia_set_error("lia_attention: B=%d T=%d S=%d cache_batch=%d b0=%d", B, T, S, cache_batch, b0);
+    return LIA_ERR_INVALID;
+  }
+  int rc;
+  if (T == 1) {
+    rc = lia_attn_decode_launch(q, ldq, kcache, vcache, out, ldo, B, S, heads, head_dim, cache_batch, b0, (hipStream_t)stream);
+  } else {
+    if (S != T) { lia_set_error("lia_attention: multi-token blocks only as a prefill (S == T), got S=%d T=%d", S, T); return LIA_ERR_INVALID; }
+    rc = lia_attn_prefill_launch(q, ldq, kcache, vcache, out, ldo, B, T, heads, head_dim, cache_batch, b0, (hipStream_t)stream);
+  }
+  if (rc) { lia_set_error("lia_attention: head_dim %d unsupported (32/64/128) or S=%d too long", head_dim, S); return LIA_ERR_INVALID; }
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+extern "C" int lia_embed(const int64_t* ids, const lia_bf16* tok, const lia_bf16* pos, lia_bf16* y, int B, int T,
+                         int past_len, int H, void* stream) {
+  if (!ids || !tok || !pos || !y) { lia_set_error("lia_embed: NULL tensor"); return LIA_ERR_MISSING; }
+  if (B <= 0 || T <= 0 || past_len < 0 || H % 8) { lia_set_error("lia_embed: B=%d T=%d past=%d H=%d", B, T, past_len, H); return LIA_ERR_INVALID; }
+  lia_embed_launch(ids, tok, pos, y, B, T, past_len, H, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+extern "C" int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* lnw,
+                           const lia_bf16* lnb, const lia_bf16* emb, int vocab, float eps, lia_bf16* logits,
+                           int64_t* next_ids, void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  if (!hidden || !lnw || !lnb || !emb || !logits || !next_ids) { lia_set_error("lia_lm_head: NULL tensor"); return LIA_ERR_MISSING; }
+  if (B <= 0 || B > 256 || T <= 0 || vocab % 16) { lia_set_error("lia_lm_head: B=%d (<=256) T=%d vocab=%d (%%16)", B, T, vocab); return LIA_ERR_INVALID; }
+  size_t scratch = align_up((size_t)B * H * 2, 256);
+  size_t gemm_need = (size_t)8 * B * vocab * 4;
+  if (ctx->ws_bytes < scratch) { lia_set_error("lia_lm_head: workspace too small"); return LIA_ERR_MEMORY; }
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* lno = (bf16_t*)ctx->ws;
+  // hidden[:, -1, :] -> final LN (lia/modeling_opt.py:1563 applies it to all positions; only the last one feeds
+  // lm_head, models.py:424-431, and LN is row-wise, so the other rows are never needed)
+  lia_layernorm_launch(hidden + (long)(T - 1) * H, (long)T * H, lnw, lnb, lno, H, B, H, eps, st);
+  LiaEpilogue ep{nullptr, nullptr, 0, 0};
+  LiaOutMap om = plain_out(logits, vocab, vocab);
+  size_t have = ctx->ws_bytes - scratch;
+  int rc = gemm_checked(ctx, lno, H, emb, B, vocab, H, ep, om, (float*)(ctx->ws + scratch), std::min(have, gemm_need), 0, st);
+  if (rc) return rc;
+  lia_argmax_launch(logits, next_ids, B, vocab, st);
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the decoder-layer operator
+// ------------------------------------------------------------------------------------------------
+static int ensure_host_stage(lia_ctx* c, size_t bytes) {
+  if (c->host_stage_bytes >= bytes) return LIA_OK;
+  if (c->host_stage) (void)hipHostFree(c->host_stage);
+  c->host_stage = nullptr;
+  c->host_stage_bytes = 0;
+  HIP_TRY(hipHostMalloc((void**)&c->host_stage, bytes, hipHostMallocDefault));
+  c->host_stage_bytes = bytes;
+  return LIA_OK;
+}
+
+extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
+                                 const lia_bf16* x, lia_bf16* y, lia_kv* kv, int B, int T, int pos0, int b0, void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!weights || !x || !y || !kv || !kv->k || !kv->v) { lia_set_error("lia_layer_forward: NULL tensor"); return LIA_ERR_MISSING; }
+  for (int i = 0; i < 16; ++i)
+    if (!weights[i]) { lia_set_error("lia_layer_forward: weights[%d] is NULL", i); return LIA_ERR_MISSING; }
+  if (policy != 0 && policy != 2 && policy != 3) {
+    lia_set_error("lia_layer_forward: policy %d is not a GPU policy (0, 2, 3)", policy);
+    return LIA_ERR_INVALID;
+  }
+  if (B <= 0 || T <= 0 || pos0 < 0 || b0 < 0 || b0 + B > kv->batch || pos0 + T > kv->smax) {
+    lia_set_error("lia_layer_forward: B=%d T=%d pos0=%d b0=%d vs cache batch=%d smax=%d", B, T, pos0, b0, kv->batch, kv->smax);
+    return LIA_ERR_INVALID;
+  }
+  if (T > 1 && pos0 != 0) { lia_set_error("lia_layer_forward: multi-token call must be a prefill (pos0 == 0)"); return LIA_ERR_INVALID; }
+  if ((policy == 3) != (kv->on_device != 0)) {
+    lia_set_error("lia_layer_forward: policy %d needs a %s cache", policy, policy == 3 ? "device" : "host");
+    return LIA_ERR_INVALID;
+  }
+  const int H = d->hidden, F = d->ffn, hd = H / d->heads;
+  const long M = (long)B * T;
+  // policy-0 decode parks the whole cached prefix [pos0+1][B][H] (K and V) in a slab
+  const WsLayout w = ws_layout(d, M, policy == 0 ? (long)(pos0 + T) * B : M);
+  if (w.total > ctx->ws_bytes) {
+    lia_set_error("lia_layer_forward: workspace %zu < %zu needed for %ld rows", ctx->ws_bytes, w.total, M);
+    return LIA_ERR_MEMORY;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  {
+    // a K/V delivery still draining from a slab of a DIFFERENT layout could overlap this call's buffers
+    const long sr = policy == 0 ? (long)(pos0 + T) * B : M;
+    if (ctx->last_rows != M || ctx->last_slab_rows != sr) {
+      for (int i = 0; i < 2; ++i)
+        if (ctx->slab_used[i]) HIP_TRY(hipStreamWaitEvent(st, ctx->slab_done[i], 0));
+      ctx->last_rows = M;
+      ctx->last_slab_rows = sr;
+    }
+  }
+  char* ws = ctx->ws;
+  bf16_t *ln = (bf16_t*)(ws + w.ln), *qb = (bf16_t*)(ws + w.q), *kb = (bf16_t*)(ws + w.k), *vb = (bf16_t*)(ws + w.v);
+  bf16_t *ao = (bf16_t*)(ws + w.attn), *h1 = (bf16_t*)(ws + w.h1), *f1 = (bf16_t*)(ws + w.f1);
+  float* gws = (float*)(ws + w.gemm);
+  const bf16_t* const* W = (const bf16_t* const*)weights;
+  const bool fused_qkv = (W[4] == W[2] + (size_t)H * H) && (W[6] == W[4] + (size_t)H * H) && (W[5] == W[3] + H) &&
+                         (W[7] == W[5] + H);
+  const float eps = d->ln_eps;
+  const size_t S = (size_t)pos0 + T;
+
+  // LN1 (decoder.py:199-206)
+  lia_layernorm_launch(x, H, W[0], W[1], ln, H, M, H, eps, st);
+
+  // destinations of the fresh K/V rows
+  bf16_t *kdst, *vdst;
+  int dst_batch, dst_b0, dst_pos0;
+  bool cache_mode = true;
+  int slab = -1;
+  if (policy == 3) {
+    kdst = kv->k; vdst = kv->v; dst_batch = kv->batch; dst_b0 = b0; dst_pos0 = pos0;
+  } else if (policy == 0) {
+    // device slab [S][B][h][d] shared by K then V; two slabs alternate so the previous delivery may still drain
+    slab = ctx->slab_next; ctx->slab_next ^= 1;
+    if (ctx->slab_used[slab]) HIP_TRY(hipStreamWaitEvent(st, ctx->slab_done[slab], 0));
+    kdst = (bf16_t*)(ws + w.slab[slab]); vdst = kdst + S * B * H;
+    dst_batch = B; dst_b0 = 0; dst_pos0 = pos0;
+    if (pos0 > 0) {
+      // intended semantics of the reference's decode policy 0 (modeling_opt.py:1379-1491; its own
+      // implementation is not an oracle): bring the cached rows to the GPU, attend there
+      const size_t width = (size_t)B * H * 2, pitch = (size_t)kv->batch * H * 2;
+      HIP_TRY(hipMemcpy2DAsync(kdst, width, kv->k + (size_t)b0 * H, pitch, width, pos0, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpy2DAsync(vdst, width, kv->v + (size_t)b0 * H, pitch, width, pos0, hipMemcpyHostToDevice, st));
+    }
+  } else {  // policy 2: plain [M,H] buffers that travel to the host
+    kdst = kb; vdst = vb; dst_batch = B; dst_b0 = 0; dst_pos0 = 0; cache_mode = false;
+  }
+
+  // q | k | v projection (attentions.py:393-394, 418)
+  if (fused_qkv) {
+    rc = qkv_project(ctx, ln, W[2], W[3], qb, kdst, vdst, cache_mode, B, T, H, dst_batch, dst_b0, dst_pos0, gws, w.gemm_bytes, st);
+    if (rc) return rc;
+  } else {
+    for (int i = 0; i < 3; ++i) {
+      LiaEpilogue ep{W[3 + 2 * i], nullptr, 0, 0};
+      LiaOutMap om = plain_out(i == 0 ? qb : (i == 1 ? kdst : vdst), H, H);
+      if (i > 0 && cache_mode) { om.cache_mode[0] = 1; om.T = T; om.Bc = dst_batch; om.b0 = dst_b0; om.pos0 = dst_pos0; }
+      rc = gemm_checked(ctx, ln, H, W[2 + 2 * i], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st);
+      if (rc) return rc;
+    }
+  }
+
+  if (policy == 2) {
+    // q, k, v -> host; host attention over the host cache; result back (attentions.py:421-440)
+    const size_t one = (size_t)M * H * 2;
+    rc = ensure_host_stage(ctx, 4 * one);
+    if (rc) return rc;
+    bf16_t* hq = (bf16_t*)ctx->host_stage;
+    bf16_t *hk = hq + (size_t)M * H, *hv = hk + (size_t)M * H, *ha = hv + (size_t)M * H;
+    HIP_TRY(hipMemcpyAsync(hq, qb, one, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hk, kb, one, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hv, vb, one, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rc = lia_host_attention(hq, hk, hv, kv->k, kv->v, ha, B, T, pos0, d->heads, hd, kv->batch, b0, ctx->host_threads);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ao, ha, one, hipMemcpyHostToDevice, st));
+  } else {
+    // GPU attention (attentions.py:443-536)
+    int arc = T == 1 ? lia_attn_decode_launch(qb, H, kdst, vdst, ao, H, B, (int)S, d->heads, hd, dst_batch, dst_b0, st)
+                     : lia_attn_prefill_launch(qb, H, kdst, vdst, ao, H, B, T, d->heads, hd, dst_batch, dst_b0, st);
+    if (arc) { lia_set_error("attention: unsupported head_dim %d / S %zu", hd, S); return LIA_ERR_INVALID; }
+    if (policy == 0) {
+      // deliver rows [pos0, pos0+T) of batch rows [b0, b0+B) to the host cache
+      HIP_TRY(hipEventRecord(ctx->slab_ready[slab], st));
+      HIP_TRY(hipStreamWaitEvent(ctx->d2h, ctx->slab_ready[slab], 0));
+      const size_t width = (size_t)B * H * 2, pitch = (size_t)kv->batch * H * 2;
+      HIP_TRY(hipMemcpy2DAsync(kv->k + ((size_t)pos0 * kv->batch + b0) * H, pitch, kdst + (size_t)pos0 * B * H, width, width, T,
+                               hipMemcpyDeviceToHost, ctx->d2h));
+      HIP_TRY(hipMemcpy2DAsync(kv->v + ((size_t)pos0 * kv->batch + b0) * H, pitch, vdst + (size_t)pos0 * B * H, width, width, T,
+                               hipMemcpyDeviceToHost, ctx->d2h));
+      HIP_TRY(hipEventRecord(ctx->slab_done[slab], ctx->d2h));
+      ctx->slab_used[slab] = true;
+    }
+  }
+
+  // out-proj + bias, residual (decoder.py:225-229)
+  {
+    LiaEpilogue ep{W[9], x, H, 0};
+    LiaOutMap om = plain_out(h1, H, H);
+    rc = gemm_checked(ctx, ao, H, W[8], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  }
+  // LN2 (decoder.py:268-276), fc1 + relu (:282-285), fc2 + residual (:306-310)
+  lia_layernorm_launch(h1, H, W[10], W[11], ln, H, M, H, eps, st);
+  {
+    LiaEpilogue ep{W[13], nullptr, 0, 1};
+    LiaOutMap om = plain_out(f1, F, F);
+    rc = gemm_checked(ctx, ln, H, W[12], (int)M, F, H, ep, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  }
+  {
+    LiaEpilogue ep{W[15], h1, H, 0};
+    LiaOutMap om = plain_out(y, H, H);
+    rc = gemm_checked(ctx, f1, F, W[14], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight streamer
+// ------------------------------------------------------------------------------------------------
+struct lia_streamer {
+  lia_ctx* ctx;
+  int n_slots;
+  size_t slot_bytes;
+  char* slots;
+  hipStream_t copy;
+  std::vector<hipEvent_t> copied, released, t0, t1;
+  std::vector<char> has_release, timing_pending;
+  std::vector<size_t> pending_bytes;
+  char* bounce;
+  double bytes, busy_ms;
+};
+
+static void streamer_collect(lia_streamer* s, int slot) {
+  if (!s->timing_pending[slot]) return;
+  if (hipEventSynchronize(s->t1[slot]) == hipSuccess) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->t0[slot], s->t1[slot]) == hipSuccess) {
+      s->busy_ms += ms;
+      s->bytes += (double)s->pending_bytes[slot];
+    }
+  }
+  s->timing_pending[slot] = 0;
+}
+
+extern "C" int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, lia_streamer** out) {
+  if (!ctx || !out || n_slots < 1 || n_slots > 16 || slot_bytes == 0) { lia_set_error("lia_stream_create: n_slots=%d slot_bytes=%zu", n_slots, slot_bytes); return LIA_ERR_INVALID; }
+  *out = nullptr;
+  lia_streamer* s = new lia_streamer();
+  s->ctx = ctx; s->n_slots = n_slots; s->slot_bytes = align_up(slot_bytes, 256);
+  s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr;
+  HIP_TRY(hipMalloc((void**)&s->slots, s->slot_bytes * n_slots));
+  HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+  s->copied.resize(n_slots); s->released.resize(n_slots); s->t0.resize(n_slots); s->t1.resize(n_slots);
+  s->has_release.assign(n_slots, 0); s->timing_pending.assign(n_slots, 0); s->pending_bytes.assign(n_slots, 0);
+  for (int i = 0; i < n_slots; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&s->copied[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->released[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&s->t0[i]));
+    HIP_TRY(hipEventCreate(&s->t1[i]));
+  }
+  *out = s;
+  return LIA_OK;
+}
+
+extern "C" void lia_stream_destroy(lia_streamer* s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s->copy);
+  for (int i = 0; i < s->n_slots; ++i) {
+    (void)hipEventDestroy(s->copied[i]); (void)hipEventDestroy(s->released[i]);
+    (void)hipEventDestroy(s->t0[i]); (void)hipEventDestroy(s->t1[i]);
+  }
+  if (s->bounce) (void)hipHostFree(s->bounce);
+  if (s->slots) (void)hipFree(s->slots);
+  (void)hipStreamDestroy(s->copy);
+  delete s;
+}
+
+extern "C" void* lia_stream_slot_ptr(lia_streamer* s, int slot) {
+  if (!s || slot < 0 || slot >= s->n_slots) return nullptr;
+  return s->slots + (size_t)slot * s->slot_bytes;
+}
+
+extern "C" void* lia_stream_copy_stream(lia_streamer* s) { return s ? (void*)s->copy : nullptr; }
+
+extern "C" int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t bytes, int pinned) {
+  if (!s || slot < 0 || slot >= s->n_slots || !host_ptr || bytes > s->slot_bytes) {
+    lia_set_error("lia_stream_prefetch: slot=%d bytes=%zu (slot holds %zu)", slot, bytes, s ? s->slot_bytes : 0);
+    return LIA_ERR_INVALID;
+  }
+  streamer_collect(s, slot);
+  if (s->has_release[slot]) HIP_TRY(hipStreamWaitEvent(s->copy, s->released[slot], 0));
+  const void* src = host_ptr;
+  if (!pinned) {
+    // pageable source: stage through a pinned bounce buffer (the reference's cpu_buff, modeling_opt.py:1219-1220)
+    if (!s->bounce) HIP_TRY(hipHostMalloc((void**)&s->bounce, s->slot_bytes, hipHostMallocDefault));
+    HIP_TRY(hipStreamSynchronize(s->copy));  // previous use of the bounce buffer has left the host
+    memcpy(s->bounce, host_ptr, bytes);
+    src = s->bounce;
+  }
+  HIP_TRY(hipEventRecord(s->t0[slot], s->copy));
+  HIP_TRY(hipMemcpyAsync(s->slots + (size_t)slot * s->slot_bytes, src, bytes, hipMemcpyHostToDevice, s->copy));
+  HIP_TRY(hipEventRecord(s->t1[slot], s->copy));
+  HIP_TRY(hipEventRecord(s->copied[slot], s->copy));
+  s->timing_pending[slot] = 1;
+  s->pending_bytes[slot] = bytes;
+  return LIA_OK;
+}
+
+extern "C" int lia_stream_wait(lia_streamer* s, int slot, void* compute_stream) {
+  if (!s || slot < 0 || slot >= s->n_slots) return LIA_ERR_INVALID;
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)compute_stream, s->copied[slot], 0));
+  return LIA_OK;
+}
+
+extern "C" int lia_stream_release(lia_streamer* s, int slot, void* compute_stream) {
+  if (!s || slot < 0 || slot >= s->n_slots) return LIA_ERR_INVALID;
+  HIP_TRY(hipEventRecord(s->released[slot], (hipStream_t)compute_stream));
+  s->has_release[slot] = 1;
+  return LIA_OK;
+}
+
+extern "C" int lia_stream_stats(lia_streamer* s, double* bytes, double* busy_ms, int reset) {
+  if (!s) return LIA_ERR_INVALID;
+  for (int i = 0; i < s->n_slots; ++i) streamer_collect(s, i);
+  if (bytes) *bytes = s->bytes;
+  if (busy_ms) *busy_ms = s->busy_ms;
+  if (reset) { s->bytes = 0; s->busy_ms = 0; }
+  return LIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pinned / registered host memory
+// ------------------------------------------------------------------------------------------------
+extern "C" void* lia_host_alloc_pinned(size_t size) {
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, size, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    lia_set_error("hipHostMalloc(%zu) failed: %s", size, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void lia_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int lia_numa_register(void* ptr, size_t size) {
+  if (!ptr || !size) return LIA_ERR_INVALID;
+  hipError_t e = hipHostRegister(ptr, size, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    lia_set_error("hipHostRegister(%p, %zu) failed: %s", ptr, size, hipGetErrorString(e));
+    return LIA_ERR_MEMORY;
+  }
+  return LIA_OK;
+}
+extern "C" int lia_numa_unregister(void* ptr) {
+  if (!ptr) return LIA_ERR_INVALID;
+  HIP_TRY(hipHostUnregister(ptr));
+  return LIA_OK;
+}

@@ -1,0 +1,299 @@
+// GPU attention for policies 0 / 3 (attentions.py:443-536), with every bf16 rounding point of the
+// reference's op sequence kept:
+//     q  = bf16(q * d^-0.5)            (:456)
+//     s  = bf16(q . k)                 torch.bmm output (:499)
+//     prefill: causal mask -> -inf     (:444-449, 500-509: fp32 add of -3.4028e38, clamp, cast to bf16)
+//     p  = bf16(softmax(s))            fp32 inside (:512);  decode (T == 1): no mask
+//     o  = bf16(p . v)                 torch.bmm output (:529)
+// Because p is rounded AFTER normalisation by the full-row sum, a one-pass online softmax cannot
+// reproduce it; the prefill kernel therefore makes two sweeps over the keys (statistics, then P.V).
+// Attention is 0.3 % of the prefill flops at T = 256, so the second Q.K^T is
+// irrelevant to the layer time while keeping bit-level agreement with the oracle.
+//
+// K and V are always read from the seq-major cache layout [S][Bc][h][d] (attentions.py:457-476) --
+// the q|k|v GEMM epilogue has already scattered the fresh rows there -- so one kernel serves the
+// resident layers (device cache) and the streamed prefill (staging slab that is then copied to the
+// host cache).
+#include "lia_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// prefill: LDS-tiled, MFMA 32x32x16.  Workgroup = 4 waves = 128 query rows of one (batch, head);
+// wave w owns query rows q0 + 32w .. +31.  Key tiles of 32 are staged in LDS and shared.
+//   S^T = K . Qs^T   (A = K rows from LDS, B = Qs rows held in registers): the lane owns one query
+//   column, so the softmax row statistics are in-lane + one cross-half shuffle.
+//   O^T = V^T . P^T  (A = V^T from a transposed LDS image, B = the P^T accumulator registers re-used
+//   directly as the next MFMA's operand, cdna_hip_programming.md section 3).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __restrict__ q, long ldq,
+                                                                const bf16_t* __restrict__ kc,
+                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
+                                                                long ldo, int T, int heads, int Bc, int b0, float scaling) {
+  constexpr int CH = D / 8;              // 16-byte chunks per K row
+  constexpr int RPB = 16 / CH;           // K rows per 256-byte LDS bank row
+  constexpr int KSTEPS = D / 16;         // MFMA k-steps over d for S^T
+  constexpr int DB = D / 32;             // 32-row blocks of O^T
+  constexpr int VT_STRIDE = 72;          // bytes per V^T row: 32 keys * 2 B + 8 pad (8-byte aligned)
+  __shared__ __attribute__((aligned(16))) char k_lds[32 * D * 2];
+  __shared__ __attribute__((aligned(16))) char vt_lds[D * VT_STRIDE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int hh = blockIdx.y, b = blockIdx.z;
+  const int q_wg = blockIdx.x * 128;
+  const int q_wave = q_wg + wave * 32;
+  const long hd = (long)heads * D;
+  const long kv_row = (long)Bc * hd;  // elements between consecutive sequence positions
+  const bf16_t* kbase = kc + ((long)(b0 + b) * heads + hh) * D;
+  const bf16_t* vbase = vc + ((long)(b0 + b) * heads + hh) * D;
+
+  // Qs fragments: B operand, lane holds Qs[q_wave + r][16 s + 8 h + j]
+  bf16x8 qf[KSTEPS];
+  {
+    const int qrow = min(q_wave + r, T - 1);
+    const bf16_t* qp = q + ((long)b * T + qrow) * ldq + (long)hh * D;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      uint4 v = *(const uint4*)(qp + 16 * s + 8 * h);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf2f(w[j] & 0xffff) * scaling, bf2f(w[j] >> 16) * scaling);
+      qf[s] = __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
+    }
+  }
+
+  const int n_tiles_wg = min((q_wg + 128 + 31) / 32, (T + 31) / 32);  // causal: keys <= last query of the WG
+  const int my_q = q_wave + r;                                        // this lane's query (column of S^T)
+
+  auto stage_k = [&](int kt) {
+    // 32 keys x D: thread -> (key = tid / CH', chunk); 256 threads move 4 KB per round
+    constexpr int ROUNDS = (32 * CH + 255) / 256;
+#pragma unroll
+    for (int rr = 0; rr < ROUNDS; ++rr) {
+      int idx = rr * 256 + tid;
+      if (idx < 32 * CH) {
+        int key = idx / CH, c = idx % CH;
+        int gk = min(kt * 32 + key, T - 1);
+        uint4 v = *(const uint4*)(kbase + (long)gk * kv_row + 8 * c);
+        *(uint4*)(k_lds + key * (D * 2) + ((c ^ ((key / RPB) % CH)) << 4)) = v;
+      }
+    }
+  };
+  auto stage_vt = [&](int kt) {
+    constexpr int ROUNDS = (32 * CH + 255) / 256;
+#pragma unroll
+    for (int rr = 0; rr < ROUNDS; ++rr) {
+      int idx = rr * 256 + tid;
+      if (idx < 32 * CH) {
+        int key = idx / CH, c = idx % CH;
+        int gk = min(kt * 32 + key, T - 1);
+        uint4 v = *(const uint4*)(vbase + (long)gk * kv_row + 8 * c);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          *(bf16_t*)(vt_lds + (8 * c + 2 * j) * VT_STRIDE + key * 2) = (bf16_t)(w[j] & 0xffff);
+          *(bf16_t*)(vt_lds + (8 * c + 2 * j + 1) * VT_STRIDE + key * 2) = (bf16_t)(w[j] >> 16);
+        }
+      }
+    }
+  };
+  // S^T tile for key tile kt: lane gets S^T[key = kt*32 + (i&3) + 8*(i>>2) + 4h][query = my_q], rounded
+  // to bf16 and causally masked
+  auto scores = [&](int kt, f32x16& sacc) {
+    sacc = f32x16{0};
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      uint4 kv = *(const uint4*)(k_lds + r * (D * 2) + (((2 * s + h) ^ ((r / RPB) % CH)) << 4));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv), qf[s], sacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      sacc[i] = (key <= my_q && key < T) ? rbf(sacc[i]) : -INFINITY;
+    }
+  };
+
+  // ---- sweep 1: row max and sum of exp over all keys <= query ----
+  float m = -INFINITY, l = 0.f;
+  for (int kt = 0; kt < n_tiles_wg; ++kt) {
+    __syncthreads();
+    stage_k(kt);
+    __syncthreads();
+    if (kt * 32 <= q_wave + 31) {  // wave-uniform: tile not entirely above the diagonal
+      f32x16 s;
+      scores(kt, s);
+      float tm = s[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) tm = fmaxf(tm, s[i]);
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      float mn = fmaxf(m, tm);
+      if (mn > -INFINITY) {
+        float ts = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ts += __expf(s[i] - mn);
+        ts += __shfl_xor(ts, 32, 64);
+        l = l * __expf(m - mn) + ts;
+        m = mn;
+      }
+    }
+  }
+  const float inv_l = 1.0f / l;
+
+  // ---- sweep 2: P = bf16(exp(s - m) / l), O^T += V^T . P^T ----
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) oacc[d] = f32x16{0};
+  for (int kt = 0; kt < n_tiles_wg; ++kt) {
+    __syncthreads();
+    stage_k(kt);
+    stage_vt(kt);
+    __syncthreads();
+    if (kt * 32 <= q_wave + 31) {
+      f32x16 s;
+      scores(kt, s);
+      uint32_t pk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        pk[i] = pack_bf16x2(__expf(s[2 * i] - m) / l, __expf(s[2 * i + 1] - m) / l);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[4 * ks], pk[4 * ks + 1], pk[4 * ks + 2], pk[4 * ks + 3]});
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const char* vrow = vt_lds + (32 * d + r) * VT_STRIDE + (16 * ks + 4 * h) * 2;
+          uint2 lo = *(const uint2*)(vrow), hi = *(const uint2*)(vrow + 16);
+          bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  (void)inv_l;
+
+  if (my_q < T) {
+    bf16_t* op = out + ((long)b * T + my_q) * ldo + (long)hh * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 o;
+        o.x = pack_bf16x2(oacc[d][4 * g], oacc[d][4 * g + 1]);
+        o.y = pack_bf16x2(oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
+        *(uint2*)(op + 32 * d + 8 * g + 4 * h) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode (T == 1): one workgroup per (batch, head); KV-bandwidth bound.  LPK = D/8 lanes share one key
+// row (16 bytes each); scores are parked in LDS, then every thread accumulates its 8 output dims over
+// its share of the keys and the shares are combined through LDS.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __restrict__ q, long ldq,
+                                                               const bf16_t* __restrict__ kc,
+                                                               const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
+                                                               long ldo, int S, int heads, int Bc, int b0, float scaling) {
+  constexpr int LPK = D / 8;          // lanes per key
+  constexpr int KPP = 256 / LPK;      // keys per pass of the workgroup
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = (float*)smem;                         // [S] scores -> probabilities
+  float* red = (float*)(smem + (((size_t)S * 4 + 15) & ~(size_t)15));  // [KPP][D] partial outputs, [8] scratch after
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = blockIdx.x, b = blockIdx.y;
+  const long hd = (long)heads * D;
+  const long kv_row = (long)Bc * hd;
+  const bf16_t* kbase = kc + ((long)(b0 + b) * heads + hh) * D;
+  const bf16_t* vbase = vc + ((long)(b0 + b) * heads + hh) * D;
+  const int sub = tid % LPK, kslot = tid / LPK;
+
+  float qs[8];
+  {
+    uint4 v = *(const uint4*)(q + (long)b * ldq + (long)hh * D + 8 * sub);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { qs[2 * j] = rbf(bf2f(w[j] & 0xffff) * scaling); qs[2 * j + 1] = rbf(bf2f(w[j] >> 16) * scaling); }
+  }
+  float lmax = -INFINITY;
+  for (int j0 = 0; j0 < S; j0 += KPP) {
+    int j = j0 + kslot;
+    float a = 0.f;
+    if (j < S) {
+      uint4 v = *(const uint4*)(kbase + (long)j * kv_row + 8 * sub);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a += qs[2 * e] * bf2f(w[e] & 0xffff) + qs[2 * e + 1] * bf2f(w[e] >> 16);
+    }
+#pragma unroll
+    for (int o = LPK / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (j < S) {
+      a = rbf(a);
+      if (sub == 0) sc[j] = a;
+      lmax = fmaxf(lmax, a);
+    }
+  }
+  float* scratch = red + KPP * D;
+  lmax = wave_max(lmax);
+  if (lane == 0) scratch[wave] = lmax;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+  float ls = 0.f;
+  for (int j = tid; j < S; j += 256) {
+    float e = __expf(sc[j] - m);
+    sc[j] = e;
+    ls += e;
+  }
+  ls = wave_sum(ls);
+  if (lane == 0) scratch[4 + wave] = ls;
+  __syncthreads();
+  const float l = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j = kslot; j < S; j += KPP) {
+    float p = rbf(sc[j] / l);
+    uint4 v = *(const uint4*)(vbase + (long)j * kv_row + 8 * sub);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] += p * bf2f(w[e] & 0xffff); o[2 * e + 1] += p * bf2f(w[e] >> 16); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[kslot * D + 8 * sub + e] = o[e];
+  __syncthreads();
+  if (tid < D) {
+    float a = 0.f;
+    for (int k = 0; k < KPP; ++k) a += red[k * D + tid];
+    out[(long)b * ldo + (long)hh * D + tid] = f2bf(a);
+  }
+}
+
+extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
+                                       int B, int T, int heads, int d, int Bc, int b0, hipStream_t st) {
+  if (B <= 0 || T <= 0) return 0;
+  dim3 grid((T + 127) / 128, heads, B);
+  const float scaling = 1.0f / sqrtf((float)d);
+  switch (d) {
+    case 128: hipLaunchKernelGGL(lia_attn_prefill_kernel<128>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, Bc, b0, scaling); break;
+    case 64: hipLaunchKernelGGL(lia_attn_prefill_kernel<64>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, Bc, b0, scaling); break;
+    case 32: hipLaunchKernelGGL(lia_attn_prefill_kernel<32>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, Bc, b0, scaling); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
+                                      int B, int S, int heads, int d, int Bc, int b0, hipStream_t st) {
+  if (B <= 0 || S <= 0) return 0;
+  dim3 grid(heads, B);
+  const float scaling = 1.0f / sqrtf((float)d);
+  const int kpp = 256 / (d / 8);
+  size_t lds = (((size_t)S * 4 + 15) & ~(size_t)15) + (size_t)kpp * d * 4 + 64;
+  if (lds > 160 * 1024) return -1;
+  switch (d) {
+    case 128: hipLaunchKernelGGL(lia_attn_decode_kernel<128>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, Bc, b0, scaling); break;
+    case 64: hipLaunchKernelGGL(lia_attn_decode_kernel<64>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, Bc, b0, scaling); break;
+    case 32: hipLaunchKernelGGL(lia_attn_decode_kernel<32>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, Bc, b0, scaling); break;
+    default: return -1;
+  }
+  return 0;
+}

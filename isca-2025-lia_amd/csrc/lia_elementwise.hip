@@ -1,0 +1,117 @@
+// Row-wise / gather kernels of the LIA hot path (HBM-bound, 16-byte vector accesses everywhere):
+// LayerNorm, token+position embedding, last-position gather, greedy argmax.
+#include "lia_common.h"
+
+// F.layer_norm on a bf16 tensor (decoder.py:107-119; final LN lia/modeling_opt.py:1563): statistics and
+// affine in fp32, ONE rounding at the output.  One wave per row; the row (<= 24 KB) is read three
+// times, the 2nd/3rd time from L1/L2.
+__global__ __launch_bounds__(256) void lia_layernorm_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                             const bf16_t* __restrict__ g, const bf16_t* __restrict__ b,
+                                                             bf16_t* __restrict__ y, long ldy, long rows, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  const int nv = H >> 3;
+  float s = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    uint4 v = *(const uint4*)(xr + 8 * i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += bf2f(w[j] & 0xffff) + bf2f(w[j] >> 16);
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    uint4 v = *(const uint4*)(xr + 8 * i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = bf2f(w[j] & 0xffff) - mean, c = bf2f(w[j] >> 16) - mean;
+      q += a * a + c * c;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+  bf16_t* yr = y + row * ldy;
+  for (int i = lane; i < nv; i += 64) {
+    uint4 v = *(const uint4*)(xr + 8 * i);
+    uint4 gv = *(const uint4*)(g + 8 * i);
+    uint4 bv = *(const uint4*)(b + 8 * i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo = (bf2f(w[j] & 0xffff) - mean) * rstd * bf2f(gw[j] & 0xffff) + bf2f(bw[j] & 0xffff);
+      float hi = (bf2f(w[j] >> 16) - mean) * rstd * bf2f(gw[j] >> 16) + bf2f(bw[j] >> 16);
+      o[j] = pack_bf16x2(lo, hi);
+    }
+    *(uint4*)(yr + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
+                                     long rows, int H, float eps, hipStream_t st) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(lia_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, g, b, y, ldy, rows,
+                     H, eps);
+}
+
+// hidden = embed_tokens[ids] + embed_positions[past_len + t + 2], one bf16 add
+// (lia/modeling_opt.py:1108 token embedding, :357-378 learned positions with offset 2 and an all-ones
+// mask, :1142 the sum).  One workgroup per token row.
+__global__ __launch_bounds__(256) void lia_embed_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ tok,
+                                                         const bf16_t* __restrict__ pos, bf16_t* __restrict__ y, int T,
+                                                         int past_len, int H) {
+  const long row = blockIdx.x;
+  const int t = (int)(row % T);
+  const bf16_t* te = tok + ids[row] * (long)H;
+  const bf16_t* pe = pos + (long)(past_len + t + 2) * H;
+  bf16_t* yo = y + row * (long)H;
+  for (int i = threadIdx.x; i < (H >> 3); i += 256) {
+    uint4 a = *(const uint4*)(te + 8 * i), p = *(const uint4*)(pe + 8 * i);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, pw[4] = {p.x, p.y, p.z, p.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf16x2(bf2f(aw[j] & 0xffff) + bf2f(pw[j] & 0xffff), bf2f(aw[j] >> 16) + bf2f(pw[j] >> 16));
+    *(uint4*)(yo + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* y, int B, int T,
+                                 int past_len, int H, hipStream_t st) {
+  if (B * T <= 0) return;
+  hipLaunchKernelGGL(lia_embed_kernel, dim3(B * T), dim3(256), 0, st, ids, tok, pos, y, T, past_len, H);
+}
+
+// Greedy argmax over bf16 logits [B, vocab], first maximal index on ties (greedy_search.py:367,395).
+__global__ __launch_bounds__(256) void lia_argmax_kernel(const bf16_t* __restrict__ logits, int64_t* __restrict__ out,
+                                                          int vocab) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const bf16_t* row = logits + (long)blockIdx.x * vocab;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < vocab; i += 256) {
+    float f = bf2f(row[i]);
+    if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+
+extern "C" void lia_argmax_launch(const bf16_t* logits, int64_t* out, int B, int vocab, hipStream_t st) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(lia_argmax_kernel, dim3(B), dim3(256), 0, st, logits, out, vocab);
+}

@@ -1,0 +1,323 @@
+// bf16 MFMA GEMMs for the LIA GPU sub-layers:  y[M,N] = epilogue(x[M,K] . W[N,K]^T)
+//
+// Replaces the reference's  torch.matmul(x, w.t()) + b  [+ relu] [residual + .]  sequences
+// (decoder.py:79-105, 225-229, 282-285, 306-310; attentions.py:393-394, 418) and the per-use
+// un-blocking copy of every streamed weight (attentions.py:381-382,412; decoder.py:25-58): weights are
+// kept row-major [N,K] on the host, so nothing is re-laid-out on the GPU.
+//
+// Two regimes, one fragment convention (A operand = W rows, B operand = x rows, both K-contiguous, so
+// every fragment is one 16-byte load; D[n_local][m_local], lane holds 4 consecutive n of one m):
+//   * skinny  (decode, M <= 256): weight-bandwidth bound.  W goes HBM -> VGPR fragments directly (each
+//     weight byte is used by exactly one wave), a DEPTH-deep register ring keeps ~16 KB per wave in
+//     flight; the small x chunk is shared by the workgroup through swizzled LDS.  Split-K over
+//     workgroups fills the 256 CUs when N/64 is small; fp32 partial slabs are combined by a second
+//     tiny kernel that also applies the epilogue.
+//   * tiled   (prefill, M in the thousands): MFMA bound.  128x128x64 tiles, LDS-DMA staging
+//     (global_load_lds, 16 B/lane) with the XOR swizzle applied on the SOURCE address
+//     (cdna_hip_programming.md rule 21), double-buffered, XCD-aware tile order.
+#include "lia_common.h"
+
+#define GL_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---------------------------------------------------------------------------------------------
+// shared epilogue: 4 consecutive columns n..n+3 of row m
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep, const LiaOutMap& om) {
+  float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+  if (hb) {
+    uint2 bb = *(const uint2*)(ep.bias + n);
+    b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
+  }
+  if (hr) {
+    uint2 rr = *(const uint2*)(ep.residual + (long)m * ep.ldr + n);
+    r[0] = bf2f(rr.x & 0xffff); r[1] = bf2f(rr.x >> 16); r[2] = bf2f(rr.y & 0xffff); r[3] = bf2f(rr.y >> 16);
+  }
+  float t0 = lia_epilogue_apply(v[0], b[0], hb, ep.relu, r[0], hr);
+  float t1 = lia_epilogue_apply(v[1], b[1], hb, ep.relu, r[1], hr);
+  float t2 = lia_epilogue_apply(v[2], b[2], hb, ep.relu, r[2], hr);
+  float t3 = lia_epilogue_apply(v[3], b[3], hb, ep.relu, r[3], hr);
+  uint2 o;
+  o.x = pack_bf16x2(t0, t1);
+  o.y = pack_bf16x2(t2, t3);
+  *(uint2*)lia_out_ptr(om, m, n) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// skinny regime
+// ---------------------------------------------------------------------------------------------
+constexpr int SK_BN = 64;     // columns per workgroup (16 per wave)
+constexpr int SK_BK = 128;    // K per chunk (4 MFMA k-steps of 32)
+constexpr int SK_DEPTH = 4;   // W register ring depth (chunks in flight per wave)
+
+template <int MT>
+__global__ __launch_bounds__(256) void lia_gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                               const bf16_t* __restrict__ W, long ldw, int M, int N,
+                                                               int K, int chunks_per_split, float* __restrict__ partial,
+                                                               LiaEpilogue ep, LiaOutMap om) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XBUF = 16 * MT * 256;  // bytes per x chunk buffer
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int n_wave = blockIdx.x * SK_BN + wave * 16;
+  const bool wave_active = n_wave < N;
+  const int nchunks = K / SK_BK;
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_end = min(nchunks, c_begin + chunks_per_split);
+
+  // W fragment source: row n_wave + l15, 8 bf16 at k = 32*i + 8*lq inside a chunk
+  const int wrow = min(n_wave + l15, N - 1);
+  const bf16_t* wp = W + (long)wrow * ldw + 8 * lq;
+
+  // x staging: thread -> (row = tid>>4 (+16p), 16-byte chunk = tid&15).  Loads past the last chunk are
+  // clamped to it (harmless re-reads) so the loop body carries no conditional loads.
+  const int xr = tid >> 4, xc = tid & 15;
+  const bf16_t* xp[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) xp[p] = x + (long)min(xr + 16 * p, M - 1) * ldx + 8 * xc;
+  int xoff[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) xoff[p] = (xr + 16 * p) * 256 + ((xc ^ ((xr + 16 * p) & 15)) << 4);
+  uint4 xreg[MT];
+  u32x4 wreg[SK_DEPTH][4];
+
+#define SK_LOAD_X(c)                                                                              \
+  _Pragma("unroll") for (int p = 0; p < MT; ++p) xreg[p] = *(const uint4*)(xp[p] + (long)(c) * SK_BK);
+#define SK_STORE_X(buf)                                                                           \
+  _Pragma("unroll") for (int p = 0; p < MT; ++p) *(uint4*)(smem + (buf) * XBUF + xoff[p]) = xreg[p];
+#define SK_LOAD_W(s, c)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+      wreg[s][i] = __builtin_nontemporal_load((const u32x4*)(wp + (long)(c) * SK_BK + 32 * i));
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (c_begin < c_end) {
+    const int c_last = c_end - 1;
+    SK_LOAD_X(c_begin);
+#pragma unroll
+    for (int s = 0; s < SK_DEPTH; ++s) { SK_LOAD_W(s, min(c_begin + s, c_last)); }
+    SK_STORE_X(0);
+    __syncthreads();
+    for (int base = c_begin; base < c_end; base += SK_DEPTH) {
+#pragma unroll
+      for (int s = 0; s < SK_DEPTH; ++s) {
+        const int c = base + s;
+        if (c < c_end) {  // workgroup-uniform
+          const int buf = (c - c_begin) & 1;
+          SK_LOAD_X(min(c + 1, c_last));
+          const char* xb = smem + buf * XBUF;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bf16x8 a = __builtin_bit_cast(bf16x8, wreg[s][i]);
+#pragma unroll
+            for (int p = 0; p < MT; ++p) {
+              uint4 bv = *(const uint4*)(xb + (16 * p + l15) * 256 + (((4 * i + lq) ^ l15) << 4));
+              acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bv), acc[p], 0, 0, 0);
+            }
+          }
+          SK_LOAD_W(s, min(c + SK_DEPTH, c_last));
+          SK_STORE_X(buf ^ 1);
+          __syncthreads();
+        }
+      }
+    }
+  }
+  // hipcc (ROCm 7.2) was seen to read a just-written MFMA accumulator (v_accvgpr_read) with too few
+  // wait states when the read sits at a branch target; the barrier above already separates the last
+  // MFMA from everything below, keep it that way.
+#undef SK_LOAD_X
+#undef SK_STORE_X
+#undef SK_LOAD_W
+
+  if (!wave_active) return;
+  const int n = n_wave + 4 * lq;
+  if (partial != nullptr) {
+    float* pp = partial + (long)blockIdx.y * M * N;
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      int m = 16 * p + l15;
+      if (m < M) *(f32x4*)(pp + (long)m * N + n) = acc[p];
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      int m = 16 * p + l15;
+      if (m < M) store_quad(acc[p], m, n, ep, om);
+    }
+  }
+}
+
+// Combine split-K slabs [S][M][N] fp32 and apply the epilogue; one thread per 4 columns.
+__global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                                 LiaEpilogue ep, LiaOutMap om) {
+  long q = (long)blockIdx.x * 256 + threadIdx.x;
+  long nq = (long)M * (N / 4);
+  if (q >= nq) return;
+  int m = (int)(q / (N / 4));
+  int n = (int)(q - (long)m * (N / 4)) * 4;
+  f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
+  for (int s = 1; s < S; ++s) {
+    f32x4 b = *(const f32x4*)(partial + ((long)s * M + m) * N + n);
+    a += b;
+  }
+  store_quad(a, m, n, ep, om);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiled regime
+// ---------------------------------------------------------------------------------------------
+constexpr int TL_BM = 128, TL_BN = 128, TL_BK = 64;
+constexpr int TL_TILE_BYTES = 128 * TL_BK * 2;  // one operand tile: 128 rows x 128 B
+
+// LDS slot (row, c) holds global 16-byte chunk (c ^ swz(row)) of that row; a 128-B row is half a
+// 256-B bank row, so consecutive row pairs share a bank row and swz uses row>>1.
+__device__ __forceinline__ int tl_swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void tl_stage(const bf16_t* __restrict__ g, long ld, int row0, int rows_valid, int k0,
+                                         char* lds_tile, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int row = r * 32 + (tid >> 3);
+    int c = tid & 7;
+    int grow = min(row0 + row, rows_valid - 1);
+    const bf16_t* src = g + (long)grow * ld + k0 + ((c ^ tl_swz(row)) << 3);
+    __builtin_amdgcn_global_load_lds(GL_AS1(src), LDS_AS3(lds_tile + r * 4096 + wave * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void lia_gemm_tiled_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                              const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
+                                                              int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | x tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wn = wave & 1, wm = wave >> 1;
+
+  // XCD-aware tile order: blocks that share an XCD (same blockIdx % 8) walk a contiguous run of
+  // tiles, and runs sweep GM m-tiles per n-tile so the W panel and the x panels stay in that L2.
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  constexpr int GM = 8;
+  const int group = lin / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int in_g = lin - group * GM * tiles_n;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  const int m0 = tm * TL_BM, n0 = tn * TL_BN;
+
+  f32x4 acc[4][4];  // [n-block][m-block]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / TL_BK;
+  tl_stage(W, ldw, n0, N, 0, smem, tid);
+  tl_stage(x, ldx, m0, M, 0, smem + TL_TILE_BYTES, tid);
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    char* wt = smem + cur * 2 * TL_TILE_BYTES;
+    char* xt = wt + TL_TILE_BYTES;
+    if (kt + 1 < nk) {
+      char* nw = smem + (cur ^ 1) * 2 * TL_TILE_BYTES;
+      tl_stage(W, ldw, n0, N, (kt + 1) * TL_BK, nw, tid);
+      tl_stage(x, ldx, m0, M, (kt + 1) * TL_BK, nw + TL_TILE_BYTES, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = wn * 64 + i * 16 + l15;
+        a[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int row = wm * 64 + j * 16 + l15;
+        b[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(xt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int n = n0 + wn * 64 + i * 16 + 4 * lq;
+    if (n < N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int m = m0 + wm * 64 + j * 16 + l15;
+        if (m < M) store_quad(acc[i][j], m, n, ep, om);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launcher
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
+  // worst case split-K = 8 fp32 slabs of a skinny problem
+  if (M > 256) return 0;
+  return (size_t)8 * M * N * sizeof(float);
+}
+
+template <int MT>
+static void launch_skinny(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K, int split,
+                          int cps, float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
+  dim3 grid((N + SK_BN - 1) / SK_BN, split);
+  size_t lds = 2 * 16 * MT * 256;
+  hipLaunchKernelGGL(lia_gemm_skinny_kernel<MT>, grid, dim3(256), lds, st, x, ldx, W, ldw, M, N, K, cps,
+                     split > 1 ? partial : nullptr, ep, om);
+}
+
+// Returns 0 on success, -1 on unsupported shape.  workspace is only touched when split-K is chosen.
+extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
+                               const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
+                               int force_split, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if ((N % 16) != 0 || (om->seg_n % 4) != 0) return -1;
+  if (M <= 256 && (K % SK_BK) == 0) {
+    const int nchunks = K / SK_BK;
+    const int tiles = (N + SK_BN - 1) / SK_BN;
+    int split = 1;
+    if (force_split > 0) {
+      split = force_split;
+    } else {
+      // aim for >= 2 workgroups per CU; every split needs a few chunks to amortise its prologue
+      while (split < 8 && tiles * split < 512 && nchunks / (split * 2) >= 4) split *= 2;
+    }
+    if (split > nchunks) split = nchunks;
+    if (split > 1 && (size_t)split * M * N * sizeof(float) > workspace_bytes) split = 1;
+    int cps = (nchunks + split - 1) / split;
+    split = (nchunks + cps - 1) / cps;
+    if (M <= 16) launch_skinny<1>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 32) launch_skinny<2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 64) launch_skinny<4>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 128) launch_skinny<8>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else launch_skinny<16>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    if (split > 1) {
+      long nq = (long)M * (N / 4);
+      hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace,
+                         split, M, N, *ep, *om);
+    }
+    return 0;
+  }
+  if ((K % TL_BK) != 0) return -1;
+  int tiles_m = (M + TL_BM - 1) / TL_BM, tiles_n = (N + TL_BN - 1) / TL_BN;
+  hipLaunchKernelGGL(lia_gemm_tiled_kernel, dim3(tiles_m * tiles_n), dim3(256), 4 * TL_TILE_BYTES, st, x, ldx, W, ldw,
+                     M, N, K, tiles_m, tiles_n, *ep, *om);
+  return 0;
+}
