@@ -120,9 +120,11 @@ int lia_attention(const lia_bf16* q, long ldq, const lia_bf16* kcache, const lia
 int lia_embed(const int64_t* ids, const lia_bf16* tok, const lia_bf16* pos, lia_bf16* y, int B, int T, int past_len, int H,
               void* stream);
 /* final LN on the last position + tied lm_head + greedy argmax: modeling_opt.py:1563, models.py:424-431,
- * greedy_search.py:367,395.  scratch: device, >= 2*B*H bf16.  logits [B,vocab], next_ids [B] (device). */
+ * greedy_search.py:367,395.  logits [B,vocab], next_ids [B] (device).  suppress_token >= 0: that token's score
+ * counts as -inf (EOS while min_new_tokens is unmet, run_generation.py:173,179-182); -1: none. */
 int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* lnw, const lia_bf16* lnb,
-                const lia_bf16* emb, int vocab, float eps, lia_bf16* logits, int64_t* next_ids, void* stream);
+                const lia_bf16* emb, int vocab, float eps, int suppress_token, lia_bf16* logits, int64_t* next_ids,
+                void* stream);
 
 /* ---- host side of the cooperative policies -------------------------------------------------------
  * Indirect-access-KV masked MHA, csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp:513-842: fp32
@@ -166,6 +168,10 @@ int lia_numa_unregister(void* ptr);
 /* pinned host memory (Tensor.pin_memory(), modeling_opt.py:207-227) */
 void* lia_host_alloc_pinned(size_t size);
 void lia_host_free_pinned(void* p);
+
+/* blocking copies between a host range and device memory (model placement, lia/modeling_opt.py:229-268) */
+int lia_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
+int lia_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
 
 /* TPP-blocked [N/16,K/64,32,16,2] <-> row-major [N,K] on the host (_weight_prepack.py:19-63;
  * attentions.py:381-382) */

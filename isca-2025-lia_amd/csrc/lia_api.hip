@@ -19,7 +19,7 @@ extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g,
                                      long rows, int H, float eps, hipStream_t st);
 extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* y, int B, int T,
                                  int past_len, int H, hipStream_t st);
-extern "C" void lia_argmax_launch(const bf16_t* logits, int64_t* out, int B, int vocab, hipStream_t st);
+extern "C" void lia_argmax_launch(const bf16_t* logits, int64_t* out, int B, int vocab, int suppress, hipStream_t st);
 extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
                                        int B, int T, int heads, int d, int Bc, int b0, hipStream_t st);
 extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
@@ -304,8 +304,8 @@ extern "C" int lia_embed(const int64_t* ids, const lia_bf16* tok, const lia_bf16
 }
 
 extern "C" int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* lnw,
-                           const lia_bf16* lnb, const lia_bf16* emb, int vocab, float eps, lia_bf16* logits,
-                           int64_t* next_ids, void* stream) {
+                           const lia_bf16* lnb, const lia_bf16* emb, int vocab, float eps, int suppress_token,
+                           lia_bf16* logits, int64_t* next_ids, void* stream) {
   if (!ctx) return LIA_ERR_INVALID;
   if (!hidden || !lnw || !lnb || !emb || !logits || !next_ids) { lia_set_error("lia_lm_head: NULL tensor"); return LIA_ERR_MISSING; }
   if (B <= 0 || B > 256 || T <= 0 || vocab % 16) { lia_set_error("lia_lm_head: B=%d (<=256) T=%d vocab=%d (%%16)", B, T, vocab); return LIA_ERR_INVALID; }
@@ -322,7 +322,7 @@ extern "C" int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, i
   size_t have = ctx->ws_bytes - scratch;
   int rc = gemm_checked(ctx, lno, H, emb, B, vocab, H, ep, om, (float*)(ctx->ws + scratch), std::min(have, gemm_need), 0, st);
   if (rc) return rc;
-  lia_argmax_launch(logits, next_ids, B, vocab, st);
+  lia_argmax_launch(logits, next_ids, B, vocab, suppress_token, st);
   HIP_TRY(hipGetLastError());
   return LIA_OK;
 }
@@ -616,6 +616,17 @@ extern "C" void* lia_host_alloc_pinned(size_t size) {
   return p;
 }
 extern "C" void lia_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int lia_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes) {
+  if (!dst_device || !src_host) return LIA_ERR_MISSING;
+  HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+  return LIA_OK;
+}
+extern "C" int lia_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes) {
+  if (!dst_host || !src_device) return LIA_ERR_MISSING;
+  HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+  return LIA_OK;
+}
 
 extern "C" int lia_numa_register(void* ptr, size_t size) {
   if (!ptr || !size) return LIA_ERR_INVALID;

@@ -85,15 +85,17 @@ extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf
 }
 
 // Greedy argmax over bf16 logits [B, vocab], first maximal index on ties (greedy_search.py:367,395).
+// `suppress` (or -1): a token whose score counts as -inf -- what HF's MinNewTokensLengthLogitsProcessor does
+// to EOS while min_new_tokens is not reached (run_generation.py:173,179-182 sets min_new_tokens = max_new_tokens).
 __global__ __launch_bounds__(256) void lia_argmax_kernel(const bf16_t* __restrict__ logits, int64_t* __restrict__ out,
-                                                          int vocab) {
+                                                          int vocab, int suppress) {
   __shared__ float sv[4];
   __shared__ int si[4];
   const bf16_t* row = logits + (long)blockIdx.x * vocab;
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = threadIdx.x; i < vocab; i += 256) {
-    float f = bf2f(row[i]);
+    float f = i == suppress ? -INFINITY : bf2f(row[i]);
     if (f > best || (f == best && i < bi)) { best = f; bi = i; }
   }
 #pragma unroll
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void lia_argmax_kernel(const bf16_t* __restric
   }
 }
 
-extern "C" void lia_argmax_launch(const bf16_t* logits, int64_t* out, int B, int vocab, hipStream_t st) {
+extern "C" void lia_argmax_launch(const bf16_t* logits, int64_t* out, int B, int vocab, int suppress, hipStream_t st) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(lia_argmax_kernel, dim3(B), dim3(256), 0, st, logits, out, vocab);
+  hipLaunchKernelGGL(lia_argmax_kernel, dim3(B), dim3(256), 0, st, logits, out, vocab, suppress);
 }

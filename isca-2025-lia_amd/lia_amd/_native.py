@@ -52,7 +52,7 @@ SIGNATURES = {
                               c_int, c_int, c_void_p]),
     "lia_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lia_lm_head": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
-                            c_void_p, c_void_p, c_void_p]),
+                            c_int, c_void_p, c_void_p, c_void_p]),
     "lia_host_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int]),
     "lia_stream_create": (c_int, [c_void_p, c_int, c_size_t, ctypes.POINTER(c_void_p)]),
@@ -73,6 +73,8 @@ SIGNATURES = {
     "lia_numa_unregister": (c_int, [c_void_p]),
     "lia_host_alloc_pinned": (c_void_p, [c_size_t]),
     "lia_host_free_pinned": (None, [c_void_p]),
+    "lia_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lia_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lia_tpp_unblock": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "lia_tpp_block": (c_int, [c_void_p, c_void_p, c_int, c_int]),
 }

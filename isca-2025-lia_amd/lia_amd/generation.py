@@ -1,0 +1,91 @@
+"""generate() + the greedy loop: counterpart of GenerationMixin.generate with the LIA edits
+(lia/generation_utils.py:1166-1170, 1542-1558) and IPEX's _greedy_search
+(intel_extension_for_pytorch/transformers/generation/greedy_search.py:37-458).
+
+Same call convention as the reference harness uses (llm/single_instance/run_generation.py:179-182,
+319-320):
+
+    out = generate(model, input_ids, do_sample=False, num_beams=1, max_new_tokens=N, min_new_tokens=N,
+                   prefill_policy=, decoding_policy=, no_overlap=, pin_weight=, gpu_percentage=,
+                   num_minibatch=, enable_cxl=, token_latency=True)
+    ids, latency_list = out        # (ids only when token_latency is False)
+
+latency_list[i] is the wall clock of greedy iteration i (prepare inputs -> forward -> lm_head -> argmax
+-> append), exactly the quantity greedy_search.py:145,424 records: [0] is the prefill, [1:] the decode steps.
+"""
+import time
+
+import torch
+
+from .scheduler import KVState, OffloadScheduler
+
+LIA_KWARGS = ("prefill_policy", "decoding_policy", "no_overlap", "pin_weight", "gpu_percentage", "num_minibatch",
+              "enable_cxl")
+
+
+def _scheduler_of(model):
+    if getattr(model, "_lia_scheduler", None) is None:
+        model._lia_scheduler = OffloadScheduler(model)
+    return model._lia_scheduler
+
+
+def generate(model, input_ids, max_new_tokens=None, min_new_tokens=None, do_sample=False, num_beams=1,
+             eos_token_id=2, pad_token_id=1, token_latency=False, return_logits=False, **model_kwargs):
+    if do_sample or num_beams != 1:
+        raise ValueError("only greedy search carries the LIA kwargs (run.py --greedy; beam/sample paths are not plumbed "
+                         "in the reference either)")
+    if max_new_tokens is None or max_new_tokens < 1:
+        raise ValueError("max_new_tokens must be >= 1")
+    # unknown kwargs are NOT rejected: the reference disables that check so its flags reach forward()
+    # (lia/generation_utils.py:1166-1170)
+    lia = {k: model_kwargs.pop(k, None) for k in LIA_KWARGS}
+    lia = {"prefill_policy": 1 if lia["prefill_policy"] is None else lia["prefill_policy"],
+           "decoding_policy": 1 if lia["decoding_policy"] is None else lia["decoding_policy"],
+           "no_overlap": bool(lia["no_overlap"]), "pin_weight": bool(lia["pin_weight"]),
+           "gpu_percentage": lia["gpu_percentage"] or 0, "num_minibatch": lia["num_minibatch"] or 1,
+           "enable_cxl": bool(lia["enable_cxl"])}
+    min_new = min_new_tokens or 0
+    return _greedy_search(model, input_ids, max_new_tokens, min_new, eos_token_id, pad_token_id, token_latency,
+                          return_logits, lia)
+
+
+def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_id, pad_token_id, token_latency,
+                   return_logits, lia):
+    sched = _scheduler_of(model)
+    ids = torch.as_tensor(input_ids, dtype=torch.int64).cpu()
+    if ids.dim() != 2:
+        raise ValueError("input_ids must be [batch, seq]")
+    B, T = ids.shape
+    if T + max_new_tokens > model.shape.max_pos:
+        raise ValueError(f"prompt {T} + max_new_tokens {max_new_tokens} exceeds max positions {model.shape.max_pos}")
+    L = model.shape.layers
+    n_gpu = int(L * lia["gpu_percentage"] / 100)
+    kv = KVState(model, n_gpu, B, T + max_new_tokens)   # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278
+    unfinished = torch.ones(B, dtype=torch.int64)
+    latency_list, logits_list = [], []
+    cur = ids
+    step = 0
+    while True:
+        tic = time.time()
+        # EOS is suppressed while fewer than min_new_tokens were generated (HF MinNewTokensLengthLogitsProcessor)
+        suppress = eos_token_id if (eos_token_id is not None and step < min_new_tokens) else -1
+        logits, nxt = sched.forward(cur, kv, max_new_tokens=max_new_tokens, suppress_token=suppress, **lia)
+        next_tokens = nxt.cpu()
+        if eos_token_id is not None:
+            next_tokens = next_tokens * unfinished + pad_token_id * (1 - unfinished)   # greedy_search.py:398-405
+        ids = torch.cat([ids, next_tokens[:, None]], dim=-1)                           # :408
+        if eos_token_id is not None:
+            unfinished = unfinished * (next_tokens != eos_token_id).long()             # :415-421
+        cur = next_tokens[:, None]
+        step += 1
+        if return_logits:
+            logits_list.append(logits.clone())
+        latency_list.append(time.time() - tic)                                         # :424
+        if unfinished.max() == 0 or step >= max_new_tokens:
+            break
+    out = ids
+    if return_logits:
+        return out, latency_list, logits_list
+    if token_latency:
+        return out, latency_list
+    return out

@@ -1,0 +1,275 @@
+"""OPT model container for the LIA hot path: shapes, weight tiers (HBM-resident / pinned host /
+NUMA-CXL host / pageable host) and the packed per-layer wire format.
+
+Reference counterparts:
+  * shapes                      llm/utils/opt-weight-gen.py:84-96 (+ HF OPT configs)
+  * move_gpu_layer              lia/modeling_opt.py:229-268   -> LayerStore.to_device()
+  * pin_memory (pinned / CXL)   lia/modeling_opt.py:167-227   -> LayerStore.to_pinned() / to_cxl()
+  * create_buffer's 16 tensors  lia/modeling_opt.py:90-126    -> one packed flat buffer per layer
+  * dummy weights               llm/utils/opt-weight-gen.py:61-69 (torch.rand_like, unseeded) -> init="uniform01", seeded
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import ops
+
+LAYER_TENSORS = ops.LAYER_TENSORS
+
+
+@dataclass(frozen=True)
+class OPTShape:
+    name: str
+    hidden: int
+    heads: int
+    ffn: int
+    layers: int
+    vocab: int = 50272
+    max_pos: int = 2048
+    ln_eps: float = 1e-5
+
+    @property
+    def head_dim(self):
+        return self.hidden // self.heads
+
+    def layer_param_bytes(self):
+        H, F = self.hidden, self.ffn
+        return 2 * (4 * H * H + 2 * H * F + 9 * H + F)
+
+
+# do_layer_norm_before=True family only (opt-350m is post-LN with a 512-wide projection: out of scope)
+SHAPES = {s.name: s for s in (
+    OPTShape("opt-125m", 768, 12, 3072, 12),
+    OPTShape("opt-1.3b", 2048, 32, 8192, 24),
+    OPTShape("opt-2.7b", 2560, 32, 10240, 32),
+    OPTShape("opt-6.7b", 4096, 32, 16384, 32),
+    OPTShape("opt-13b", 5120, 40, 20480, 40),
+    OPTShape("opt-30b", 7168, 56, 28672, 48),
+    OPTShape("opt-66b", 9216, 72, 36864, 64),
+    OPTShape("opt-175b", 12288, 96, 49152, 96),
+)}
+
+
+def resolve_shape(name):
+    key = name.lower().split("/")[-1]
+    if key not in SHAPES:
+        raise ValueError(f"unknown OPT shape {name!r}; known: {sorted(SHAPES)}")
+    return SHAPES[key]
+
+
+class LayerStore:
+    """One decoder layer's 16 tensors packed into a flat 256-byte-aligned buffer (lia_layer_pack_offsets),
+    living in exactly one tier at a time."""
+
+    def __init__(self, desc, offsets, total_bytes):
+        self.desc, self.offsets, self.nbytes = desc, offsets, total_bytes
+        self.tier = None          # "device" | "pinned" | "cxl" | "pageable"
+        self._dev = None          # torch uint8 CUDA tensor
+        self._np = None           # numpy uint8 (pageable)
+        self._ptr = None          # raw host pointer (pinned / cxl)
+        self._lib = N.lib()
+
+    # -- construction -----------------------------------------------------------------------------
+    def set_from_device(self, flat_u8):
+        assert flat_u8.is_cuda and flat_u8.dtype == torch.uint8 and flat_u8.numel() == self.nbytes
+        self._free()
+        self._dev, self.tier = flat_u8, "device"
+
+    def set_from_numpy(self, tensors):
+        """tensors: dict name -> uint16 ndarray (bf16 bits), row-major linears."""
+        flat = np.zeros(self.nbytes, np.uint8)
+        for i, n in enumerate(LAYER_TENSORS):
+            a = np.ascontiguousarray(tensors[n], dtype=np.uint16).reshape(-1).view(np.uint8)
+            flat[self.offsets[i]: self.offsets[i] + a.size] = a
+        self._free()
+        self._np, self.tier = flat, "pageable"
+
+    # -- tier moves -------------------------------------------------------------------------------
+    def _host_view(self):
+        if self.tier == "pageable":
+            return self._np
+        if self.tier in ("pinned", "cxl"):
+            return np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self._ptr))
+        raise RuntimeError("layer is on the device")
+
+    def host_ptr(self):
+        if self.tier == "pageable":
+            return self._np.ctypes.data
+        if self.tier in ("pinned", "cxl"):
+            return self._ptr
+        raise RuntimeError("layer is on the device")
+
+    def device_ptr(self):
+        assert self.tier == "device"
+        return self._dev.data_ptr()
+
+    def _fill_host(self, ptr):
+        if self.tier == "device":
+            N.check(self._lib.lia_memcpy_d2h(ptr, self._dev.data_ptr(), self.nbytes), "lia_memcpy_d2h")
+        else:
+            dst = np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(ptr))
+            dst[:] = self._host_view()
+
+    def to_device(self):
+        """move_gpu_layer (lia/modeling_opt.py:229-268), minus the un-blocking (weights are already row-major)."""
+        if self.tier == "device":
+            return
+        dev = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
+        N.check(self._lib.lia_memcpy_h2d(dev.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
+        self._free()
+        self._dev, self.tier = dev, "device"
+
+    def to_pinned(self):
+        """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227)."""
+        if self.tier == "pinned":
+            return
+        ptr = self._lib.lia_host_alloc_pinned(self.nbytes)
+        if not ptr:
+            raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
+        self._fill_host(ptr)
+        self._free()
+        self._ptr, self.tier = ptr, "pinned"
+
+    def to_cxl(self):
+        """realloc_to_numa (lia/modeling_opt.py:168-175) + hipHostRegister so the copy engine can DMA from it
+        (the reference leaves the CXL copy pageable, lia/cxl/numa_alloc.py:49)."""
+        if self.tier == "cxl":
+            return
+        ptr = self._lib.numa_alloc_interleave(self.nbytes)
+        if not ptr:
+            raise MemoryError("Fail to allocate CXL memory!")  # same text as lia/modeling_opt.py:175
+        self._fill_host(ptr)
+        rc = self._lib.lia_numa_register(ptr, self.nbytes)
+        if rc != 0:
+            self._lib.numa_free_node(ptr, self.nbytes)
+            N.check(rc, "lia_numa_register")
+        self._free()
+        self._ptr, self.tier = ptr, "cxl"
+
+    def is_dma_able(self):
+        return self.tier in ("pinned", "cxl")
+
+    def _free(self):
+        if self.tier == "pinned" and self._ptr:
+            self._lib.lia_host_free_pinned(self._ptr)
+        elif self.tier == "cxl" and self._ptr:
+            self._lib.lia_numa_unregister(self._ptr)
+            self._lib.numa_free_node(self._ptr, self.nbytes)
+        self._ptr = self._dev = self._np = None
+        self.tier = None
+
+    def close(self):
+        self._free()
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+class LiaOPTModel:
+    """Weights of an OPT decoder-only LM laid out for the offload scheduler.
+
+    embed_tokens (tied lm_head), embed_positions and the final LayerNorm always live in HBM (the
+    reference keeps them on the CPU, lia/modeling_opt.py:1108,1563 + models.py:430)."""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.desc = ops.make_desc(shape.hidden, shape.heads, shape.ffn, shape.ln_eps)
+        self.offsets, self.layer_bytes = ops.pack_offsets(self.desc)
+        self.layers = [LayerStore(self.desc, self.offsets, self.layer_bytes) for _ in range(shape.layers)]
+        self.embed_tokens = self.embed_positions = self.final_ln_w = self.final_ln_b = None
+        self.placed_for = None  # (n_gpu_layers, pin_weight, enable_cxl) of the last placement
+
+    # -- builders ---------------------------------------------------------------------------------
+    @classmethod
+    def from_numpy(cls, shape, m):
+        """m: dict from tests/golden/synth.make_model (uint16 bf16 bit arrays)."""
+        self = cls(shape)
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(torch.bfloat16).cuda()
+
+        self.embed_tokens, self.embed_positions = dev(m["embed_tokens"]), dev(m["embed_positions"])
+        self.final_ln_w, self.final_ln_b = dev(m["final_ln_w"]), dev(m["final_ln_b"])
+        for st, lw in zip(self.layers, m["layers"]):
+            st.set_from_numpy(lw)
+        return self
+
+    @classmethod
+    def random_init(cls, shape, seed=0, init="normal", n_gpu_layers=0, pin_weight=True, enable_cxl=False):
+        """Random-init weights of the exact architecture, generated ON THE GPU one layer at a time and
+        moved straight to their tier (an OPT-30B would take minutes to draw on the CPU).
+        init="normal": HF _init_weights (lia/modeling_opt.py:895-904): Linear/Embedding ~ N(0, 0.02), zero
+        bias, LN = (1, 0).  init="uniform01": the reference's dummy recipe (opt-weight-gen.py:61-62), seeded."""
+        self = cls(shape)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        H, F = shape.hidden, shape.ffn
+
+        def draw(*size):
+            if init == "uniform01":
+                return torch.rand(*size, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+            return (0.02 * torch.randn(*size, generator=g, device="cuda", dtype=torch.float32)).to(torch.bfloat16)
+
+        self.embed_tokens = draw(shape.vocab, H)
+        self.embed_positions = draw(shape.max_pos + 2, H)
+        self.final_ln_w = torch.ones(H, dtype=torch.bfloat16, device="cuda")
+        self.final_ln_b = torch.zeros(H, dtype=torch.bfloat16, device="cuda")
+        shapes = {"q_w": (H, H), "k_w": (H, H), "v_w": (H, H), "out_w": (H, H), "fc1_w": (F, H), "fc2_w": (H, F)}
+        for li, st in enumerate(self.layers):
+            flat = torch.zeros(self.layer_bytes // 2, dtype=torch.bfloat16, device="cuda")
+            for i, n in enumerate(LAYER_TENSORS):
+                o = self.offsets[i] // 2
+                if n in shapes:
+                    r, c = shapes[n]
+                    flat[o:o + r * c] = draw(r, c).reshape(-1)
+                elif n in ("ln1_w", "ln2_w"):
+                    flat[o:o + H] = 1.0
+                elif init == "uniform01":
+                    k = F if n == "fc1_b" else H
+                    flat[o:o + k] = draw(k)
+            st.set_from_device(flat.view(torch.uint8))
+            if li >= n_gpu_layers:
+                if enable_cxl:
+                    st.to_cxl()
+                elif pin_weight:
+                    st.to_pinned()
+                else:
+                    st.to_pinned()  # leave the device; demoted to pageable below
+                    host = np.array(st._host_view(), copy=True)
+                    st._free()
+                    st._np, st.tier = host, "pageable"
+        torch.cuda.synchronize()
+        self.placed_for = (n_gpu_layers, pin_weight, enable_cxl)
+        return self
+
+    # -- placement (first forward) ------------------------------------------------------------------
+    def place(self, n_gpu_layers, pin_weight, enable_cxl):
+        """Idempotent tier assignment done on the first forward, as move_gpu_layer / pin_memory are
+        (lia/modeling_opt.py:1182-1184, 1214-1217)."""
+        key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
+        if self.placed_for == key:
+            return
+        for i, st in enumerate(self.layers):
+            if i < n_gpu_layers:
+                st.to_device()
+            elif st.tier == "device":
+                raise ValueError("gpu_percentage shrank between calls: resident layers cannot be demoted")
+            elif enable_cxl and pin_weight:
+                st.to_cxl()
+            elif pin_weight:
+                st.to_pinned()
+        torch.cuda.synchronize()
+        self.placed_for = key
+
+    def streamed_bytes(self, n_gpu_layers):
+        return (self.shape.layers - n_gpu_layers) * self.layer_bytes
+
+    def close(self):
+        for st in self.layers:
+            st.close()

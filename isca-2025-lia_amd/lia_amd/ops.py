@@ -110,14 +110,14 @@ class Context:
         N.check(self.lib.lia_embed(_ptr(ids), _ptr(tok), _ptr(pos), _ptr(y), B, T, past_len, H, self._st(stream)), "lia_embed")
         return y
 
-    def lm_head(self, hidden, lnw, lnb, emb, eps=1e-5, stream=None):
+    def lm_head(self, hidden, lnw, lnb, emb, eps=1e-5, suppress_token=-1, stream=None):
         for t in (hidden, lnw, lnb, emb):
             _chk(t)
         B, T, H = hidden.shape
         vocab = emb.shape[0]
         logits = torch.empty((B, vocab), dtype=torch.bfloat16, device=hidden.device)
         nxt = torch.empty((B,), dtype=torch.int64, device=hidden.device)
-        N.check(self.lib.lia_lm_head(self.handle, _ptr(hidden), B, T, H, _ptr(lnw), _ptr(lnb), _ptr(emb), vocab, eps, _ptr(logits),
+        N.check(self.lib.lia_lm_head(self.handle, _ptr(hidden), B, T, H, _ptr(lnw), _ptr(lnb), _ptr(emb), vocab, eps, suppress_token, _ptr(logits),
                                      _ptr(nxt), self._st(stream)), "lia_lm_head")
         return logits, nxt
 

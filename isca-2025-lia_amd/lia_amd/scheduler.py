@@ -1,0 +1,232 @@
+"""The offload scheduler: MI355X-native counterpart of OPTDecoder.forward (lia/modeling_opt.py:1021-1586).
+
+Same policy table (lia/modeling_opt.py:1167-1176), same flag surface, different machinery:
+
+  reference                                                   here
+  ---------------------------------------------------------   ------------------------------------------------------
+  16 copy_ per layer on load_weight_stream (:270-293)          ONE pinned hipMemcpyAsync of the packed layer on the
+                                                               streamer's copy stream into an HBM slot
+  torch.cuda.synchronize() after every minibatch/layer          hipEvent handshakes slot<->compute stream; the host only
+  (:1298,1339,1346,1506,1528)                                   blocks for the policy-2 host attention round trip
+  first streamed layer loaded synchronously at the start        prefetch runs ahead across token steps (after the last
+  of every forward (:1287-1298, :1497-1506)                     layer it wraps to the first streamed layer), so the copy
+                                                               engine never idles between forwards
+  hidden states bounced through pinned host memory             the whole-batch hidden state stays in HBM (235 MB at
+  (:1262-1267, load_activation/store_hidden :320-355)          B=64,T=256,H=7168; the GPU has 288 GB)
+  GPU-side un-blocking of every streamed weight (G2)           none: host weights are row-major
+  KV cache host tensors re-pinned per call (:1381-1387)        pinned once per generation
+  embed / final LN / lm_head on the CPU                        on the GPU (weights resident), last position only
+
+Weights of layers [0, n_gpu) are HBM-resident (policy 3, KV in HBM); layers [n_gpu, L) are streamed and
+run the phase's policy: prefill 0 (minibatched, K/V delivered to the host cache) | decode 2 (GPU linears
++ host attention) | decode 0 (cached rows fetched to the GPU).  Policy 1 (all-CPU) is the IPEX baseline
+and is not scheduled here.
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+from . import ops
+
+
+class WeightPipeline:
+    """Slot bookkeeping over lia_stream_*: prefetch(layer) -> acquire(layer) -> release(layer)."""
+
+    def __init__(self, ctx, model, n_slots):
+        self.ctx, self.model, self.lib = ctx, model, N.lib()
+        h = ctypes.c_void_p()
+        N.check(self.lib.lia_stream_create(ctx.handle, n_slots, model.layer_bytes, ctypes.byref(h)), "lia_stream_create")
+        self.handle, self.n_slots = h, n_slots
+        self.next_slot = 0
+        self.inflight = []          # [(layer_idx, slot)] in issue order, not yet acquired
+        self.held = {}              # layer_idx -> slot (acquired, not yet released)
+        self.slot_ptrs = [self.lib.lia_stream_slot_ptr(h, s) for s in range(n_slots)]
+        self.ptr_arrays = [ops.weight_ptr_array(p, model.offsets) for p in self.slot_ptrs]
+
+    def can_prefetch(self):
+        return len(self.inflight) + len(self.held) < self.n_slots
+
+    def prefetch(self, layer_idx):
+        if any(li == layer_idx for li, _ in self.inflight) or layer_idx in self.held:
+            return
+        if not self.can_prefetch():
+            return
+        st = self.model.layers[layer_idx]
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % self.n_slots
+        N.check(self.lib.lia_stream_prefetch(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.nbytes, int(st.is_dma_able())),
+                "lia_stream_prefetch")
+        self.inflight.append((layer_idx, slot))
+
+    def acquire(self, layer_idx):
+        """Make the compute stream wait for the layer's copy; returns the 16 device pointers."""
+        if not self.inflight or self.inflight[0][0] != layer_idx:
+            # nothing (or something else) was prefetched: drop stale prefetches, load on demand
+            self.inflight = [(li, s) for li, s in self.inflight if li == layer_idx]
+            if not self.inflight:
+                self.prefetch(layer_idx)
+        li, slot = self.inflight.pop(0)
+        assert li == layer_idx
+        N.check(self.lib.lia_stream_wait(self.handle, slot, ctypes.c_void_p(self.ctx.stream)), "lia_stream_wait")
+        self.held[layer_idx] = slot
+        return self.ptr_arrays[slot]
+
+    def release(self, layer_idx):
+        slot = self.held.pop(layer_idx)
+        N.check(self.lib.lia_stream_release(self.handle, slot, ctypes.c_void_p(self.ctx.stream)), "lia_stream_release")
+
+    def stats(self, reset=False):
+        b, ms = ctypes.c_double(), ctypes.c_double()
+        N.check(self.lib.lia_stream_stats(self.handle, ctypes.byref(b), ctypes.byref(ms), int(reset)))
+        return b.value, ms.value
+
+    def close(self):
+        if self.handle:
+            self.lib.lia_stream_destroy(self.handle)
+            self.handle = None
+
+
+class KVState:
+    """Per-layer KV caches of one generation: seq-major [Smax,B,h,d] (attentions.py:462-476), in HBM for
+    resident layers and in pinned host memory for streamed ones (lia/modeling_opt.py:1270-1281)."""
+
+    def __init__(self, model, n_gpu, B, smax):
+        sh = model.shape
+        self.B, self.smax, self.len = B, smax, 0
+        self.tensors, self.kv = [], []
+        for i in range(sh.layers):
+            if i < n_gpu:
+                k = torch.empty((smax, B, sh.heads, sh.head_dim), dtype=torch.bfloat16, device="cuda")
+                v = torch.empty_like(k)
+                on_dev = 1
+            else:
+                k = torch.empty((smax, B, sh.heads, sh.head_dim), dtype=torch.bfloat16, pin_memory=True)
+                v = torch.empty((smax, B, sh.heads, sh.head_dim), dtype=torch.bfloat16, pin_memory=True)
+                on_dev = 0
+            self.tensors.append((k, v))
+            self.kv.append(N.KV(k.data_ptr(), v.data_ptr(), smax, B, on_dev))
+
+
+class OffloadScheduler:
+    """forward(input_ids, kv_state, **lia flags) -> (logits [B,vocab], next_ids [B]) on the device."""
+
+    def __init__(self, model, device=0, n_slots=None):
+        import os
+        self.model, self.device = model, device
+        self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "2"))
+        self.ctx = None
+        self.ws_rows = 0
+        self.pipe = None
+        self.hidden = {}
+        self.resident_ptrs = {}
+        self.last_step_ms = {}
+
+    # -- resources -----------------------------------------------------------------------------------
+    def _ensure(self, rows, B, T, n_gpu):
+        """Context workspace (sized by the largest layer call seen so far), streamer slots, hidden buffers."""
+        sh = self.model.shape
+        lm_bytes = 2 * 256 * sh.hidden + 8 * min(B, 256) * sh.vocab * 4 + (1 << 20)
+        need = max(ops.workspace_bytes(self.model.desc, rows), lm_bytes)
+        if self.ctx is None or need > self.ctx.workspace_bytes:
+            if self.pipe is not None:
+                self.pipe.close()
+                self.pipe = None
+            if self.ctx is not None:
+                self.ctx.close()
+            self.ctx = ops.Context(self.device, need)
+        if self.pipe is None and n_gpu < sh.layers:
+            self.pipe = WeightPipeline(self.ctx, self.model, self.n_slots)
+        key = (B, T)
+        if key not in self.hidden:
+            if len(self.hidden) > 4:
+                self.hidden.clear()
+            self.hidden[key] = (torch.empty((B, T, sh.hidden), dtype=torch.bfloat16, device="cuda"),
+                                torch.empty((B, T, sh.hidden), dtype=torch.bfloat16, device="cuda"))
+        return self.hidden[key]
+
+    def _resident(self, idx):
+        if idx not in self.resident_ptrs:
+            self.resident_ptrs[idx] = ops.weight_ptr_array(self.model.layers[idx].device_ptr(), self.model.offsets)
+        return self.resident_ptrs[idx]
+
+    # -- one forward -----------------------------------------------------------------------------------
+    def forward(self, input_ids, kv_state, prefill_policy=1, decoding_policy=1, no_overlap=False, pin_weight=False,
+                gpu_percentage=0, num_minibatch=1, enable_cxl=False, max_new_tokens=None, suppress_token=-1):
+        m, sh = self.model, self.model.shape
+        B, T = input_ids.shape
+        L = sh.layers
+        n_gpu = int(L * gpu_percentage / 100)                      # lia/modeling_opt.py:1182
+        is_prefill = T != 1                                        # :1186-1188
+        policy = prefill_policy if is_prefill else decoding_policy
+        if n_gpu < L and policy == 1:
+            raise NotImplementedError(
+                "policy 1 (everything on the CPU) is the IPEX baseline, not a GPU schedule; "
+                "run it with lia_amd.cpu_baseline (timed beside the GPU path by bench.py)")
+        if n_gpu < L and policy not in (0, 2):
+            raise ValueError(f"unsupported policy {policy} (prefill: 0; decode: 0 or 2)")
+        if is_prefill and policy == 2 and n_gpu < L:
+            raise ValueError("prefill policy must be 0 on the GPU path (the reference has no prefill-2 branch)")
+        if B % num_minibatch:
+            raise ValueError(f"batch {B} not divisible by num_minibatch {num_minibatch}")
+        mini = B // num_minibatch if (policy == 0) else B          # :1178 mini_bsz
+        overlap = not no_overlap
+
+        m.place(n_gpu, pin_weight, enable_cxl)                    # move_gpu_layer / pin_memory, idempotent
+        rows = B * T if n_gpu > 0 else mini * T                    # resident layers take the whole batch
+        if policy == 0 and n_gpu < L:
+            rows = max(rows, mini * kv_state.smax)                 # policy-0 decode parks the cached prefix in a slab
+        x, y = self._ensure(rows, B, T, n_gpu)
+        ctx, pipe = self.ctx, self.pipe
+        pos0 = kv_state.len
+
+        ids_dev = input_ids.to("cuda", non_blocking=False).contiguous()
+        N.check(ctx.lib.lia_embed(ctypes.c_void_p(ids_dev.data_ptr()), ctypes.c_void_p(m.embed_tokens.data_ptr()),
+                                  ctypes.c_void_p(m.embed_positions.data_ptr()), ctypes.c_void_p(x.data_ptr()), B, T, pos0,
+                                  sh.hidden, ctypes.c_void_p(ctx.stream)), "lia_embed")
+
+        first_streamed = n_gpu
+        if n_gpu < L and overlap:
+            pipe.prefetch(first_streamed)                          # no-op if the previous step already wrapped to it
+        for idx in range(L):
+            if idx < n_gpu:
+                # resident layer: whole batch, everything on the GPU incl. KV (policy 3; :1246-1260)
+                ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
+                x, y = y, x
+                continue
+            if not overlap:
+                pipe.prefetch(idx)
+            wptrs = pipe.acquire(idx)
+            if overlap:
+                # weight prefetch of the next streamed layer overlaps this layer's compute (:1305-1312, :1508-1515);
+                # after the last layer it wraps to the first streamed layer of the NEXT forward
+                nxt = idx + 1 if idx + 1 < L else first_streamed
+                pipe.prefetch(nxt)
+            if policy == 0:
+                for i in range(num_minibatch):                     # FlexGen-style minibatches (:1283-1365)
+                    sl = slice(i * mini, (i + 1) * mini)
+                    ctx.layer_forward(m.desc, 0, wptrs, x[sl], y[sl], kv_state.kv[idx], mini, T, pos0, i * mini)
+            else:
+                ctx.layer_forward(m.desc, 2, wptrs, x, y, kv_state.kv[idx], B, T, pos0, 0)   # :1493-1543
+            pipe.release(idx)
+            x, y = y, x
+            if not overlap:
+                ctx.synchronize()
+
+        logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
+        ctx.synchronize()
+        if policy == 0:
+            ctx.kv_store_wait()                                    # host cache complete before the next step reads it
+        kv_state.len = pos0 + T
+        return logits, nxt
+
+    def stream_stats(self, reset=False):
+        return self.pipe.stats(reset) if self.pipe else (0.0, 0.0)
+
+    def close(self):
+        if self.pipe:
+            self.pipe.close()
+            self.pipe = None
+        if self.ctx:
+            self.ctx.close()
+            self.ctx = None
