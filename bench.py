@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the LIA hot path on MI355X: OPT-30B, bs=64, in 256 / out 32, gpu%=10,
+prefill policy 0 / decode policy 2 (BASELINE.json configs[1], the paper headline).
+
+A "step" is one decode step of the whole batch (every row advances one token) through the offload
+scheduler: 4 HBM-resident layers + 44 layers streamed from pinned host memory, GPU linears, host
+attention.  The timed region is EXACTLY --steps decode steps after one prefill and --warmup untimed
+decode steps, bracketed by barrier + synchronize; value = batch * steps / elapsed (tokens/s).  The
+prefill is timed separately (prefill_ms = latency_list[0] of the reference's protocol,
+run_generation.py:345-354).  Weights: random-init of the exact architecture (no checkpoints offline).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model opt-30b] [--batch 64] [--prompt 256]
+
+N > 1 (launched by torch.distributed.run): batch-sharded data parallel, one rank per GPU, each rank owns
+`--batch` rows (weak scaling); rank 0 streams every layer once over PCIe and RCCL-broadcasts it over xGMI.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+# OpenMP teams park instead of spinning between the per-layer host-attention bursts (a spinning team burns
+# the container's CPU quota and the next burst is throttled); must be set before libgomp is mapped.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "isca-2025-lia_amd"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
+PCIE_PEAK_GBS = 63.0       # PCIe Gen5 x16 spec
+
+
+def cpu_baseline(shape, B, T, threads=None):
+    """The reference's policy-1 all-CPU path (IPEX/AMX there), timed here as the oracle's CPU restatement
+    ("port") on this box's host cores, on a bounded sample: ONE OPT-30B-shaped layer, one decode step at
+    S = T+1 and one prefill of B/8 rows, scaled to the full model."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import lia_oracle as orc
+    orc.lib()
+    from lia_amd import hostinfo
+    threads = threads or hostinfo.default_host_threads(1)
+    orc.lib().lia_oracle_set_threads(threads)
+    H, F, heads, L = shape.hidden, shape.ffn, shape.heads, shape.layers
+    rs = np.random.RandomState(0)
+    blk = (rs.standard_normal(1 << 20) * 0.02).astype(np.float32)
+    blk_bits = ((blk.view(np.uint32) + 0x8000) >> 16).astype(np.uint16)
+
+    def filled(*shp):
+        n = int(np.prod(shp))
+        return np.resize(blk_bits, n).reshape(shp)
+
+    W = {"ln1_w": filled(H), "ln1_b": filled(H), "q_w": filled(H, H), "q_b": filled(H), "k_w": filled(H, H),
+         "k_b": filled(H), "v_w": filled(H, H), "v_b": filled(H), "out_w": filled(H, H), "out_b": filled(H),
+         "ln2_w": filled(H), "ln2_b": filled(H), "fc1_w": filled(F, H), "fc1_b": filled(F), "fc2_w": filled(H, F),
+         "fc2_b": filled(H)}
+    d = H // heads
+    kc, vc = filled(T + 2, B, heads, d).copy(), filled(T + 2, B, heads, d).copy()
+    xd = filled(B, 1, H)
+    orc.layer_forward(1, W, xd, kc, vc, T, heads)      # warm (page-in, thread pool)
+    t0 = time.time()
+    reps = 2
+    for _ in range(reps):
+        orc.layer_forward(1, W, xd, kc, vc, T, heads)
+    dec_layer_s = (time.time() - t0) / reps
+    Bp = max(1, B // 8)
+    xp = filled(Bp, T, H)
+    kp, vp = filled(T + 2, Bp, heads, d).copy(), filled(T + 2, Bp, heads, d).copy()
+    t0 = time.time()
+    orc.layer_forward(1, W, xp, kp, vp, 0, heads)
+    pre_layer_s = (time.time() - t0) * (B / Bp)
+    return {"value": B / (dec_layer_s * L), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "cpu": hostinfo.cpu_model(), "isa": hostinfo.isa_flags(), "cpus_usable": hostinfo.usable_cpus(),
+            "prefill_ms": 1e3 * pre_layer_s * L,
+            "sample": f"oracle policy 1, ONE {shape.name}-shaped layer: decode step B={B} S={T + 1} x{reps} and prefill "
+                      f"B={Bp} T={T}; scaled x{L} layers (x{B // Bp} batch for prefill); embeddings/lm_head excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=31)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="opt-30b")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--prompt", type=int, default=256)
+    ap.add_argument("--gpu-percentage", type=int, default=10)
+    ap.add_argument("--prefill-policy", type=int, default=0)
+    ap.add_argument("--decoding-policy", type=int, default=2)
+    ap.add_argument("--num-minibatch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-threads", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lia_amd.model import LiaOPTModel, resolve_shape
+    from lia_amd.generation import LIA_KWARGS  # noqa: F401
+    from lia_amd.scheduler import KVState, OffloadScheduler
+    from lia_amd import dp
+
+    shape = resolve_shape(a.model)
+    B, T = a.batch, a.prompt
+    new = 1 + a.warmup + a.steps
+    if T + new > shape.max_pos:
+        raise SystemExit("prompt + steps exceeds max positions")
+    n_gpu = int(shape.layers * a.gpu_percentage / 100)
+    flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
+                 gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=False, no_overlap=False)
+
+    t_build = time.time()
+    group = dp.DataParallelGroup(dist, rank, world, local_rank) if world > 1 else None
+    model = LiaOPTModel.random_init(shape, seed=0, n_gpu_layers=n_gpu, pin_weight=True,
+                                    host_owner=(group is None or group.is_root))
+    sched = OffloadScheduler(model, device=local_rank, dp_group=group)
+    from lia_amd import hostinfo
+    host_threads = a.host_threads or hostinfo.default_host_threads(world)
+    g = torch.Generator().manual_seed(0)
+    row = torch.randint(4, shape.vocab, (T,), generator=g, dtype=torch.int64)
+    row[0] = 2
+    ids = row[None, :].repeat(B, 1)                      # identical rows, run_generation.py:285
+    build_s = time.time() - t_build
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed shake-out: allocations (pinned KV, workspace), page-in, clocks
+    kv = KVState(model, n_gpu, B, T + new)
+    sched.forward(ids, kv, max_new_tokens=new, **flags)
+    sched.ctx.set_host_threads(host_threads)
+    cur = ids[:, -1:].clone()
+    sched.forward(cur, kv, max_new_tokens=new, **flags)
+
+    # measured generation: prefill, W warm-up decode steps, K timed decode steps
+    kv.len = 0
+    sync()
+    t0 = time.time()
+    logits, nxt = sched.forward(ids, kv, max_new_tokens=new, **flags)
+    sync()
+    prefill_ms = 1e3 * (time.time() - t0)
+    cur = nxt.cpu()[:, None]
+    for _ in range(a.warmup):
+        logits, nxt = sched.forward(cur, kv, max_new_tokens=new, **flags)
+        cur = nxt.cpu()[:, None]
+    sched.stream_stats(reset=True)
+    sched.ctx.prof_start(16384)
+    sync()
+    t0 = time.time()
+    step_lat = []
+    for _ in range(a.steps):
+        ts = time.time()
+        logits, nxt = sched.forward(cur, kv, max_new_tokens=new, **flags)
+        cur = nxt.cpu()[:, None]
+        step_lat.append(time.time() - ts)
+    sync()
+    elapsed = time.time() - t0
+    prof = sched.ctx.prof_stop()
+    h2d_bytes, h2d_ms = sched.stream_stats()
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed, prefill_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed, prefill_ms = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        tokens = B * world * a.steps
+        sk_ms, sk_n = prof["skinny_ms"], max(1, prof["skinny_launches"])
+        achieved = prof["skinny_bytes"] / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
+        out = {
+            "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if (a.model == "opt-30b" and B == 64 and T == 256)
+                      else f"decode tokens/s (+ prefill ms), {a.model} bs={B} in{T} gpu%={a.gpu_percentage}",
+            "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{shape.name} shape (random-init N(0,0.02)), batch {B}/GPU identical rows, prompt {T}, "
+                                   f"gpu%={a.gpu_percentage} ({n_gpu} resident + {shape.layers - n_gpu} streamed layers), "
+                                   f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight, "
+                                   f"num-minibatch {a.num_minibatch}",
+                       "global_batch": B * world, "prompt_len": T, "new_tokens": new,
+                       "parallelism": f"dp{world} batch-shard" if world > 1 else "single GPU",
+                       "host_attention_threads": host_threads},
+            "prefill_ms": prefill_ms,
+            "decode_latency_ms": {"mean": 1e3 * sum(step_lat) / len(step_lat), "p90": 1e3 * sorted(step_lat)[int(0.9 * (len(step_lat) - 1))],
+                                  "max": 1e3 * max(step_lat)},
+            "roofline": {"bound": "hbm", "kernel": "lia_gemm_skinny_kernel (decode linears + lm_head)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "launches": prof["skinny_launches"], "avg_launch_us": 1e3 * sk_ms / sk_n,
+                         "algorithmic_bytes_per_launch": prof["skinny_bytes"] / sk_n},
+            "host_link": {"bound": "pcie", "achieved": h2d_bytes / (elapsed * 1e9), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                          "frac": h2d_bytes / (elapsed * 1e9) / PCIE_PEAK_GBS,
+                          "copy_engine_busy_frac": (h2d_ms * 1e-3) / elapsed, "bytes_per_step": h2d_bytes / a.steps},
+            "build_s": build_s,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(shape, B, T)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

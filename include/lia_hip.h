@@ -51,6 +51,15 @@ void* lia_ctx_compute_stream(lia_ctx* ctx); /* hipStream_t created by the contex
 int lia_ctx_synchronize(lia_ctx* ctx);
 int lia_ctx_set_host_threads(lia_ctx* ctx, int n); /* OpenMP threads of the policy-2 host attention */
 
+/* Live kernel timing for the benchmark's roofline report: while enabled, every GEMM main-kernel launch made
+ * through this context is bracketed by HIP events on the stream it is launched on. */
+typedef struct {
+  long skinny_launches; double skinny_ms, skinny_bytes, skinny_flops; /* decode regime (M <= 256)  */
+  long tiled_launches;  double tiled_ms, tiled_bytes, tiled_flops;    /* prefill regime            */
+} lia_prof_result;
+int lia_prof_start(lia_ctx* ctx, int max_launches);
+int lia_prof_stop(lia_ctx* ctx, lia_prof_result* out); /* synchronises the compute stream */
+
 /* ---- layer description and the 16-tensor weight set --------------------------------------------
  * Order fixed by create_buffer (modeling_opt.py:90-126) and consumed by index in decoder.py /
  * attentions.py:  0 ln1.w 1 ln1.b 2 q.w 3 q.b 4 k.w 5 k.b 6 v.w 7 v.b 8 out.w 9 out.b
@@ -145,6 +154,11 @@ void* lia_stream_slot_ptr(lia_streamer* s, int slot);
  * pinned = 0 stages through the streamer's pinned bounce buffer (the reference's cpu_buff path,
  * modeling_opt.py:1219-1220, 1289-1292). */
 int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t bytes, int pinned);
+/* the same in three steps, for callers that put work of their own (an RCCL broadcast of each chunk to the
+ * data-parallel peers) between the host copy and the moment the slot is declared ready */
+int lia_stream_begin(lia_streamer* s, int slot);
+int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned);
+int lia_stream_mark_ready(lia_streamer* s, int slot);
 int lia_stream_wait(lia_streamer* s, int slot, void* compute_stream);    /* compute waits for the copy  */
 int lia_stream_release(lia_streamer* s, int slot, void* compute_stream); /* slot reusable after this    */
 /* bytes copied and copy-engine busy milliseconds since the last reset (hipEvent timing on the copy stream) */

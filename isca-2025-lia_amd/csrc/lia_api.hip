@@ -14,7 +14,7 @@
 // kernels' host launchers
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               int force_split, hipStream_t st);
+                               int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime);
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st);
 extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* y, int B, int T,
@@ -67,6 +67,12 @@ struct lia_ctx {
   size_t host_stage_bytes;
   int host_threads;
   long last_rows, last_slab_rows;  // workspace layout of the previous layer call
+  // live kernel timing for bench.py's roofline object (lia_prof_*)
+  bool prof_on;
+  std::vector<hipEvent_t>* prof_events;
+  struct ProfRec { int regime; double bytes, flops; };
+  std::vector<ProfRec>* prof_recs;
+  size_t prof_cap;
 };
 
 extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out) {
@@ -105,6 +111,11 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
   }
   if (c->ws) (void)hipFree(c->ws);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
+  if (c->prof_events) {
+    for (hipEvent_t e : *c->prof_events) (void)hipEventDestroy(e);
+    delete c->prof_events;
+    delete c->prof_recs;
+  }
   (void)hipStreamDestroy(c->compute);
   (void)hipStreamDestroy(c->d2h);
   delete c;
@@ -122,6 +133,36 @@ extern "C" int lia_ctx_synchronize(lia_ctx* c) {
 extern "C" int lia_ctx_set_host_threads(lia_ctx* c, int n) {
   if (!c || n < 0) return LIA_ERR_INVALID;
   c->host_threads = n;
+  return LIA_OK;
+}
+
+extern "C" int lia_prof_start(lia_ctx* c, int max_launches) {
+  if (!c || max_launches <= 0) return LIA_ERR_INVALID;
+  if (!c->prof_events) { c->prof_events = new std::vector<hipEvent_t>(); c->prof_recs = new std::vector<lia_ctx::ProfRec>(); }
+  while (c->prof_events->size() < (size_t)2 * max_launches) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    c->prof_events->push_back(e);
+  }
+  c->prof_recs->clear();
+  c->prof_cap = max_launches;
+  c->prof_on = true;
+  return LIA_OK;
+}
+
+extern "C" int lia_prof_stop(lia_ctx* c, lia_prof_result* out) {
+  if (!c || !out || !c->prof_events) return LIA_ERR_INVALID;
+  c->prof_on = false;
+  memset(out, 0, sizeof(*out));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  for (size_t i = 0; i < c->prof_recs->size(); ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize((*c->prof_events)[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, (*c->prof_events)[2 * i], (*c->prof_events)[2 * i + 1]));
+    const auto& r = (*c->prof_recs)[i];
+    if (r.regime == 1) { out->skinny_launches++; out->skinny_ms += ms; out->skinny_bytes += r.bytes; out->skinny_flops += r.flops; }
+    else { out->tiled_launches++; out->tiled_ms += ms; out->tiled_bytes += r.bytes; out->tiled_flops += r.flops; }
+  }
   return LIA_OK;
 }
 
@@ -224,12 +265,24 @@ extern "C" int lia_layernorm(const lia_bf16* x, long ldx, const lia_bf16* g, con
 
 static int gemm_checked(lia_ctx* ctx, const bf16_t* x, long ldx, const bf16_t* w, int M, int N, int K,
                         const LiaEpilogue& ep, const LiaOutMap& om, float* ws, size_t ws_bytes, int split, hipStream_t st) {
-  (void)ctx;
   if (N % 16 || K % 64) {
     lia_set_error("linear: N=%d must be a multiple of 16 and K=%d of 64", N, K);
     return LIA_ERR_INVALID;
   }
-  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, split, st);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int regime = 0;
+  const bool timed = ctx && ctx->prof_on && ctx->prof_recs->size() < ctx->prof_cap;
+  if (timed) {
+    size_t i = ctx->prof_recs->size();
+    e0 = (*ctx->prof_events)[2 * i];
+    e1 = (*ctx->prof_events)[2 * i + 1];
+  }
+  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, split, st, e0, e1, &regime);
+  if (timed && rc == 0 && regime != 0) {
+    // algorithmic traffic of the op: the weight once, the activations in and out once
+    double bytes = 2.0 * ((double)N * K + (double)M * K + (double)M * N);
+    ctx->prof_recs->push_back({regime, bytes, 2.0 * M * (double)N * K});
+  }
   if (rc) { lia_set_error("linear: unsupported shape M=%d N=%d K=%d", M, N, K); return LIA_ERR_INVALID; }
   HIP_TRY(hipGetLastError());
   return LIA_OK;
@@ -557,13 +610,23 @@ extern "C" void* lia_stream_slot_ptr(lia_streamer* s, int slot) {
 
 extern "C" void* lia_stream_copy_stream(lia_streamer* s) { return s ? (void*)s->copy : nullptr; }
 
-extern "C" int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t bytes, int pinned) {
-  if (!s || slot < 0 || slot >= s->n_slots || !host_ptr || bytes > s->slot_bytes) {
-    lia_set_error("lia_stream_prefetch: slot=%d bytes=%zu (slot holds %zu)", slot, bytes, s ? s->slot_bytes : 0);
-    return LIA_ERR_INVALID;
-  }
+// prefetch = begin + copy_chunk(whole layer) + mark_ready.  The three-step form lets a data-parallel caller
+// interleave RCCL broadcasts of the chunks (on streams ordered after the copy stream) before the slot is
+// declared ready.
+extern "C" int lia_stream_begin(lia_streamer* s, int slot) {
+  if (!s || slot < 0 || slot >= s->n_slots) { lia_set_error("lia_stream_begin: slot=%d", slot); return LIA_ERR_INVALID; }
   streamer_collect(s, slot);
   if (s->has_release[slot]) HIP_TRY(hipStreamWaitEvent(s->copy, s->released[slot], 0));
+  HIP_TRY(hipEventRecord(s->t0[slot], s->copy));
+  s->pending_bytes[slot] = 0;
+  return LIA_OK;
+}
+
+extern "C" int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned) {
+  if (!s || slot < 0 || slot >= s->n_slots || !host_ptr || offset + bytes > s->slot_bytes) {
+    lia_set_error("lia_stream_copy_chunk: slot=%d offset=%zu bytes=%zu (slot holds %zu)", slot, offset, bytes, s ? s->slot_bytes : 0);
+    return LIA_ERR_INVALID;
+  }
   const void* src = host_ptr;
   if (!pinned) {
     // pageable source: stage through a pinned bounce buffer (the reference's cpu_buff, modeling_opt.py:1219-1220)
@@ -572,13 +635,29 @@ extern "C" int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_p
     memcpy(s->bounce, host_ptr, bytes);
     src = s->bounce;
   }
-  HIP_TRY(hipEventRecord(s->t0[slot], s->copy));
-  HIP_TRY(hipMemcpyAsync(s->slots + (size_t)slot * s->slot_bytes, src, bytes, hipMemcpyHostToDevice, s->copy));
+  HIP_TRY(hipMemcpyAsync(s->slots + (size_t)slot * s->slot_bytes + offset, src, bytes, hipMemcpyHostToDevice, s->copy));
+  s->pending_bytes[slot] += bytes;
+  return LIA_OK;
+}
+
+extern "C" int lia_stream_mark_ready(lia_streamer* s, int slot) {
+  if (!s || slot < 0 || slot >= s->n_slots) return LIA_ERR_INVALID;
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));
   HIP_TRY(hipEventRecord(s->copied[slot], s->copy));
   s->timing_pending[slot] = 1;
-  s->pending_bytes[slot] = bytes;
   return LIA_OK;
+}
+
+extern "C" int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t bytes, int pinned) {
+  if (!s || slot < 0 || slot >= s->n_slots || !host_ptr || bytes > s->slot_bytes) {
+    lia_set_error("lia_stream_prefetch: slot=%d bytes=%zu (slot holds %zu)", slot, bytes, s ? s->slot_bytes : 0);
+    return LIA_ERR_INVALID;
+  }
+  int rc = lia_stream_begin(s, slot);
+  if (rc) return rc;
+  rc = lia_stream_copy_chunk(s, slot, 0, host_ptr, bytes, pinned);
+  if (rc) return rc;
+  return lia_stream_mark_ready(s, slot);
 }
 
 extern "C" int lia_stream_wait(lia_streamer* s, int slot, void* compute_stream) {

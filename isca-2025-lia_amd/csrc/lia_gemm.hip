@@ -286,7 +286,10 @@ static void launch_skinny(const bf16_t* x, long ldx, const bf16_t* W, long ldw, 
 // Returns 0 on success, -1 on unsupported shape.  workspace is only touched when split-K is chosen.
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               int force_split, hipStream_t st) {
+                               int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime) {
+  // ev0/ev1 (nullable): recorded on `st` immediately around the MAIN kernel launch only (bench.py's live
+  // roofline timing; the split-K combine kernel is outside the bracket).  *regime: 1 skinny, 2 tiled.
+  if (regime) *regime = 0;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N % 16) != 0 || (om->seg_n % 4) != 0) return -1;
   if (M <= 256 && (K % SK_BK) == 0) {
@@ -303,11 +306,14 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     if (split > 1 && (size_t)split * M * N * sizeof(float) > workspace_bytes) split = 1;
     int cps = (nchunks + split - 1) / split;
     split = (nchunks + cps - 1) / cps;
+    if (regime) *regime = 1;
+    if (ev0) (void)hipEventRecord(ev0, st);
     if (M <= 16) launch_skinny<1>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     else if (M <= 32) launch_skinny<2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     else if (M <= 64) launch_skinny<4>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     else if (M <= 128) launch_skinny<8>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     else launch_skinny<16>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    if (ev1) (void)hipEventRecord(ev1, st);
     if (split > 1) {
       long nq = (long)M * (N / 4);
       hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace,
@@ -317,7 +323,10 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   }
   if ((K % TL_BK) != 0) return -1;
   int tiles_m = (M + TL_BM - 1) / TL_BM, tiles_n = (N + TL_BN - 1) / TL_BN;
+  if (regime) *regime = 2;
+  if (ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(lia_gemm_tiled_kernel, dim3(tiles_m * tiles_n), dim3(256), 4 * TL_TILE_BYTES, st, x, ldx, W, ldw,
                      M, N, K, tiles_m, tiles_n, *ep, *om);
+  if (ev1) (void)hipEventRecord(ev1, st);
   return 0;
 }

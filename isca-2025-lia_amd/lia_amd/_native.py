@@ -24,6 +24,11 @@ class LayerDesc(ctypes.Structure):
     _fields_ = [("hidden", c_int), ("heads", c_int), ("ffn", c_int), ("ln_eps", c_float)]
 
 
+class ProfResult(ctypes.Structure):
+    _fields_ = [("skinny_launches", c_long), ("skinny_ms", c_double), ("skinny_bytes", c_double), ("skinny_flops", c_double),
+                ("tiled_launches", c_long), ("tiled_ms", c_double), ("tiled_bytes", c_double), ("tiled_flops", c_double)]
+
+
 class KV(ctypes.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("smax", c_int), ("batch", c_int), ("on_device", c_int)]
 
@@ -38,6 +43,8 @@ SIGNATURES = {
     "lia_ctx_compute_stream": (c_void_p, [c_void_p]),
     "lia_ctx_synchronize": (c_int, [c_void_p]),
     "lia_ctx_set_host_threads": (c_int, [c_void_p, c_int]),
+    "lia_prof_start": (c_int, [c_void_p, c_int]),
+    "lia_prof_stop": (c_int, [c_void_p, ctypes.POINTER(ProfResult)]),
     "lia_layer_pack_offsets": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_size_t * 16), ctypes.POINTER(c_size_t)]),
     "lia_layer_workspace_bytes": (c_size_t, [ctypes.POINTER(LayerDesc), c_int]),
     "lia_layer_forward": (c_int, [c_void_p, ctypes.POINTER(LayerDesc), c_int, ctypes.POINTER(c_void_p * 16), c_void_p,
@@ -59,6 +66,9 @@ SIGNATURES = {
     "lia_stream_destroy": (None, [c_void_p]),
     "lia_stream_slot_ptr": (c_void_p, [c_void_p, c_int]),
     "lia_stream_prefetch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int]),
+    "lia_stream_begin": (c_int, [c_void_p, c_int]),
+    "lia_stream_copy_chunk": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, c_int]),
+    "lia_stream_mark_ready": (c_int, [c_void_p, c_int]),
     "lia_stream_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lia_stream_release": (c_int, [c_void_p, c_int, c_void_p]),
     "lia_stream_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double), c_int]),

@@ -1,0 +1,68 @@
+"""Host facts the cooperative (CPU+GPU) policies depend on: how many cores this process may really use.
+
+The reference pins its CPU work with `OMP_NUM_THREADS=40 numactl -m 0 -C 0-39` (README.md:78;
+llm/scripts/*.sh).  Here the usable core count is the minimum of the affinity mask and the cgroup CPU
+quota: a container may expose 256 CPUs yet be throttled to 16 CPUs' worth of time, and an OpenMP team larger
+than the quota stalls every layer's host-attention round trip.
+"""
+import math
+import os
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of time the cgroup grants (cpu.max: "<quota> <period>" or "max"), or None if unlimited."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                return max(1, int(math.floor(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return max(1, q // p)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cpus():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    q = cgroup_cpu_quota()
+    return max(1, min(n, q) if q else n)
+
+
+def default_host_threads(world=1):
+    """Threads for the policy-2 host attention of one rank: the usable CPUs split across ranks; when the box is
+    not quota-limited only the physical cores (half the SMT threads) are counted."""
+    n = usable_cpus()
+    if cgroup_cpu_quota() is None:
+        n = max(1, n // 2)
+    return max(1, n // max(1, world))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def isa_flags():
+    want = ("avx512f", "avx512_bf16", "amx_bf16", "amx_tile")
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                have = set(line.split(":", 1)[1].split())
+                return {w: (w in have) for w in want}
+    except OSError:
+        pass
+    return {w: False for w in want}

@@ -201,14 +201,17 @@ class LiaOPTModel:
         return self
 
     @classmethod
-    def random_init(cls, shape, seed=0, init="normal", n_gpu_layers=0, pin_weight=True, enable_cxl=False):
+    def random_init(cls, shape, seed=0, init="normal", n_gpu_layers=0, pin_weight=True, enable_cxl=False,
+                    host_owner=True):
         """Random-init weights of the exact architecture, generated ON THE GPU one layer at a time and
         moved straight to their tier (an OPT-30B would take minutes to draw on the CPU).
         init="normal": HF _init_weights (lia/modeling_opt.py:895-904): Linear/Embedding ~ N(0, 0.02), zero
-        bias, LN = (1, 0).  init="uniform01": the reference's dummy recipe (opt-weight-gen.py:61-62), seeded."""
+        bias, LN = (1, 0).  init="uniform01": the reference's dummy recipe (opt-weight-gen.py:61-62), seeded.
+        Every tensor group has its own seed, so data-parallel ranks draw identical resident layers;
+        host_owner=False (non-root DP ranks) skips the streamed layers, which arrive by broadcast."""
         self = cls(shape)
         g = torch.Generator(device="cuda")
-        g.manual_seed(seed)
+        g.manual_seed(seed * 100003)
         H, F = shape.hidden, shape.ffn
 
         def draw(*size):
@@ -222,6 +225,10 @@ class LiaOPTModel:
         self.final_ln_b = torch.zeros(H, dtype=torch.bfloat16, device="cuda")
         shapes = {"q_w": (H, H), "k_w": (H, H), "v_w": (H, H), "out_w": (H, H), "fc1_w": (F, H), "fc2_w": (H, F)}
         for li, st in enumerate(self.layers):
+            if li >= n_gpu_layers and not host_owner:
+                st.tier = "remote"          # lives on the DP root's host; reaches this rank by broadcast
+                continue
+            g.manual_seed(seed * 100003 + li + 1)
             flat = torch.zeros(self.layer_bytes // 2, dtype=torch.bfloat16, device="cuda")
             for i, n in enumerate(LAYER_TENSORS):
                 o = self.offsets[i] // 2
@@ -256,6 +263,8 @@ class LiaOPTModel:
         if self.placed_for == key:
             return
         for i, st in enumerate(self.layers):
+            if st.tier == "remote":
+                continue
             if i < n_gpu_layers:
                 st.to_device()
             elif st.tier == "device":

@@ -59,6 +59,14 @@ class Context:
     def set_host_threads(self, n):
         N.check(self.lib.lia_ctx_set_host_threads(self.handle, n))
 
+    def prof_start(self, max_launches=16384):
+        N.check(self.lib.lia_prof_start(self.handle, max_launches), "lia_prof_start")
+
+    def prof_stop(self):
+        r = N.ProfResult()
+        N.check(self.lib.lia_prof_stop(self.handle, ctypes.byref(r)), "lia_prof_stop")
+        return {k: getattr(r, k) for k, _ in r._fields_}
+
     def _st(self, stream):
         return ctypes.c_void_p(self.stream if stream is None else stream)
 

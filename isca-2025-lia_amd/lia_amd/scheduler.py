@@ -33,8 +33,9 @@ from . import ops
 class WeightPipeline:
     """Slot bookkeeping over lia_stream_*: prefetch(layer) -> acquire(layer) -> release(layer)."""
 
-    def __init__(self, ctx, model, n_slots):
+    def __init__(self, ctx, model, n_slots, dp_group=None):
         self.ctx, self.model, self.lib = ctx, model, N.lib()
+        self.dp = dp_group
         h = ctypes.c_void_p()
         N.check(self.lib.lia_stream_create(ctx.handle, n_slots, model.layer_bytes, ctypes.byref(h)), "lia_stream_create")
         self.handle, self.n_slots = h, n_slots
@@ -43,6 +44,10 @@ class WeightPipeline:
         self.held = {}              # layer_idx -> slot (acquired, not yet released)
         self.slot_ptrs = [self.lib.lia_stream_slot_ptr(h, s) for s in range(n_slots)]
         self.ptr_arrays = [ops.weight_ptr_array(p, model.offsets) for p in self.slot_ptrs]
+        if dp_group is not None:
+            from .dp import RawDeviceBuffer
+            self.slot_tensors = [RawDeviceBuffer(p, model.layer_bytes).tensor() for p in self.slot_ptrs]
+            self.copy_stream = torch.cuda.ExternalStream(self.lib.lia_stream_copy_stream(h))
 
     def can_prefetch(self):
         return len(self.inflight) + len(self.held) < self.n_slots
@@ -55,9 +60,33 @@ class WeightPipeline:
         st = self.model.layers[layer_idx]
         slot = self.next_slot
         self.next_slot = (slot + 1) % self.n_slots
-        N.check(self.lib.lia_stream_prefetch(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.nbytes, int(st.is_dma_able())),
-                "lia_stream_prefetch")
+        if self.dp is None:
+            N.check(self.lib.lia_stream_prefetch(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.nbytes, int(st.is_dma_able())),
+                    "lia_stream_prefetch")
+        else:
+            self._prefetch_broadcast(st, slot)
         self.inflight.append((layer_idx, slot))
+
+    def _prefetch_broadcast(self, st, slot):
+        """Root: host -> slot in chunks, each chunk RCCL-broadcast over xGMI as soon as it is enqueued, so chunk
+        k travels to the peers while chunk k+1 is still arriving over PCIe.  Peers: receive into the same slot.
+        Everything is ordered on the copy stream; the slot is declared ready after the last broadcast."""
+        from .dp import broadcast_chunked
+        dp = self.dp
+        N.check(self.lib.lia_stream_begin(self.handle, slot), "lia_stream_begin")
+        before = None
+        if dp.is_root:
+            base, pinned = st.host_ptr(), int(st.is_dma_able())
+
+            def before(off, n):
+                N.check(self.lib.lia_stream_copy_chunk(self.handle, slot, off, ctypes.c_void_p(base + off), n, pinned),
+                        "lia_stream_copy_chunk")
+        with torch.cuda.stream(self.copy_stream):
+            works = broadcast_chunked(dp.dist, self.slot_tensors[slot][:self.model.layer_bytes], dp.root, dp.chunk_bytes,
+                                      before_chunk=before)
+            for w in works:
+                w.wait()              # the copy stream waits for RCCL's stream; the host does not block
+        N.check(self.lib.lia_stream_mark_ready(self.handle, slot), "lia_stream_mark_ready")
 
     def acquire(self, layer_idx):
         """Make the compute stream wait for the layer's copy; returns the 16 device pointers."""
@@ -111,10 +140,10 @@ class KVState:
 class OffloadScheduler:
     """forward(input_ids, kv_state, **lia flags) -> (logits [B,vocab], next_ids [B]) on the device."""
 
-    def __init__(self, model, device=0, n_slots=None):
+    def __init__(self, model, device=0, n_slots=None, dp_group=None):
         import os
-        self.model, self.device = model, device
-        self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "2"))
+        self.model, self.device, self.dp = model, device, dp_group
+        self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "3"))
         self.ctx = None
         self.ws_rows = 0
         self.pipe = None
@@ -136,7 +165,7 @@ class OffloadScheduler:
                 self.ctx.close()
             self.ctx = ops.Context(self.device, need)
         if self.pipe is None and n_gpu < sh.layers:
-            self.pipe = WeightPipeline(self.ctx, self.model, self.n_slots)
+            self.pipe = WeightPipeline(self.ctx, self.model, self.n_slots, self.dp)
         key = (B, T)
         if key not in self.hidden:
             if len(self.hidden) > 4:
