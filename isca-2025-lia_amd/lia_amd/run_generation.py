@@ -1,0 +1,119 @@
+"""Benchmark harness: counterpart of llm/single_instance/run_generation.py (reference :60-117 flags,
+:179-182 generate kwargs, :285 identical-row batch, :308-335 timing loop, :337-354 summary).
+
+Differences forced by the environment: there is no network, so no HF checkpoint / tokenizer / prompt.json
+(tools/env_setup.sh:221 downloads it) -- the prompt is `--input-tokens` synthetic token ids drawn with
+seed 0 (row 0 = BOS), and weights are a seeded random init of the named OPT shape unless `-m` points at a
+local HF checkpoint directory.  Everything else -- the protocol and the four summary lines -- is the
+reference's.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from .generation import generate
+from .model import LiaOPTModel, resolve_shape
+
+
+def build_parser():
+    p = argparse.ArgumentParser("Generation script (bf16 path, MI355X)", add_help=True)
+    p.add_argument("-m", "--model-id", type=str, default="facebook/opt-30b", help="OPT shape name or local HF checkpoint dir")
+    p.add_argument("--dtype", type=str, choices=["bfloat16"], default="bfloat16")
+    p.add_argument("--input-tokens", default="32", type=str)
+    p.add_argument("--max-new-tokens", default=32, type=int)
+    p.add_argument("--greedy", action="store_true")
+    p.add_argument("--ipex", action="store_true", help="accepted for command-line compatibility; no effect")
+    p.add_argument("--benchmark", action="store_true")
+    p.add_argument("--num-iter", default=100, type=int)
+    p.add_argument("--num-warmup", default=10, type=int)
+    p.add_argument("--batch-size", default=1, type=int)
+    p.add_argument("--token-latency", action="store_true")
+    # the seven LIA flags, same names / types / defaults as run.py:195-215 and run_generation.py:111-117
+    p.add_argument("--prefill-policy", default=1, type=int)
+    p.add_argument("--decoding-policy", default=1, type=int)
+    p.add_argument("--no-overlap", action="store_true")
+    p.add_argument("--pin-weight", action="store_true")
+    p.add_argument("--gpu-percentage", default=0, type=int)
+    p.add_argument("--num-minibatch", default=1, type=int)
+    p.add_argument("--enable-cxl", action="store_true")
+    # build-specific
+    p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--init", default="normal", choices=["normal", "uniform01"],
+                   help="uniform01 = the reference's dummy-weight recipe (utils/opt-weight-gen.py:61-62)")
+    return p
+
+
+def synthetic_prompt(vocab, n_tokens, batch, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    row = torch.randint(4, vocab, (n_tokens,), generator=g, dtype=torch.int64)
+    row[0] = 2
+    return row[None, :].repeat(batch, 1)          # prompt = [prompt] * batch_size  (run_generation.py:285)
+
+
+def load_model(args):
+    if os.path.isdir(args.model_id):
+        from .checkpoint import load_hf_opt
+        return load_hf_opt(args.model_id)
+    shape = resolve_shape(args.model_id)
+    n_gpu = int(shape.layers * args.gpu_percentage / 100)
+    return LiaOPTModel.random_init(shape, seed=args.seed, init=args.init, n_gpu_layers=n_gpu,
+                                   pin_weight=args.pin_weight or args.enable_cxl, enable_cxl=args.enable_cxl)
+
+
+def summarize(total_time, num_iter, num_warmup, total_list, batch_size, out=print):
+    """The reference's summary block (run_generation.py:337-354), verbatim formats; returns the numbers."""
+    out("\n", "-" * 10, "Summary:", "-" * 10)
+    latency = total_time / (num_iter - num_warmup)
+    out("Inference latency: %.3f sec." % latency)
+    res = {"inference_latency_s": latency}
+    if total_list:
+        from itertools import chain
+        first_latency = float(np.mean([x[0] for x in total_list]))
+        average_2n = sorted(chain(*[x[1:] for x in total_list]))
+        average_2n_latency = float(np.mean(average_2n))
+        p90_latency = average_2n[int(len(average_2n) * 0.9)]
+        p99_latency = average_2n[int(len(average_2n) * 0.99)]
+        out("First token average latency: %.3f sec." % first_latency)
+        out("Average 2... latency: %.3f sec." % average_2n_latency)
+        out("P90 2... latency: %.3f sec." % p90_latency)
+        out("P99 2... latency: %.3f sec." % p99_latency)
+        res.update(prefill_ms=1e3 * first_latency, decode_tokens_per_s=batch_size / average_2n_latency,
+                   p90_s=p90_latency, p99_s=p99_latency)
+    return res
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print(args)
+    if not args.benchmark:
+        print("note: only --benchmark mode exists here (no tokenizer offline); running the benchmark protocol")
+    model = load_model(args)
+    generate_kwargs = dict(do_sample=False, num_beams=1, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
+                           token_latency=args.token_latency, prefill_policy=args.prefill_policy,
+                           decoding_policy=args.decoding_policy, no_overlap=args.no_overlap, pin_weight=args.pin_weight,
+                           gpu_percentage=args.gpu_percentage, num_minibatch=args.num_minibatch, enable_cxl=args.enable_cxl)
+    input_ids = synthetic_prompt(model.shape.vocab, int(args.input_tokens), args.batch_size)
+    total_time, total_list = 0.0, []
+    for i in range(args.num_iter):
+        tic = time.time()
+        output = generate(model, input_ids, **generate_kwargs)
+        gen_ids = output[0] if args.token_latency else output
+        toc = time.time()
+        total_new_tokens = [int(o.shape[0] - i_.shape[0]) for i_, o in zip(input_ids, gen_ids)]
+        print(gen_ids[0, input_ids.shape[1]:].tolist(), total_new_tokens[:4], flush=True)
+        print("Iteration: %d, Time: %.6f sec" % (i, toc - tic), flush=True)
+        if i >= args.num_warmup:
+            total_time += toc - tic
+            if args.token_latency:
+                total_list.append(output[1])
+    res = summarize(total_time, args.num_iter, args.num_warmup, total_list, args.batch_size)
+    if "decode_tokens_per_s" in res:
+        print("Decode throughput: %.2f tokens/s, prefill %.1f ms" % (res["decode_tokens_per_s"], res["prefill_ms"]))
+    return res
+
+
+if __name__ == "__main__":
+    main()

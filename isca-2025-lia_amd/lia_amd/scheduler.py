@@ -227,10 +227,15 @@ class OffloadScheduler:
                 pipe.prefetch(idx)
             wptrs = pipe.acquire(idx)
             if overlap:
-                # weight prefetch of the next streamed layer overlaps this layer's compute (:1305-1312, :1508-1515);
-                # after the last layer it wraps to the first streamed layer of the NEXT forward
-                nxt = idx + 1 if idx + 1 < L else first_streamed
-                pipe.prefetch(nxt)
+                # weight prefetch of the next streamed layer(s) overlaps this layer's compute (:1305-1312, :1508-1515):
+                # every free slot is filled; after the last layer the order wraps to the first streamed layer of the
+                # NEXT forward, so the copy engine keeps running across token steps
+                nxt = idx
+                for _ in range(pipe.n_slots - 1):
+                    nxt = nxt + 1 if nxt + 1 < L else first_streamed
+                    if nxt == idx or not pipe.can_prefetch():
+                        break
+                    pipe.prefetch(nxt)
             if policy == 0:
                 for i in range(num_minibatch):                     # FlexGen-style minibatches (:1283-1365)
                     sl = slice(i * mini, (i + 1) * mini)

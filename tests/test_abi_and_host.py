@@ -1,0 +1,198 @@
+"""CPU-only checks (no GPU, no compute kernels): the C-ABI library loads and exports every symbol
+include/lia_hip.h declares; the host-side pieces of the product (policy-2 host attention, TPP layout
+converter, NUMA/CXL allocator, packed-layer layout, host facts) behave like the reference's."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lia_hip.h")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from lia_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "isca-2025-lia_amd", "csrc"), "-j4"], check=True)
+    return _native
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_header_symbols_are_exported_and_bound(native):
+    decl = declared_functions()
+    assert len(decl) > 40
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    missing = [n for n in decl if n not in exported]
+    assert not missing, f"declared in lia_hip.h but not exported: {missing}"
+    unbound = [n for n in decl if n not in native.SIGNATURES]
+    assert not unbound, f"declared in lia_hip.h but not bound in _native.SIGNATURES: {unbound}"
+    stale = [n for n in native.SIGNATURES if n not in decl]
+    assert not stale, f"bound but not declared: {stale}"
+
+
+def test_library_loads_without_gpu_and_reports_errors(native):
+    L = native.lib()
+    assert b"gfx950" in L.lia_version()
+    h = ctypes.c_void_p()
+    rc = L.lia_ctx_create(0, 0, ctypes.byref(h))
+    import torch
+    if not torch.cuda.is_available():
+        assert rc != 0 and len(L.lia_last_error()) > 0   # fails loudly, no CPU fallback
+        with pytest.raises((RuntimeError, ValueError, MemoryError)):
+            native.check(rc, "lia_ctx_create")
+    else:
+        L.lia_ctx_destroy(h)
+
+
+def test_pack_offsets_layout(native):
+    from lia_amd import ops
+    d = ops.make_desc(7168, 56, 28672)
+    offs, total = ops.pack_offsets(d)
+    H, F = 7168, 28672
+    assert all(o % 256 == 0 for i, o in enumerate(offs) if i not in (4, 6, 5, 7))
+    assert offs[4] == offs[2] + 2 * H * H and offs[6] == offs[4] + 2 * H * H      # q|k|v weights adjacent
+    assert offs[5] == offs[3] + 2 * H and offs[7] == offs[5] + 2 * H              # q|k|v biases adjacent
+    params = 2 * (4 * H * H + 2 * H * F + 9 * H + F)
+    assert params <= total <= params + 16 * 256
+    assert params == 1233311744                                                    # bytes/layer
+    with pytest.raises(ValueError):
+        ops.pack_offsets(ops.make_desc(250, 5, 1024))
+    assert ops.workspace_bytes(d, 64) > 0
+
+
+@pytest.mark.parametrize("B,T,pos0,heads,d", [(2, 1, 8, 4, 32), (3, 1, 33, 4, 64), (2, 1, 40, 4, 128), (2, 5, 0, 8, 64),
+                                              (1, 1, 0, 2, 128)])
+def test_host_attention_matches_oracle(native, oracle, B, T, pos0, heads, d):
+    """lia_host_attention (product, AVX-512) == the oracle's restatement of Krnl.cpp:513-842, incl. the in-place
+    append of the new K/V rows and a minibatch offset into a wider cache."""
+    L = native.lib()
+    H = heads * d
+    rs = np.random.RandomState(7)
+    q, k, v = (synth.f32_to_bf16_bits(rs.standard_normal((B, T, H)).astype(np.float32)) for _ in range(3))
+    Bc, b0, smax = B + 2, 1, pos0 + T + 1
+    kc = synth.f32_to_bf16_bits(rs.standard_normal((smax, Bc, heads, d)).astype(np.float32))
+    vc = synth.f32_to_bf16_bits(rs.standard_normal((smax, Bc, heads, d)).astype(np.float32))
+    kc_o, vc_o = np.ascontiguousarray(kc[:, b0:b0 + B]), np.ascontiguousarray(vc[:, b0:b0 + B])
+    oracle.lib().lia_oracle_kv_store(k.ctypes.data, kc_o.ctypes.data, B, T, H, pos0)
+    oracle.lib().lia_oracle_kv_store(v.ctypes.data, vc_o.ctypes.data, B, T, H, pos0)
+    ref = oracle.attention(q, kc_o, vc_o, pos0 + T, heads, policy_gpu=False)
+    out = np.zeros_like(q)
+    rc = L.lia_host_attention(q.ctypes.data, k.ctypes.data, v.ctypes.data, kc.ctypes.data, vc.ctypes.data, out.ctypes.data,
+                              B, T, pos0, heads, d, Bc, b0, 3)
+    assert rc == 0
+    err = np.abs(synth.bf16_bits_to_f32(out) - synth.bf16_bits_to_f32(ref))
+    assert err.max() <= 0.02 and (out == ref).mean() > 0.97
+    assert (kc[pos0:pos0 + T, b0:b0 + B].reshape(T, B, H) == k.transpose(1, 0, 2)).all()      # rows appended in place
+    assert (kc[:, 0] == kc[:, 0]).all() and (vc[pos0:pos0 + T, b0:b0 + B].reshape(T, B, H) == v.transpose(1, 0, 2)).all()
+    # argument errors come back as codes, not crashes
+    assert L.lia_host_attention(None, k.ctypes.data, v.ctypes.data, kc.ctypes.data, vc.ctypes.data, out.ctypes.data, B, T, pos0,
+                                heads, d, Bc, b0, 1) == native.LIA_ERR_MISSING
+    assert L.lia_host_attention(q.ctypes.data, k.ctypes.data, v.ctypes.data, kc.ctypes.data, vc.ctypes.data, out.ctypes.data, B, T,
+                                pos0, heads, d, Bc, Bc, 1) == native.LIA_ERR_INVALID
+
+
+def test_tpp_layout_converter(native, oracle):
+    L = native.lib()
+    N, K = 64, 192
+    w = np.arange(N * K, dtype=np.uint16).reshape(N, K)
+    blocked = np.zeros(N * K, np.uint16)
+    assert L.lia_tpp_block(w.ctypes.data, blocked.ctypes.data, N, K) == 0
+    assert (blocked.reshape(N // 16, K // 64, 32, 16, 2) == oracle.tpp_block(w)).all()
+    back = np.zeros_like(w)
+    assert L.lia_tpp_unblock(blocked.ctypes.data, back.ctypes.data, N, K) == 0
+    assert (back == w).all()
+    assert L.lia_tpp_unblock(blocked.ctypes.data, back.ctypes.data, 60, K) == native.LIA_ERR_INVALID   # tpp_fallback shapes
+
+
+def test_numa_shim_matches_reference_build(native):
+    """Same four exports and behaviour as the reference's lia/cxl/numa_alloc.c (compiled from the reference's own
+    source into oracle/_ref when the reference tree is present)."""
+    L = native.lib()
+    if not L.lia_numa_available():
+        pytest.skip("no NUMA support on this host")
+    size = 1 << 20
+    p = L.numa_alloc_node(size, 0)
+    assert p
+    buf = (ctypes.c_uint8 * size).from_address(p)
+    buf[0], buf[size - 1] = 7, 9
+    assert buf[0] == 7 and buf[size - 1] == 9
+    L.numa_free_node(p, size)
+    assert not L.numa_alloc_node(size, 4096)          # non-existent node -> NULL (+ stderr), like the reference
+    nodes = (ctypes.c_int * 1)(0)
+    assert L.lia_numa_set_interleave_nodes(nodes, 1) == 0
+    p = L.numa_alloc_interleave(size)
+    assert p
+    L.numa_free_node(p, size)
+    bad = (ctypes.c_int * 1)(4096)
+    assert L.lia_numa_set_interleave_nodes(bad, 1) == native.LIA_ERR_INVALID
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libnuma_alloc_ref.so")
+    if os.path.exists(ref_path):
+        R = ctypes.CDLL(ref_path)
+        R.numa_alloc_node.restype = ctypes.c_void_p
+        R.numa_alloc_node.argtypes = [ctypes.c_size_t, ctypes.c_int]
+        R.numa_free_node.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        rp = R.numa_alloc_node(size, 0)
+        assert rp                                        # reference allocates on node 0 as ours does
+        R.numa_free_node(rp, size)
+        R.numa_alloc_interleave.restype = ctypes.c_void_p
+        R.numa_alloc_interleave.argtypes = [ctypes.c_size_t]
+    
+
+def test_hostinfo():
+    from lia_amd import hostinfo
+    n = hostinfo.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert 1 <= hostinfo.default_host_threads(1) <= n
+    assert hostinfo.default_host_threads(8) >= 1
+    assert isinstance(hostinfo.cpu_model(), str) and "avx512f" in hostinfo.isa_flags()
+
+
+def test_shapes_and_flag_defaults():
+    from lia_amd.model import SHAPES, resolve_shape
+    s = resolve_shape("facebook/opt-30b")
+    assert (s.hidden, s.heads, s.ffn, s.layers, s.head_dim) == (7168, 56, 28672, 48, 128)
+    assert s.layer_param_bytes() == 1233311744
+    assert resolve_shape("opt-175b").layer_param_bytes() == 2 * (4 * 12288 ** 2 + 2 * 12288 * 49152 + 9 * 12288 + 49152)
+    assert int(48 * 10 / 100) == 4                       # n_gpu_layers at gpu%=10 (lia/modeling_opt.py:1182)
+    with pytest.raises(ValueError):
+        resolve_shape("opt-350m")                         # post-LN variant: out of scope
+    assert set(SHAPES) >= {"opt-125m", "opt-30b", "opt-66b", "opt-175b"}
+
+
+def test_checkpoint_state_dict_conversion(native, oracle):
+    """HF-named state dict (one linear stored TPP-blocked, as an IPEX-prepacked checkpoint would) -> packed layout."""
+    import torch
+    from lia_amd.checkpoint import state_dict_to_numpy
+    vocab, max_pos, H, F, L = 64, 16, 128, 256, 2
+    m = synth.make_model(5, vocab, max_pos, H, F, L)
+
+    def t(bits):
+        return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16)
+
+    hf = {"ln1": "self_attn_layer_norm", "q": "self_attn.q_proj", "k": "self_attn.k_proj", "v": "self_attn.v_proj",
+          "out": "self_attn.out_proj", "ln2": "final_layer_norm", "fc1": "fc1", "fc2": "fc2"}
+    sd = {"model.decoder.embed_tokens.weight": t(m["embed_tokens"]), "model.decoder.embed_positions.weight": t(m["embed_positions"]),
+          "model.decoder.final_layer_norm.weight": t(m["final_ln_w"]), "model.decoder.final_layer_norm.bias": t(m["final_ln_b"])}
+    for i, lw in enumerate(m["layers"]):
+        for n, v in lw.items():
+            base, kind = n.rsplit("_", 1)
+            sd[f"model.decoder.layers.{i}.{hf[base]}.{'weight' if kind == 'w' else 'bias'}"] = t(v)
+    sd["model.decoder.layers.1.fc1.weight"] = t(oracle.tpp_block(m["layers"][1]["fc1_w"]))     # blocked on disk
+    got = state_dict_to_numpy(sd, dict(hidden_size=H, ffn_dim=F, num_hidden_layers=L))
+    assert (got["embed_tokens"] == m["embed_tokens"]).all() and (got["final_ln_b"] == m["final_ln_b"]).all()
+    for a, b in zip(got["layers"], m["layers"]):
+        for n in synth.LAYER_TENSORS:
+            assert a[n].shape == b[n].shape and (a[n] == b[n]).all(), n
