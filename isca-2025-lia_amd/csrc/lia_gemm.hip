@@ -7,11 +7,10 @@
 //
 // Two regimes, one fragment convention (A operand = W rows, B operand = x rows, both K-contiguous, so
 // every fragment is one 16-byte load; D[n_local][m_local], lane holds 4 consecutive n of one m):
-//   * skinny  (decode, M <= 256): weight-bandwidth bound.  W goes HBM -> VGPR fragments directly (each
-//     weight byte is used by exactly one wave), a DEPTH-deep register ring keeps ~16 KB per wave in
-//     flight; the small x chunk is shared by the workgroup through swizzled LDS.  Split-K over
-//     workgroups fills the 256 CUs when N/64 is small; fp32 partial slabs are combined by a second
-//     tiny kernel that also applies the epilogue.
+//   * skinny  (decode, M <= 256): weight-bandwidth bound.  W and x chunks arrive by LDS-DMA into a
+//     3-stage swizzled LDS ring (counted vmcnt, raw s_barrier), 8 waves x 16 weight rows per workgroup.
+//     Split-K over workgroups fills the CUs when N/128 is small; fp32 partial slabs are combined by a
+//     second tiny kernel that also applies the epilogue.
 //   * tiled   (prefill, M in the thousands): MFMA bound.  128x128x64 tiles, LDS-DMA staging
 //     (global_load_lds, 16 B/lane) with the XOR swizzle applied on the SOURCE address
 //     (cdna_hip_programming.md rule 21), double-buffered, XCD-aware tile order.
@@ -44,112 +43,6 @@ __device__ __forceinline__ void store_quad(const f32x4& v, int m, int n, const L
   *(uint2*)lia_out_ptr(om, m, n) = o;
 }
 
-// ---------------------------------------------------------------------------------------------
-// skinny regime
-// ---------------------------------------------------------------------------------------------
-constexpr int SK_BN = 64;     // columns per workgroup (16 per wave)
-constexpr int SK_BK = 128;    // K per chunk (4 MFMA k-steps of 32)
-constexpr int SK_DEPTH = 4;   // W register ring depth (chunks in flight per wave)
-
-template <int MT>
-__global__ __launch_bounds__(256) void lia_gemm_skinny_kernel(const bf16_t* __restrict__ x, long ldx,
-                                                               const bf16_t* __restrict__ W, long ldw, int M, int N,
-                                                               int K, int chunks_per_split, float* __restrict__ partial,
-                                                               LiaEpilogue ep, LiaOutMap om) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int XBUF = 16 * MT * 256;  // bytes per x chunk buffer
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int n_wave = blockIdx.x * SK_BN + wave * 16;
-  const bool wave_active = n_wave < N;
-  const int nchunks = K / SK_BK;
-  const int c_begin = blockIdx.y * chunks_per_split;
-  const int c_end = min(nchunks, c_begin + chunks_per_split);
-
-  // W fragment source: row n_wave + l15, 8 bf16 at k = 32*i + 8*lq inside a chunk
-  const int wrow = min(n_wave + l15, N - 1);
-  const bf16_t* wp = W + (long)wrow * ldw + 8 * lq;
-
-  // x staging: thread -> (row = tid>>4 (+16p), 16-byte chunk = tid&15).  Loads past the last chunk are
-  // clamped to it (harmless re-reads) so the loop body carries no conditional loads.
-  const int xr = tid >> 4, xc = tid & 15;
-  const bf16_t* xp[MT];
-#pragma unroll
-  for (int p = 0; p < MT; ++p) xp[p] = x + (long)min(xr + 16 * p, M - 1) * ldx + 8 * xc;
-  int xoff[MT];
-#pragma unroll
-  for (int p = 0; p < MT; ++p) xoff[p] = (xr + 16 * p) * 256 + ((xc ^ ((xr + 16 * p) & 15)) << 4);
-  uint4 xreg[MT];
-  u32x4 wreg[SK_DEPTH][4];
-
-#define SK_LOAD_X(c)                                                                              \
-  _Pragma("unroll") for (int p = 0; p < MT; ++p) xreg[p] = *(const uint4*)(xp[p] + (long)(c) * SK_BK);
-#define SK_STORE_X(buf)                                                                           \
-  _Pragma("unroll") for (int p = 0; p < MT; ++p) *(uint4*)(smem + (buf) * XBUF + xoff[p]) = xreg[p];
-#define SK_LOAD_W(s, c)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-      wreg[s][i] = __builtin_nontemporal_load((const u32x4*)(wp + (long)(c) * SK_BK + 32 * i));
-
-  f32x4 acc[MT];
-#pragma unroll
-  for (int p = 0; p < MT; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (c_begin < c_end) {
-    const int c_last = c_end - 1;
-    SK_LOAD_X(c_begin);
-#pragma unroll
-    for (int s = 0; s < SK_DEPTH; ++s) { SK_LOAD_W(s, min(c_begin + s, c_last)); }
-    SK_STORE_X(0);
-    __syncthreads();
-    for (int base = c_begin; base < c_end; base += SK_DEPTH) {
-#pragma unroll
-      for (int s = 0; s < SK_DEPTH; ++s) {
-        const int c = base + s;
-        if (c < c_end) {  // workgroup-uniform
-          const int buf = (c - c_begin) & 1;
-          SK_LOAD_X(min(c + 1, c_last));
-          const char* xb = smem + buf * XBUF;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            bf16x8 a = __builtin_bit_cast(bf16x8, wreg[s][i]);
-#pragma unroll
-            for (int p = 0; p < MT; ++p) {
-              uint4 bv = *(const uint4*)(xb + (16 * p + l15) * 256 + (((4 * i + lq) ^ l15) << 4));
-              acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bv), acc[p], 0, 0, 0);
-            }
-          }
-          SK_LOAD_W(s, min(c + SK_DEPTH, c_last));
-          SK_STORE_X(buf ^ 1);
-          __syncthreads();
-        }
-      }
-    }
-  }
-  // hipcc (ROCm 7.2) was seen to read a just-written MFMA accumulator (v_accvgpr_read) with too few
-  // wait states when the read sits at a branch target; the barrier above already separates the last
-  // MFMA from everything below, keep it that way.
-#undef SK_LOAD_X
-#undef SK_STORE_X
-#undef SK_LOAD_W
-
-  if (!wave_active) return;
-  const int n = n_wave + 4 * lq;
-  if (partial != nullptr) {
-    float* pp = partial + (long)blockIdx.y * M * N;
-#pragma unroll
-    for (int p = 0; p < MT; ++p) {
-      int m = 16 * p + l15;
-      if (m < M) *(f32x4*)(pp + (long)m * N + n) = acc[p];
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < MT; ++p) {
-      int m = 16 * p + l15;
-      if (m < M) store_quad(acc[p], m, n, ep, om);
-    }
-  }
-}
-
 // Combine split-K slabs [S][M][N] fp32 and apply the epilogue; one thread per 4 columns.
 __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
                                                                  LiaEpilogue ep, LiaOutMap om) {
@@ -166,15 +59,152 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __r
   store_quad(a, m, n, ep, om);
 }
 
+// LDS slot (row, c) holds global 16-byte chunk (c ^ swz(row)) of that row; a 128-B row is half a
+// 256-B bank row, so consecutive row pairs share a bank row and swz uses row>>1.
+__device__ __forceinline__ int tl_swz(int row) { return (row >> 1) & 7; }
+
+// ---------------------------------------------------------------------------------------------
+// skinny regime (decode, M <= 256): weight-bandwidth bound.  Every operand byte arrives by LDS-DMA
+// (global_load_lds, 16 B/lane, 128-B rows -> whole cache lines per request) into an S-stage LDS ring;
+// S-1 chunks stay in flight per workgroup behind a COUNTED vmcnt and a raw s_barrier
+// (cdna_hip_programming.md "Pipelining across barriers").  Workgroup = 8 waves = 128 weight rows x all M
+// rows: the x chunk (L2-resident) is shared by 8 waves, so LDS-DMA moves 1.5 bytes per weight byte.
+// Measured on MI355X (tools/gemm_bench.hip, cold weights, M = 64): 4.6-5.1 TB/s on the OPT-30B shapes.
+// History: a first version kept W in a 4-deep VGPR ring (plain loads) and staged x through registers;
+// x and W then share one in-order vmcnt queue and the ring's depth collapses to one chunk (2.9 TB/s).
+// A 64-row workgroup moves 2 LDS-DMA bytes per weight byte and saturates the CU's ~34 GB/s LDS-DMA path
+// at 4.2 TB/s.
+// ---------------------------------------------------------------------------------------------
+constexpr int S2_BK = 64;     // K per chunk: 128-byte rows
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else static_assert(N < 0, "add the immediate");
+}
+
+template <int MT, int S, int NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                       const bf16_t* __restrict__ W, long ldw, int M, int N,
+                                                                       int K, int chunks_per_split,
+                                                                       float* __restrict__ partial, LiaEpilogue ep,
+                                                                       LiaOutMap om) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BN = 16 * WAVES;                    // W rows per workgroup (16 per wave)
+  constexpr int RR = 8 * WAVES;                     // rows one LDS-DMA round of the workgroup covers (128 B each)
+  constexpr int RB = RR * 128;                      // bytes per round
+  constexpr int XR = 16 * MT;                       // x rows in a stage
+  constexpr int XL = (XR + RR - 1) / RR;            // x rounds per chunk
+  constexpr int NL = 2 + XL;                        // LDS-DMA instructions per thread per chunk (2 rounds of W)
+  constexpr int WTILE = BN * 128, STAGE = WTILE + XL * RB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int n_tile = blockIdx.x * BN;
+  const int nchunks = K / S2_BK;
+  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_end = min(nchunks, c_begin + chunks_per_split);
+  const int n = c_end - c_begin;
+
+  // per-thread source rows (clamped: out-of-range rows re-read a valid one and are never stored)
+  const int srow = tid >> 3, sc = tid & 7;
+  const bf16_t* wsrc[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    int row = srow + RR * r;
+    wsrc[r] = W + (long)min(n_tile + row, N - 1) * ldw + ((sc ^ tl_swz(row)) << 3);
+  }
+  const bf16_t* xsrc[XL];
+#pragma unroll
+  for (int r = 0; r < XL; ++r) {
+    int row = srow + RR * r;
+    xsrc[r] = x + (long)min(min(row, XR - 1), M - 1) * ldx + ((sc ^ tl_swz(row)) << 3);
+  }
+  auto issue = [&](int c, int stage) {
+    char* st = smem + stage * STAGE;
+    const long koff = (long)c * S2_BK;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      // weights are read once by one workgroup: non-temporal (aux = 2) keeps them from evicting x in L2
+      if constexpr (NT) __builtin_amdgcn_global_load_lds(GL_AS1(wsrc[r] + koff), LDS_AS3(st + r * RB + wave * 1024), 16, 0, 2);
+      else __builtin_amdgcn_global_load_lds(GL_AS1(wsrc[r] + koff), LDS_AS3(st + r * RB + wave * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < XL; ++r)
+      __builtin_amdgcn_global_load_lds(GL_AS1(xsrc[r] + koff), LDS_AS3(st + WTILE + r * RB + wave * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (n > 0) {
+    const int c_last = c_end - 1;
+#pragma unroll
+    for (int j = 0; j < S - 1; ++j) issue(min(c_begin + j, c_last), j);
+    const int wrow = wave * 16 + l15;
+    for (int i = 0; i < n; ++i) {
+      // retire chunk i (issued S-1 groups ago); the groups behind it stay in flight
+      const int behind = min(S - 2, n - 1 - i);       // groups issued after chunk i that may still be pending
+      if (behind >= S - 2) wait_vmcnt<(S - 2) * NL>();
+      else if (S > 3 && behind == S - 3) wait_vmcnt<(S > 3 ? (S - 3) : 0) * NL>();
+      else if (S > 4 && behind == S - 4) wait_vmcnt<(S > 4 ? (S - 4) : 0) * NL>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (i + S - 1 < n) issue(c_begin + i + S - 1, (i + S - 1) % S);
+      const char* wt = smem + (i % S) * STAGE;
+      const char* xt = wt + WTILE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + wrow * 128 + (((4 * ks + lq) ^ tl_swz(wrow)) << 4)));
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+          int row = 16 * p + l15;
+          bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(xt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[p], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // keep the last MFMA well clear of the accumulator reads below (see the note in v1)
+  __builtin_amdgcn_s_barrier();
+
+  const int n_wave = n_tile + wave * 16;
+  if (n_wave >= N) return;
+  const int nn = n_wave + 4 * lq;
+  if (partial != nullptr) {
+    float* pp = partial + (long)blockIdx.y * M * N;
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      int m = 16 * p + l15;
+      if (m < M) *(f32x4*)(pp + (long)m * N + nn) = acc[p];
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      int m = 16 * p + l15;
+      if (m < M) store_quad(acc[p], m, nn, ep, om);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // tiled regime
 // ---------------------------------------------------------------------------------------------
 constexpr int TL_BM = 128, TL_BN = 128, TL_BK = 64;
 constexpr int TL_TILE_BYTES = 128 * TL_BK * 2;  // one operand tile: 128 rows x 128 B
 
-// LDS slot (row, c) holds global 16-byte chunk (c ^ swz(row)) of that row; a 128-B row is half a
-// 256-B bank row, so consecutive row pairs share a bank row and swz uses row>>1.
-__device__ __forceinline__ int tl_swz(int row) { return (row >> 1) & 7; }
 
 __device__ __forceinline__ void tl_stage(const bf16_t* __restrict__ g, long ld, int row0, int rows_valid, int k0,
                                          char* lds_tile, int tid) {
@@ -274,12 +304,19 @@ extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
   return (size_t)8 * M * N * sizeof(float);
 }
 
-template <int MT>
-static void launch_skinny(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K, int split,
-                          int cps, float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
-  dim3 grid((N + SK_BN - 1) / SK_BN, split);
-  size_t lds = 2 * 16 * MT * 256;
-  hipLaunchKernelGGL(lia_gemm_skinny_kernel<MT>, grid, dim3(256), lds, st, x, ldx, W, ldw, M, N, K, cps,
+template <int MT, int S, int NT, int WAVES>
+static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K, int split, int cps,
+                           float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
+  constexpr int BN = 16 * WAVES, RR = 8 * WAVES;
+  constexpr int XL = (16 * MT + RR - 1) / RR;
+  dim3 grid((N + BN - 1) / BN, split);
+  size_t lds = (size_t)S * (BN * 128 + XL * RR * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)lia_gemm_skinny2_kernel<MT, S, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lia_gemm_skinny2_kernel<MT, S, NT, WAVES>), grid, dim3(64 * WAVES), lds, st, x, ldx, W, ldw, M, N, K, cps,
                      split > 1 ? partial : nullptr, ep, om);
 }
 
@@ -292,15 +329,22 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   if (regime) *regime = 0;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N % 16) != 0 || (om->seg_n % 4) != 0) return -1;
-  if (M <= 256 && (K % SK_BK) == 0) {
-    const int nchunks = K / SK_BK;
-    const int tiles = (N + SK_BN - 1) / SK_BN;
+  if (M <= 256 && (K % (2 * S2_BK)) == 0) {
+    constexpr int WAVES = 8, BN = 16 * WAVES;
+    const int nchunks = K / S2_BK;
+    const int tiles = (N + BN - 1) / BN;
+    // M <= 64: 3 stages x 24 KB -> two 8-wave workgroups per CU = 512 slots on the chip
+    const int slots = M <= 64 ? 512 : 256;
     int split = 1;
     if (force_split > 0) {
       split = force_split;
     } else {
-      // aim for >= 2 workgroups per CU; every split needs a few chunks to amortise its prologue
-      while (split < 8 && tiles * split < 512 && nchunks / (split * 2) >= 4) split *= 2;
+      // fill the slots once; beyond 4 slices the fp32 slab traffic (2 x M x BN x 4 B per workgroup) costs more
+      // than the idle CUs it recovers (measured on OPT-30B shapes, tools/gemm_bench.hip)
+      split = (slots + tiles / 2) / tiles;
+      if (tiles * 10 > slots * 6 && tiles < slots) split = 3;   // 0.6..1 waves: three slices balance better than one
+      split = split < 1 ? 1 : (split > 4 ? 4 : split);
+      while (split > 1 && nchunks / split < 8) --split;
     }
     if (split > nchunks) split = nchunks;
     if (split > 1 && (size_t)split * M * N * sizeof(float) > workspace_bytes) split = 1;
@@ -308,11 +352,11 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     split = (nchunks + cps - 1) / cps;
     if (regime) *regime = 1;
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (M <= 16) launch_skinny<1>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-    else if (M <= 32) launch_skinny<2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-    else if (M <= 64) launch_skinny<4>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-    else if (M <= 128) launch_skinny<8>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-    else launch_skinny<16>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 64) launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 128) launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     if (split > 1) {
       long nq = (long)M * (N / 4);

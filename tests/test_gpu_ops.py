@@ -86,7 +86,9 @@ def test_linear(gpu, oracle, M, N, K, relu, res, split):
                    split_k=split)
     ctx.synchronize()
     ref = oracle.linear(x, w, bias, r, relu=relu, split_bias=True)
-    assert_close(to_bits(y), ref, atol=0.02, rtol=0.008, min_exact=0.97, what=f"linear {M}x{N}x{K}")
+    # with a residual the pre-residual value (|t| up to ~6, ulp 0.031) can flip by one ulp and then cancel against
+    # the residual, so the absolute bound is one ulp of the intermediate, not of the result
+    assert_close(to_bits(y), ref, atol=0.035 if res else 0.02, rtol=0.008, min_exact=0.97, what=f"linear {M}x{N}x{K}")
 
 
 def test_linear_no_bias_and_errors(gpu, oracle):

@@ -7,7 +7,8 @@ ctx = ops.Context(0, 1 << 30)
 def dev(b): return torch.from_numpy(np.ascontiguousarray(b).view(np.int16)).view(torch.bfloat16).cuda()
 def bits(t): return t.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
 def rb(seed, shape, s=1.0): return synth.f32_to_bf16_bits((s*np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))
-for (M,N,K,split) in [(64,512,1024,1),(64,512,1024,2),(16,512,1024,2),(32,512,1024,1),(64,64,128,1),(64,64,256,1),(64,64,512,1),(48,64,256,1)]:
+shapes = eval(sys.argv[1]) if len(sys.argv) > 1 else [(130,768,512,0),(130,768,512,1),(256,768,512,0),(130,64,128,1),(130,64,256,1),(129,64,512,1),(200,64,512,1)]
+for (M,N,K,split) in shapes:
     x, w = rb(10,(M,K)), rb(11,(N,K),K**-0.5)
     y = ctx.linear(dev(x), dev(w), split_k=split); ctx.synchronize()
     ref = o.linear(x, w)

@@ -1,0 +1,53 @@
+// Stand-alone timing of the GEMM kernels on cold weights (rotating buffers > Infinity Cache).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I isca-2025-lia_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench
+#include "../isca-2025-lia_amd/csrc/lia_gemm.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("ERR %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint32_t h = (uint32_t)(i * 2654435761u) ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    float f = ((int)(h & 0xffff) - 32768) * (0.02f / 32768.f);
+    p[i] = (uint16_t)(__float_as_uint(f) >> 16);
+  }
+}
+
+int main(int argc, char** argv) {
+  int M = argc > 1 ? atoi(argv[1]) : 64;
+  int force_split = argc > 2 ? atoi(argv[2]) : 0;
+
+  struct Shape { const char* name; int N, K; };
+  std::vector<Shape> shapes = {{"qkv", 21504, 7168}, {"out", 7168, 7168}, {"fc1", 28672, 7168}, {"fc2", 7168, 28672}, {"lm_head", 50272, 7168}};
+  const int NBUF = 4;
+  size_t maxw = (size_t)50272 * 7168;
+  uint16_t* w[NBUF];
+  for (int i = 0; i < NBUF; ++i) { CK(hipMalloc(&w[i], maxw * 2)); fill_kernel<<<2048, 256>>>(w[i], maxw, 17 + i); }
+  uint16_t *x, *y, *bias, *res; float* ws;
+  CK(hipMalloc(&x, (size_t)M * 28672 * 2)); fill_kernel<<<2048, 256>>>(x, (size_t)M * 28672, 3);
+  CK(hipMalloc(&y, (size_t)M * 50272 * 2)); CK(hipMalloc(&bias, 50272 * 2)); CK(hipMalloc(&res, (size_t)M * 50272 * 2));
+  fill_kernel<<<256, 256>>>(bias, 50272, 5); fill_kernel<<<2048, 256>>>(res, (size_t)M * 50272, 7);
+  size_t ws_bytes = (size_t)8 * (M <= 256 ? M : 1) * 50272 * 4; CK(hipMalloc(&ws, ws_bytes));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipDeviceSynchronize());
+  for (auto& s : shapes) {
+    LiaEpilogue ep{bias, res, s.N, 0};
+    LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
+    const int iters = 12;
+    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K, w[it % NBUF], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, force_split, st, nullptr, nullptr, nullptr);
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K, w[it % NBUF], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, force_split, st, nullptr, nullptr, nullptr);
+    CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    double bytes = 2.0 * ((double)s.N * s.K + (double)M * s.K + (double)M * s.N);
+    double flops = 2.0 * M * (double)s.N * s.K;
+    printf("%-8s M=%d N=%d K=%d: %8.1f us  %7.1f GB/s  %7.1f TFLOP/s\n", s.name, M, s.N, s.K, ms * 1e3, bytes / ms / 1e6, flops / ms / 1e9);
+  }
+  return 0;
+}
