@@ -148,11 +148,15 @@ def main():
 
     # measured generation: prefill, W warm-up decode steps, K timed decode steps
     kv.len = 0
+    sched.stream_stats(reset=True)
+    sched.ctx.prof_start(4096)
     sync()
     t0 = time.time()
     logits, nxt = sched.forward(ids, kv, max_new_tokens=new, **flags)
     sync()
     prefill_ms = 1e3 * (time.time() - t0)
+    prof_prefill = sched.ctx.prof_stop()
+    pre_h2d_bytes, pre_h2d_ms = sched.stream_stats()
     cur = nxt.cpu()[:, None]
     for _ in range(a.warmup):
         logits, nxt = sched.forward(cur, kv, max_new_tokens=new, **flags)
@@ -204,6 +208,10 @@ def main():
             "host_link": {"bound": "pcie", "achieved": h2d_bytes / (elapsed * 1e9), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                           "frac": h2d_bytes / (elapsed * 1e9) / PCIE_PEAK_GBS,
                           "copy_engine_busy_frac": (h2d_ms * 1e-3) / elapsed, "bytes_per_step": h2d_bytes / a.steps},
+            "prefill_detail": {"gemm_ms": prof_prefill["tiled_ms"], "gemm_launches": prof_prefill["tiled_launches"],
+                               "gemm_tflops": prof_prefill["tiled_flops"] / max(prof_prefill["tiled_ms"], 1e-9) / 1e9,
+                               "mfma_frac": prof_prefill["tiled_flops"] / max(prof_prefill["tiled_ms"], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS,
+                               "h2d_busy_ms": pre_h2d_ms, "h2d_gbs_while_busy": pre_h2d_bytes / max(pre_h2d_ms, 1e-9) / 1e6},
             "build_s": build_s,
         }
         if world == 1 and not a.no_cpu_baseline:

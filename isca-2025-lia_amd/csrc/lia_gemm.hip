@@ -64,6 +64,66 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __r
 __device__ __forceinline__ int tl_swz(int row) { return (row >> 1) & 7; }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-staged epilogue of the tiled kernels.  A wave's accumulators cover 64 columns n x (16*MB) rows m, the
+// lane owning 4 consecutive n of one m: stored directly that is 32-byte fragments of 16 different rows per
+// instruction.  Instead each wave parks its tile as bf16 [m][64 n] (128-byte rows, XOR-swizzled 16-byte
+// chunks) in its own LDS region after matmul-rounding, bias and relu, then streams it out row-wise:
+// 16 bytes per lane, whole 128-byte lines per row, the residual read the same way.  Rounding points are
+// unchanged: bf16(acc) -> bf16(+bias) -> relu -> bf16(residual + .).
+// ---------------------------------------------------------------------------------------------
+template <int MB>
+__device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char* region, int m_base, int n_base, int M, int N,
+                                                 const LiaEpilogue& ep, const LiaOutMap& om, int lane) {
+  const int l15 = lane & 15, lq = lane >> 4;
+  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = n_base + i * 16 + 4 * lq;
+    if (hb && n < N) {
+      uint2 bb = *(const uint2*)(ep.bias + n);
+      b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
+    }
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const int m = j * 16 + l15;
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t[e] = rbf(acc[i][j][e]);
+        if (hb) t[e] = rbf(t[e] + b[e]);
+        if (ep.relu) t[e] = fmaxf(t[e], 0.f);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(t[0], t[1]);
+      o.y = pack_bf16x2(t[2], t[3]);
+      const int chunk = (2 * i + (lq >> 1)) ^ (m & 7);
+      *(uint2*)(region + m * 128 + chunk * 16 + (lq & 1) * 8) = o;
+    }
+  }
+  // same-wave LDS write -> read: program order + the compiler's lgkmcnt wait suffice (the region is private)
+  const int c = lane & 7;
+#pragma unroll
+  for (int r = 0; r < 2 * MB; ++r) {
+    const int m = r * 8 + (lane >> 3);
+    const int gm = m_base + m, gn = n_base + c * 8;
+    uint4 v = *(const uint4*)(region + m * 128 + ((c ^ (m & 7)) << 4));
+    if (gm < M && gn < N) {
+      if (hr) {
+        uint4 rr = *(const uint4*)(ep.residual + (long)gm * ep.ldr + gn);
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ow[e] = pack_bf16x2(bf2f(rw[e] & 0xffff) + bf2f(vw[e] & 0xffff), bf2f(rw[e] >> 16) + bf2f(vw[e] >> 16));
+        v = uint4{ow[0], ow[1], ow[2], ow[3]};
+      }
+      *(uint4*)lia_out_ptr(om, gm, gn) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // skinny regime (decode, M <= 256): weight-bandwidth bound.  Every operand byte arrives by LDS-DMA
 // (global_load_lds, 16 B/lane, 128-B rows -> whole cache lines per request) into an S-stage LDS ring;
 // S-1 chunks stay in flight per workgroup behind a COUNTED vmcnt and a raw s_barrier
@@ -282,22 +342,102 @@ __global__ __launch_bounds__(256) void lia_gemm_tiled_kernel(const bf16_t* __res
     cur ^= 1;
   }
 
+  epilogue_via_lds<4>(acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiled regime, large: 256 x 256 x 64 tiles, 8 waves (2 along n x 4 along m... each wave 64 n x 128 m),
+// one workgroup per CU.  Twice the flops per staged byte of the 128^2 tile: the 128^2 structure tops out
+// near 0.9 PFLOP/s because its LDS-DMA traffic (64 flop/B) saturates the CU's load path first.
+// LDS: 2 buffers x (W tile 32 KB + x tile 32 KB) = 128 KB.
+// ---------------------------------------------------------------------------------------------
+constexpr int T2_BM = 256, T2_BN = 256, T2_BK = 64;
+constexpr int T2_TILE_BYTES = 256 * T2_BK * 2;  // one operand tile: 256 rows x 128 B = 32 KB
+
+__device__ __forceinline__ void t2_stage(const bf16_t* __restrict__ g, long ld, int row0, int rows_valid, int k0,
+                                         char* lds_tile, int tid) {
+  const int wave = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int n = n0 + wn * 64 + i * 16 + 4 * lq;
-    if (n < N) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int m = m0 + wm * 64 + j * 16 + l15;
-        if (m < M) store_quad(acc[i][j], m, n, ep, om);
-      }
-    }
+  for (int r = 0; r < 4; ++r) {
+    int row = r * 64 + (tid >> 3);
+    int c = tid & 7;
+    int grow = min(row0 + row, rows_valid - 1);
+    const bf16_t* src = g + (long)grow * ld + k0 + ((c ^ tl_swz(row)) << 3);
+    __builtin_amdgcn_global_load_lds(GL_AS1(src), LDS_AS3(lds_tile + r * 8192 + wave * 1024), 16, 0, 0);
   }
+}
+
+__global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                 const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
+                                                                 int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | x tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wn = wave & 3, wm = wave >> 2;   // wave tile: n rows [64 wn, +64), m rows [128 wm, +128)
+
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  constexpr int GM = 8;
+  const int group = lin / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int in_g = lin - group * GM * tiles_n;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  const int m0 = tm * T2_BM, n0 = tn * T2_BN;
+
+  f32x4 acc[4][8];  // [n-block][m-block]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / T2_BK;
+  t2_stage(W, ldw, n0, N, 0, smem, tid);
+  t2_stage(x, ldx, m0, M, 0, smem + T2_TILE_BYTES, tid);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    char* wt = smem + cur * 2 * T2_TILE_BYTES;
+    char* xt = wt + T2_TILE_BYTES;
+    if (kt + 1 < nk) {
+      char* nw = smem + (cur ^ 1) * 2 * T2_TILE_BYTES;
+      t2_stage(W, ldw, n0, N, (kt + 1) * T2_BK, nw, tid);
+      t2_stage(x, ldx, m0, M, (kt + 1) * T2_BK, nw + T2_TILE_BYTES, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = wn * 64 + i * 16 + l15;
+        a[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int row = wm * 128 + j * 16 + l15;
+        b[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(xt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // every wave is past its last LDS read (the loop's closing barrier): reuse the staging buffers
+  epilogue_via_lds<8>(acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, M, N, ep, om, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------------------------
+static int g_tiled_variant = 256;
+extern "C" void lia_gemm_set_tiled_variant(int v) { g_tiled_variant = v; }
+
 extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
   // worst case split-K = 8 fp32 slabs of a skinny problem
   if (M > 256) return 0;
@@ -366,8 +506,21 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     return 0;
   }
   if ((K % TL_BK) != 0) return -1;
-  int tiles_m = (M + TL_BM - 1) / TL_BM, tiles_n = (N + TL_BN - 1) / TL_BN;
   if (regime) *regime = 2;
+  if (M >= 1024 && N >= 512 && g_tiled_variant == 256) {
+    int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_TILE_BYTES);
+      attr_set = true;
+    }
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL(lia_gemm_tiled256_kernel, dim3(tiles_m * tiles_n), dim3(512), 4 * T2_TILE_BYTES, st, x, ldx, W, ldw, M, N,
+                       K, tiles_m, tiles_n, *ep, *om);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    return 0;
+  }
+  int tiles_m = (M + TL_BM - 1) / TL_BM, tiles_n = (N + TL_BN - 1) / TL_BN;
   if (ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(lia_gemm_tiled_kernel, dim3(tiles_m * tiles_n), dim3(256), 4 * TL_TILE_BYTES, st, x, ldx, W, ldw,
                      M, N, K, tiles_m, tiles_n, *ep, *om);
