@@ -79,6 +79,24 @@ def cpu_baseline(shape, B, T, threads=None):
                       f"B={Bp} T={T}; scaled x{L} layers (x{B // Bp} batch for prefill); embeddings/lm_head excluded"}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
+    (profiles/r*_bench_opt30b_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).
+    PMC collection cannot run inside the timed benchmark, so the live line carries the committed measurement."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_opt30b_pmc_hbm.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d["kernels"].items():
+            if kernel_substr in k:
+                return v["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,8 +121,11 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dp = os.environ.get("LIA_FORCE_DP") == "1"      # exercise the broadcast path on a single GPU (world 1)
+    if world > 1 or force_dp:
         import torch.distributed as dist
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from lia_amd.model import LiaOPTModel, resolve_shape
@@ -122,7 +143,9 @@ def main():
                  gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=False, no_overlap=False)
 
     t_build = time.time()
-    group = dp.DataParallelGroup(dist, rank, world, local_rank) if world > 1 else None
+    group = dp.DataParallelGroup(dist, rank, world, local_rank) if dist is not None else None
+    if group is not None and world > 1:
+        group.pin_host_threads()
     model = LiaOPTModel.random_init(shape, seed=0, n_gpu_layers=n_gpu, pin_weight=True,
                                     host_owner=(group is None or group.is_root))
     sched = OffloadScheduler(model, device=local_rank, dp_group=group)
@@ -185,6 +208,7 @@ def main():
         tokens = B * world * a.steps
         sk_ms, sk_n = prof["skinny_ms"], max(1, prof["skinny_launches"])
         achieved = prof["skinny_bytes"] / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
+        traffic, traffic_src = (pmc_traffic("lia_gemm_skinny2_kernel<4") if (a.model == "opt-30b" and B == 64) else (None, None))
         out = {
             "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if (a.model == "opt-30b" and B == 64 and T == 256)
                       else f"decode tokens/s (+ prefill ms), {a.model} bs={B} in{T} gpu%={a.gpu_percentage}",
@@ -201,9 +225,9 @@ def main():
             "prefill_ms": prefill_ms,
             "decode_latency_ms": {"mean": 1e3 * sum(step_lat) / len(step_lat), "p90": 1e3 * sorted(step_lat)[int(0.9 * (len(step_lat) - 1))],
                                   "max": 1e3 * max(step_lat)},
-            "roofline": {"bound": "hbm", "kernel": "lia_gemm_skinny_kernel (decode linears + lm_head)",
+            "roofline": {"bound": "hbm", "kernel": "lia_gemm_skinny2_kernel<4,3,1,8> (decode linears + lm_head)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "launches": prof["skinny_launches"], "avg_launch_us": 1e3 * sk_ms / sk_n,
+                         "traffic": traffic, "traffic_source": traffic_src, "launches": prof["skinny_launches"], "avg_launch_us": 1e3 * sk_ms / sk_n,
                          "algorithmic_bytes_per_launch": prof["skinny_bytes"] / sk_n},
             "host_link": {"bound": "pcie", "achieved": h2d_bytes / (elapsed * 1e9), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                           "frac": h2d_bytes / (elapsed * 1e9) / PCIE_PEAK_GBS,
@@ -216,10 +240,18 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, B, T)
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is block-buffered when stdout is a pipe: flush it
+        # first so that the JSON line is the LAST line of the output
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
