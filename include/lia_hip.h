@@ -143,6 +143,18 @@ int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const lia_bf16* v, 
                        lia_bf16* out, int B, int T, int pos0, int heads, int head_dim, int cache_batch, int b0,
                        int n_threads);
 
+/* policy 1, "compute everything on CPU" (modeling_opt.py:1168): the same layer entirely on the host cores.  The
+ * reference routes it through IPEX (tpp_linear_bias/_relu/_add, TPPGEMMKrnl.h:89-176,671-765,858-951 + the masked
+ * MHA kernel); here AVX-512(-BF16) code in the same library.  All pointers are HOST pointers; weights row-major. */
+int lia_host_layer_forward(const lia_layer_desc* d, const void* const weights[16], const lia_bf16* x, lia_bf16* y,
+                           lia_bf16* kcache, lia_bf16* vcache, int smax, int cache_batch, int B, int T, int pos0, int b0,
+                           int n_threads);
+int lia_host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H, float eps,
+                       int n_threads);
+int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y, long M,
+                    int N, int K, int relu, int n_threads);
+int lia_host_has_avx512_bf16(void);
+
 /* ---- weight streamer ------------------------------------------------------------------------------
  * Replaces load_layer / layer_copy under torch.cuda.stream(load_weight_stream) + device-wide syncs
  * (modeling_opt.py:270-318,1287-1312,1508-1515): n_slots HBM slots, one pinned hipMemcpyAsync per packed

@@ -267,3 +267,150 @@ extern "C" void check_memory_node(void* memory, int num) {
   }
   for (int i = 0; i < num; ++i) printf("Page %d is on node %d\n", i, status[i]);
 }
+
+// ------------------------------------------------------------------------------------------------
+// policy 1: the whole decoder layer on the host cores ("compute everything on CPU", lia/modeling_opt.py:1168;
+// the reference runs it through IPEX: tpp_linear_bias/_relu/_add, csrc/cpu/tpp/kernels/TPPGEMMKrnl.h:89-176,
+// 671-765, 858-951 + the masked MHA kernel).  AVX-512-BF16 (vdpbf16ps) dot products on row-major bf16
+// weights; CPU rounding semantics: the bias is added to the fp32 accumulator before the single rounding
+// (tpp_linear_bias), "+ residual" is a second bf16 op (_IPEXlinearAddRef).
+// ------------------------------------------------------------------------------------------------
+static inline float bf16_to_f32(lia_bf16 v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+static void host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H, float eps) {
+#pragma omp parallel for schedule(static)
+  for (long r = 0; r < rows; ++r) {
+    const lia_bf16* xr = x + r * (long)H;
+    lia_bf16* yr = y + r * (long)H;
+    __m512 s = _mm512_setzero_ps();
+    for (int i = 0; i < H; i += 16) s = _mm512_add_ps(s, bf16x16_to_f32(xr + i));
+    const float mean = _mm512_reduce_add_ps(s) / (float)H;
+    const __m512 vm = _mm512_set1_ps(mean);
+    __m512 q = _mm512_setzero_ps();
+    for (int i = 0; i < H; i += 16) {
+      __m512 d = _mm512_sub_ps(bf16x16_to_f32(xr + i), vm);
+      q = _mm512_fmadd_ps(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(_mm512_reduce_add_ps(q) / (float)H + eps);
+    for (int i = 0; i < H; ++i) yr[i] = f32_to_bf16((bf16_to_f32(xr[i]) - mean) * rstd * bf16_to_f32(g[i]) + bf16_to_f32(b[i]));
+  }
+}
+
+#if defined(__AVX512BF16__)
+#define LIA_HAVE_DPBF16 1
+static inline __m512 dp32(__m512 acc, const lia_bf16* a, const lia_bf16* b) {
+  return _mm512_dpbf16_ps(acc, (__m512bh)_mm512_loadu_si512((const void*)a), (__m512bh)_mm512_loadu_si512((const void*)b));
+}
+#else
+#define LIA_HAVE_DPBF16 0
+static inline __m512 dp32(__m512 acc, const lia_bf16* a, const lia_bf16* b) {
+  acc = _mm512_fmadd_ps(bf16x16_to_f32(a), bf16x16_to_f32(b), acc);
+  return _mm512_fmadd_ps(bf16x16_to_f32(a + 16), bf16x16_to_f32(b + 16), acc);
+}
+#endif
+
+// y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.
+static void host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
+                        long M, int N, int K, int relu) {
+  constexpr int RB = 4;
+  const long mblocks = (M + RB - 1) / RB;
+  const int nblocks = (N + RB - 1) / RB;
+  // decode-sized M: parallel over weight rows (each streamed once); prefill-sized M: over both, 256-row x panels
+  const long MP = 256;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+  for (long mp = 0; mp < M; mp += MP)
+    for (int nb = 0; nb < nblocks; ++nb) {
+      const int n0 = nb * RB, nr = N - n0 < RB ? N - n0 : RB;
+      const long mend = mp + MP < M ? mp + MP : M;
+      for (long m0 = mp; m0 < mend; m0 += RB) {
+        const int mr = mend - m0 < RB ? (int)(mend - m0) : RB;
+        __m512 acc[RB][RB];
+        for (int i = 0; i < RB; ++i)
+          for (int j = 0; j < RB; ++j) acc[i][j] = _mm512_setzero_ps();
+        if (mr == RB && nr == RB) {
+          // full block: constant trip counts keep the 16 accumulators in zmm registers
+          const lia_bf16* xr = x + m0 * (long)K;
+          const lia_bf16* wr = w + (long)n0 * K;
+          for (int k = 0; k < K; k += 32) {
+#pragma GCC unroll 4
+            for (int i = 0; i < RB; ++i)
+#pragma GCC unroll 4
+              for (int j = 0; j < RB; ++j) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
+          }
+        } else {
+          for (int k = 0; k < K; k += 32)
+            for (int i = 0; i < mr; ++i)
+              for (int j = 0; j < nr; ++j) acc[i][j] = dp32(acc[i][j], x + (m0 + i) * (long)K + k, w + (long)(n0 + j) * K + k);
+        }
+        for (int i = 0; i < mr; ++i)
+          for (int j = 0; j < nr; ++j) {
+            float t = _mm512_reduce_add_ps(acc[i][j]) + (bias ? bf16_to_f32(bias[n0 + j]) : 0.f);
+            t = round_bf16(t);
+            if (relu && t < 0.f) t = 0.f;
+            if (residual) t = round_bf16(bf16_to_f32(residual[(m0 + i) * (long)N + n0 + j]) + t);
+            y[(m0 + i) * (long)N + n0 + j] = f32_to_bf16(t);
+          }
+      }
+    }
+  (void)mblocks;
+}
+
+extern "C" int lia_host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H,
+                                  float eps, int n_threads) {
+  if (!x || !g || !b || !y) return LIA_ERR_MISSING;
+  if (rows < 0 || H <= 0 || H % 16) { lia_set_error("lia_host_layernorm: H=%d must be a multiple of 16", H); return LIA_ERR_INVALID; }
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+  host_layernorm(x, g, b, y, rows, H, eps);
+  return LIA_OK;
+}
+
+extern "C" int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual,
+                               lia_bf16* y, long M, int N, int K, int relu, int n_threads) {
+  if (!x || !w || !y) return LIA_ERR_MISSING;
+  if (M < 0 || N <= 0 || K <= 0 || K % 32) { lia_set_error("lia_host_linear: K=%d must be a multiple of 32", K); return LIA_ERR_INVALID; }
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+  host_linear(x, w, bias, residual, y, M, N, K, relu);
+  return LIA_OK;
+}
+
+// One decoder layer on the host: OPTDecoderLayer_forward with gpu_linear = gpu_attn = False (decoder.py:191-193,
+// 206, 248-250, 276, 286-287, 312-315; attentions.py:365-376, 401-440).  weights: 16 HOST pointers in create_buffer
+// order, row-major.  x, y: host [B,T,H]; cache: host [smax][cache_batch][h][d], rows pos0.. appended.
+extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const weights[16], const lia_bf16* x, lia_bf16* y,
+                                      lia_bf16* kcache, lia_bf16* vcache, int smax, int cache_batch, int B, int T, int pos0,
+                                      int b0, int n_threads) {
+  if (!d || !weights || !x || !y || !kcache || !vcache) { lia_set_error("lia_host_layer_forward: NULL argument"); return LIA_ERR_MISSING; }
+  for (int i = 0; i < 16; ++i)
+    if (!weights[i]) { lia_set_error("lia_host_layer_forward: weights[%d] is NULL", i); return LIA_ERR_MISSING; }
+  const int H = d->hidden, F = d->ffn, heads = d->heads;
+  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || H % 32 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
+      pos0 + T > smax || b0 < 0 || b0 + B > cache_batch) {
+    lia_set_error("lia_host_layer_forward: bad shape H=%d heads=%d F=%d B=%d T=%d pos0=%d smax=%d", H, heads, F, B, T, pos0, smax);
+    return LIA_ERR_INVALID;
+  }
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+  const lia_bf16* const* W = (const lia_bf16* const*)weights;
+  const long M = (long)B * T;
+  std::vector<lia_bf16> ln((size_t)M * H), q((size_t)M * H), k((size_t)M * H), v((size_t)M * H), ao((size_t)M * H),
+      h1((size_t)M * H), f1((size_t)M * F);
+  host_layernorm(x, W[0], W[1], ln.data(), M, H, d->ln_eps);
+  host_linear(ln.data(), W[4], W[5], nullptr, k.data(), M, H, H, 0);
+  host_linear(ln.data(), W[6], W[7], nullptr, v.data(), M, H, H, 0);
+  host_linear(ln.data(), W[2], W[3], nullptr, q.data(), M, H, H, 0);
+  int rc = lia_host_attention(q.data(), k.data(), v.data(), kcache, vcache, ao.data(), B, T, pos0, heads, H / heads, cache_batch,
+                              b0, n_threads);
+  if (rc) return rc;
+  host_linear(ao.data(), W[8], W[9], x, h1.data(), M, H, H, 0);
+  host_layernorm(h1.data(), W[10], W[11], ln.data(), M, H, d->ln_eps);
+  host_linear(ln.data(), W[12], W[13], nullptr, f1.data(), M, F, H, 1);
+  host_linear(f1.data(), W[14], W[15], h1.data(), y, M, H, F, 0);
+  return LIA_OK;
+}
+
+extern "C" int lia_host_has_avx512_bf16(void) { return LIA_HAVE_DPBF16; }

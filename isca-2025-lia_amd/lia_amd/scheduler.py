@@ -188,12 +188,8 @@ class OffloadScheduler:
         n_gpu = int(L * gpu_percentage / 100)                      # lia/modeling_opt.py:1182
         is_prefill = T != 1                                        # :1186-1188
         policy = prefill_policy if is_prefill else decoding_policy
-        if n_gpu < L and policy == 1:
-            raise NotImplementedError(
-                "policy 1 (everything on the CPU) is the IPEX baseline, not a GPU schedule; "
-                "run it with lia_amd.cpu_baseline (timed beside the GPU path by bench.py)")
-        if n_gpu < L and policy not in (0, 2):
-            raise ValueError(f"unsupported policy {policy} (prefill: 0; decode: 0 or 2)")
+        if n_gpu < L and policy not in (0, 1, 2):
+            raise ValueError(f"unsupported policy {policy} (prefill: 0 or 1; decode: 0, 1 or 2)")
         if is_prefill and policy == 2 and n_gpu < L:
             raise ValueError("prefill policy must be 0 on the GPU path (the reference has no prefill-2 branch)")
         if B % num_minibatch:
@@ -215,6 +211,12 @@ class OffloadScheduler:
                                   sh.hidden, ctypes.c_void_p(ctx.stream)), "lia_embed")
 
         first_streamed = n_gpu
+        if policy == 1 and n_gpu < L:
+            x = self._host_layers(x, kv_state, n_gpu, B, T, pos0)  # resident prefix on the GPU, the rest on the CPU
+            logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
+            ctx.synchronize()
+            kv_state.len = pos0 + T
+            return logits, nxt
         if n_gpu < L and overlap:
             pipe.prefetch(first_streamed)                          # no-op if the previous step already wrapped to it
         for idx in range(L):
@@ -253,6 +255,34 @@ class OffloadScheduler:
             ctx.kv_store_wait()                                    # host cache complete before the next step reads it
         kv_state.len = pos0 + T
         return logits, nxt
+
+    def _host_layers(self, x, kv_state, n_gpu, B, T, pos0):
+        """Policy 1 ("compute everything on CPU", lia/modeling_opt.py:1168, branches :1367-1377 / :1545-1555): layers
+        [0, n_gpu) still run on the GPU (policy 3), the hidden state then moves to pinned host memory ONCE
+        (:1262-1267) and every remaining layer runs on the host cores (lia_host_layer_forward) straight from the
+        host copy of its weights -- nothing is streamed."""
+        m, sh, ctx = self.model, self.model.shape, self.ctx
+        lib = ctx.lib
+        y = torch.empty_like(x)
+        for idx in range(n_gpu):
+            ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
+            x, y = y, x
+        ctx.synchronize()
+        hx = torch.empty((B, T, sh.hidden), dtype=torch.bfloat16, pin_memory=True)
+        hy = torch.empty_like(hx).pin_memory()
+        N.check(lib.lia_memcpy_d2h(ctypes.c_void_p(hx.data_ptr()), ctypes.c_void_p(x.data_ptr()), hx.numel() * 2), "lia_memcpy_d2h")
+        from . import hostinfo
+        threads = hostinfo.default_host_threads(self.dp.world if self.dp else 1)
+        for idx in range(n_gpu, sh.layers):
+            st = m.layers[idx]
+            w = ops.weight_ptr_array(st.host_ptr(), m.offsets)
+            kv = kv_state.kv[idx]
+            N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx.data_ptr()),
+                                               ctypes.c_void_p(hy.data_ptr()), ctypes.c_void_p(kv.k), ctypes.c_void_p(kv.v), kv.smax,
+                                               kv.batch, B, T, pos0, 0, threads), "lia_host_layer_forward")
+            hx, hy = hy, hx
+        N.check(lib.lia_memcpy_h2d(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(hx.data_ptr()), hx.numel() * 2), "lia_memcpy_h2d")
+        return x
 
     def stream_stats(self, reset=False):
         return self.pipe.stats(reset) if self.pipe else (0.0, 0.0)

@@ -196,3 +196,34 @@ def test_checkpoint_state_dict_conversion(native, oracle):
     for a, b in zip(got["layers"], m["layers"]):
         for n in synth.LAYER_TENSORS:
             assert a[n].shape == b[n].shape and (a[n] == b[n]).all(), n
+
+
+@pytest.mark.parametrize("B,T,pos0", [(2, 6, 0), (3, 1, 7)])
+def test_host_layer_forward_matches_oracle_policy1(native, oracle, B, T, pos0):
+    """lia_host_layer_forward (product, AVX-512-BF16) vs the oracle's policy-1 restatement (fused-bias linears,
+    fp32 attention).  vdpbf16ps sums bf16 pairs before accumulating, so agreement is to rounding, not bitwise."""
+    from lia_amd import ops
+    L = native.lib()
+    H, heads, F = 256, 4, 1024
+    W = synth.make_layer(3, H, F, 0.08)
+    x = synth.make_hidden(4, B, T, H)
+    d = H // heads
+    smax = pos0 + T + 2
+    rs = np.random.RandomState(9)
+    kc = synth.f32_to_bf16_bits(rs.standard_normal((smax, B, heads, d)).astype(np.float32))
+    vc = synth.f32_to_bf16_bits(rs.standard_normal((smax, B, heads, d)).astype(np.float32))
+    kc_o, vc_o = kc.copy(), vc.copy()
+    ref = oracle.layer_forward(1, W, x, kc_o, vc_o, pos0, heads)
+    desc = ops.make_desc(H, heads, F)
+    ws = [np.ascontiguousarray(W[n]) for n in synth.LAYER_TENSORS]
+    arr = (ctypes.c_void_p * 16)(*[w.ctypes.data for w in ws])
+    y = np.zeros_like(x)
+    rc = L.lia_host_layer_forward(ctypes.byref(desc), ctypes.byref(arr), x.ctypes.data, y.ctypes.data, kc.ctypes.data, vc.ctypes.data,
+                                  smax, B, B, T, pos0, 0, 4)
+    assert rc == 0, L.lia_last_error()
+    err = np.abs(synth.bf16_bits_to_f32(y) - synth.bf16_bits_to_f32(ref))
+    assert err.max() <= 0.07 and (y == ref).mean() > 0.9, (err.max(), (y == ref).mean())
+    assert (kc[pos0:pos0 + T] == kc_o[pos0:pos0 + T]).mean() > 0.97
+    bad = (ctypes.c_void_p * 16)(*[None] * 16)
+    assert L.lia_host_layer_forward(ctypes.byref(desc), ctypes.byref(bad), x.ctypes.data, y.ctypes.data, kc.ctypes.data, vc.ctypes.data,
+                                    smax, B, B, T, pos0, 0, 1) == native.LIA_ERR_MISSING

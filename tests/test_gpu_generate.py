@@ -39,11 +39,14 @@ FLAG_SETS = [
     dict(prefill_policy=0, decoding_policy=2, gpu_percentage=99, pin_weight=True),                   # all but one resident
     dict(prefill_policy=0, decoding_policy=2, gpu_percentage=0, pin_weight=False),                   # pageable -> bounce
     dict(prefill_policy=0, decoding_policy=2, gpu_percentage=25, pin_weight=True, no_overlap=True),
+    dict(),                                                                                          # defaults 1/1: the IPEX baseline
+    dict(prefill_policy=0, decoding_policy=1, gpu_percentage=34, pin_weight=True),                   # README online configs (0/1)
+    dict(prefill_policy=1, decoding_policy=2, gpu_percentage=0, pin_weight=True),
 ]
 
 
 @pytest.mark.parametrize("name", GEN_CASES)
-@pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k[:4]}{int(v)}" for k, v in f.items()))
+@pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k[:4]}{int(v)}" for k, v in f.items()) or "defaults")
 def test_generate_ids_match_hf_golden(name, flags):
     import torch
     from lia_amd.generation import generate
@@ -92,6 +95,6 @@ def test_generate_argument_errors():
         generate(model, t, max_new_tokens=c["max_pos"], prefill_policy=0, decoding_policy=2)
     with pytest.raises(ValueError):
         generate(model, t, max_new_tokens=2, prefill_policy=0, decoding_policy=2, num_minibatch=3 if c["B"] % 3 else 5)
-    with pytest.raises(NotImplementedError):
-        generate(model, t, max_new_tokens=2)  # defaults 1/1 = the CPU baseline
+    with pytest.raises(ValueError):
+        generate(model, t, max_new_tokens=2, prefill_policy=5, decoding_policy=2)
     model.close()
