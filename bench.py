@@ -44,6 +44,8 @@ def cpu_baseline(shape, B, T, threads=None):
     from lia_amd import hostinfo
     threads = threads or hostinfo.default_host_threads(1)
     orc.lib().lia_oracle_set_threads(threads)
+    fast = bool(orc.lib().lia_oracle_fast_available())
+    orc.lib().lia_oracle_set_fast(1 if fast else 0)     # vdpbf16ps inner loops when the host has AVX-512-BF16
     H, F, heads, L = shape.hidden, shape.ffn, shape.heads, shape.layers
     rs = np.random.RandomState(0)
     blk = (rs.standard_normal(1 << 20) * 0.02).astype(np.float32)
@@ -75,6 +77,7 @@ def cpu_baseline(shape, B, T, threads=None):
     return {"value": B / (dec_layer_s * L), "unit": "tokens/s", "cores": threads, "kind": "port",
             "cpu": hostinfo.cpu_model(), "isa": hostinfo.isa_flags(), "cpus_usable": hostinfo.usable_cpus(),
             "prefill_ms": 1e3 * pre_layer_s * L,
+            "inner_loop": "avx512_bf16 vdpbf16ps" if fast else "fp32 fma",
             "sample": f"oracle policy 1, ONE {shape.name}-shaped layer: decode step B={B} S={T + 1} x{reps} and prefill "
                       f"B={Bp} T={T}; scaled x{L} layers (x{B // Bp} batch for prefill); embeddings/lm_head excluded"}
 
@@ -110,6 +113,9 @@ def main():
     ap.add_argument("--decoding-policy", type=int, default=2)
     ap.add_argument("--num-minibatch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
+    ap.add_argument("--cxl-nodes", default=None, help="NUMA nodes of the CXL tier, e.g. 2,3 (default LIA_CXL_NODES or 2,3)")
+    ap.add_argument("--init", default="normal", choices=["normal", "uniform01"])
     ap.add_argument("--host-threads", type=int, default=0)
     a = ap.parse_args()
 
@@ -140,13 +146,16 @@ def main():
         raise SystemExit("prompt + steps exceeds max positions")
     n_gpu = int(shape.layers * a.gpu_percentage / 100)
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
-                 gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=False, no_overlap=False)
+                 gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=a.enable_cxl, no_overlap=False)
+    if a.cxl_nodes:
+        from lia_amd.cxl.numa_alloc import set_cxl_nodes
+        set_cxl_nodes([int(v) for v in a.cxl_nodes.split(",")])
 
     t_build = time.time()
     group = dp.DataParallelGroup(dist, rank, world, local_rank) if dist is not None else None
     if group is not None and world > 1:
         group.pin_host_threads()
-    model = LiaOPTModel.random_init(shape, seed=0, n_gpu_layers=n_gpu, pin_weight=True,
+    model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
                                     host_owner=(group is None or group.is_root))
     sched = OffloadScheduler(model, device=local_rank, dp_group=group)
     from lia_amd import hostinfo
@@ -217,7 +226,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{shape.name} shape (random-init N(0,0.02)), batch {B}/GPU identical rows, prompt {T}, "
                                    f"gpu%={a.gpu_percentage} ({n_gpu} resident + {shape.layers - n_gpu} streamed layers), "
-                                   f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight, "
+                                   f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
                                    f"num-minibatch {a.num_minibatch}",
                        "global_batch": B * world, "prompt_len": T, "new_tokens": new,
                        "parallelism": f"dp{world} batch-shard" if world > 1 else "single GPU",

@@ -66,3 +66,34 @@ def isa_flags():
     except OSError:
         pass
     return {w: False for w in want}
+
+
+def host_memory_budget():
+    """Bytes of host memory this process may still take without risking the container: the smaller of
+    MemAvailable and (cgroup memory.max - memory.current).  None when neither can be read."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) * 1024
+                break
+    except OSError:
+        pass
+    room = None
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        if mx != "max":
+            room = int(mx) - int(open("/sys/fs/cgroup/memory.current").read().strip())
+    except (OSError, ValueError):
+        pass
+    vals = [v for v in (avail, room) if v is not None]
+    return min(vals) if vals else None
+
+
+def check_host_allocation(nbytes, what, safety=0.85):
+    """Refuse (MemoryError) a planned host allocation that would not fit: pinned / registered pages cannot be
+    reclaimed, so overshooting a cgroup limit takes the whole container down instead of failing one malloc."""
+    budget = host_memory_budget()
+    if budget is not None and nbytes > safety * budget:
+        raise MemoryError(f"{what}: needs {nbytes / 2**30:.1f} GiB of host memory but only {budget / 2**30:.1f} GiB "
+                          f"are available to this container (cgroup limit / MemAvailable); refusing to allocate")

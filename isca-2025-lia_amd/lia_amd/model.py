@@ -141,11 +141,11 @@ class LayerStore:
         ptr = self._lib.numa_alloc_interleave(self.nbytes)
         if not ptr:
             raise MemoryError("Fail to allocate CXL memory!")  # same text as lia/modeling_opt.py:175
-        self._fill_host(ptr)
-        rc = self._lib.lia_numa_register(ptr, self.nbytes)
+        rc = self._lib.lia_numa_register(ptr, self.nbytes)      # register first: the fill below then runs at DMA speed
         if rc != 0:
             self._lib.numa_free_node(ptr, self.nbytes)
             N.check(rc, "lia_numa_register")
+        self._fill_host(ptr)
         self._free()
         self._ptr, self.tier = ptr, "cxl"
 
@@ -210,6 +210,9 @@ class LiaOPTModel:
         Every tensor group has its own seed, so data-parallel ranks draw identical resident layers;
         host_owner=False (non-root DP ranks) skips the streamed layers, which arrive by broadcast."""
         self = cls(shape)
+        if host_owner:
+            from . import hostinfo
+            hostinfo.check_host_allocation(self.streamed_bytes(n_gpu_layers), f"{shape.name}: {shape.layers - n_gpu_layers} streamed layers")
         g = torch.Generator(device="cuda")
         g.manual_seed(seed * 100003)
         H, F = shape.hidden, shape.ffn
@@ -262,6 +265,10 @@ class LiaOPTModel:
         key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
         if self.placed_for == key:
             return
+        if pin_weight:
+            from . import hostinfo
+            moving = sum(st.nbytes for i, st in enumerate(self.layers) if i >= n_gpu_layers and st.tier == "pageable")
+            hostinfo.check_host_allocation(moving, "pinning the streamed layers")
         for i, st in enumerate(self.layers):
             if st.tier == "remote":
                 continue

@@ -123,6 +123,8 @@ class KVState:
     def __init__(self, model, n_gpu, B, smax):
         sh = model.shape
         self.B, self.smax, self.len = B, smax, 0
+        from . import hostinfo
+        hostinfo.check_host_allocation(2 * (sh.layers - n_gpu) * smax * B * sh.hidden * 2, "host KV cache")
         self.tensors, self.kv = [], []
         for i in range(sh.layers):
             if i < n_gpu:

@@ -118,6 +118,70 @@ static void dot_block(const float* xf, long ldx, const float* wf, long ldw, int 
     }
 }
 
+/* Timing mode for bench.py's cpu_baseline leg only: dot products with AVX-512-BF16 vdpbf16ps straight on the bf16
+ * operands (pairs summed before accumulation, so results differ from the checker mode in the last bits).  The
+ * parity tests always run with fast = 0; tests/test_oracle_golden.py bounds the difference between the modes. */
+static int g_fast = 0;
+void lia_oracle_set_fast(int on) { g_fast = on; }
+int lia_oracle_fast_available(void) {
+#if defined(__AVX512BF16__)
+  return __builtin_cpu_supports("avx512bf16") ? 1 : 0;
+#else
+  return 0;
+#endif
+}
+
+#if defined(__AVX512BF16__)
+static void linear_fast(const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* residual, bf16_t* y, long M, int N,
+                        int K, int relu, int split_bias) {
+  const long MP = 256;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+  for (long mp = 0; mp < M; mp += MP)
+    for (int n0 = 0; n0 < N; n0 += 4) {
+      const int nr = N - n0 < 4 ? N - n0 : 4;
+      const long mend = mp + MP < M ? mp + MP : M;
+      for (long m0 = mp; m0 < mend; m0 += 4) {
+        const int mr = mend - m0 < 4 ? (int)(mend - m0) : 4;
+        __m512 acc[4][4];
+        for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < 4; ++j) acc[i][j] = _mm512_setzero_ps();
+        if (mr == 4 && nr == 4) {
+          const bf16_t* xr = x + m0 * (long)K;
+          const bf16_t* wr = w + (long)n0 * K;
+          for (int k = 0; k < K; k += 32) {
+#pragma GCC unroll 4
+            for (int i = 0; i < 4; ++i)
+#pragma GCC unroll 4
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = _mm512_dpbf16_ps(acc[i][j], (__m512bh)_mm512_loadu_si512(xr + i * (long)K + k),
+                                             (__m512bh)_mm512_loadu_si512(wr + j * (long)K + k));
+          }
+        } else {
+          for (int k = 0; k < K; k += 32)
+            for (int i = 0; i < mr; ++i)
+              for (int j = 0; j < nr; ++j)
+                acc[i][j] = _mm512_dpbf16_ps(acc[i][j], (__m512bh)_mm512_loadu_si512(x + (m0 + i) * (long)K + k),
+                                             (__m512bh)_mm512_loadu_si512(w + (long)(n0 + j) * K + k));
+        }
+        for (int i = 0; i < mr; ++i)
+          for (int j = 0; j < nr; ++j) {
+            float t = _mm512_reduce_add_ps(acc[i][j]);
+            float bv = bias ? bf2f(bias[n0 + j]) : 0.f;
+            if (split_bias) {
+              t = rbf(t);
+              if (bias) t = rbf(t + bv);
+            } else {
+              t = rbf(t + bv);
+            }
+            if (relu && t < 0.f) t = 0.f;
+            if (residual) t = rbf(bf2f(residual[(m0 + i) * N + n0 + j]) + t);
+            y[(m0 + i) * N + n0 + j] = f2bf(t);
+          }
+      }
+    }
+}
+#endif
+
 /* y[M,N] = epilogue( x[M,K] @ w[N,K]^T ), row-major weights.
  *
  * split_bias = 1: the GPU sub-layer semantics, decoder.py:79-105 / attentions.py:393-394,418 --
@@ -128,6 +192,12 @@ static void dot_block(const float* xf, long ldx, const float* wf, long ldw, int 
  * bias / residual may be NULL. */
 void lia_oracle_linear(const bf16_t* x, const bf16_t* w, const bf16_t* bias, const bf16_t* residual, bf16_t* y,
                        long M, int N, int K, int relu, int split_bias) {
+#if defined(__AVX512BF16__)
+  if (g_fast && (K % 32) == 0 && lia_oracle_fast_available()) {
+    linear_fast(x, w, bias, residual, y, M, N, K, relu, split_bias);
+    return;
+  }
+#endif
   float* xf = (float*)malloc((size_t)M * K * sizeof(float));
 #pragma omp parallel for schedule(static)
   for (long i = 0; i < M * (long)K; ++i) xf[i] = bf2f(x[i]);

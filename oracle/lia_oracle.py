@@ -43,6 +43,9 @@ def lib():
         L.lia_oracle_layer_forward.argtypes = [i, vp, vp, vp, vp, vp, i, i, i, i, i, i, f]
         L.lia_oracle_embed.argtypes = [vp, vp, vp, vp, i, i, i, i]
         L.lia_oracle_lm_head.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f]
+        L.lia_oracle_set_fast.argtypes = [i]
+        L.lia_oracle_set_fast.restype = None
+        L.lia_oracle_fast_available.restype = i
         L.lia_oracle_num_threads.restype = i
         L.lia_oracle_set_threads.argtypes = [i]
         for fn in ("layernorm", "linear", "kv_store", "attn_gpu", "attn_cpu", "layer_forward", "embed", "lm_head",

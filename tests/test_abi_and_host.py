@@ -227,3 +227,30 @@ def test_host_layer_forward_matches_oracle_policy1(native, oracle, B, T, pos0):
     bad = (ctypes.c_void_p * 16)(*[None] * 16)
     assert L.lia_host_layer_forward(ctypes.byref(desc), ctypes.byref(bad), x.ctypes.data, y.ctypes.data, kc.ctypes.data, vc.ctypes.data,
                                     smax, B, B, T, pos0, 0, 1) == native.LIA_ERR_MISSING
+
+
+def test_numa_alloc_tensor_wrappers(native):
+    """numa_alloc_tensor / numa_free_tensor keep the reference's contract (lia/cxl/numa_alloc.py:28-55)."""
+    import torch
+    from lia_amd.cxl import numa_alloc
+    if not native.lib().lia_numa_available():
+        pytest.skip("no NUMA support on this host")
+    numa_alloc.set_cxl_nodes([0])
+    t = numa_alloc.numa_alloc_tensor((4, 8, 16), torch.bfloat16)
+    assert t is not None and t.shape == (4, 8, 16) and t.dtype == torch.bfloat16
+    t.fill_(1.5)
+    assert float(t.float().sum()) == 1.5 * 4 * 8 * 16
+    numa_alloc.numa_free_tensor(t)
+    with pytest.raises(ValueError):
+        numa_alloc.set_cxl_nodes([999])
+
+
+def test_host_allocation_guard(monkeypatch):
+    """An allocation plan beyond the container's memory budget is refused up front (MemoryError), not attempted."""
+    from lia_amd import hostinfo
+    b = hostinfo.host_memory_budget()
+    assert b is None or b > 0
+    monkeypatch.setattr(hostinfo, "host_memory_budget", lambda: 100 << 30)
+    hostinfo.check_host_allocation(50 << 30, "fits")
+    with pytest.raises(MemoryError):
+        hostinfo.check_host_allocation(90 << 30, "opt-175b streamed layers")

@@ -110,3 +110,22 @@ def test_generate_ids_match_hf(oracle, name, policies):
     if pp != 1:
         # first-step logits vs HF bf16 eager (different attention rounding points: HF keeps fp32 softmax)
         close(logits[0], z["logits0_bf16"], atol=0.06, rtol=0.02)
+
+
+def test_fast_timing_mode_stays_close_to_checker_mode(oracle):
+    """bench.py times the oracle with vdpbf16ps inner loops (lia_oracle_set_fast); the checker mode used by every
+    parity test is the fp32-FMA one.  The two may differ only by rounding."""
+    L = oracle.lib()
+    if not L.lia_oracle_fast_available():
+        pytest.skip("host has no AVX-512-BF16")
+    W = synth.make_layer(21, 256, 1024, 0.08)
+    x = synth.make_hidden(22, 3, 9, 256)
+    kc = np.zeros((12, 3, 4, 64), np.uint16)
+    vc = np.zeros_like(kc)
+    ref = oracle.layer_forward(1, W, x, kc.copy(), vc.copy(), 0, 4)
+    L.lia_oracle_set_fast(1)
+    try:
+        got = oracle.layer_forward(1, W, x, kc.copy(), vc.copy(), 0, 4)
+    finally:
+        L.lia_oracle_set_fast(0)
+    close(got, ref, atol=0.07, rtol=0.016, frac_exact=0.9)
