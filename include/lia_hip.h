@@ -135,6 +135,24 @@ int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const
                 const lia_bf16* emb, int vocab, float eps, int suppress_token, lia_bf16* logits, int64_t* next_ids,
                 void* stream);
 
+/* ---- Llama-family layer (BASELINE.json config 4; build-defined: the reference's LlamaDecoderLayer_forward,
+ * decoder.py:121-169, has no policy plumbing -- SURVEY.md quirk 3).  Arithmetic = HF transformers' eager bf16 Llama.
+ * weights[9]: 0 input_norm.w  1 q.w [h*d,H]  2 k.w [kvh*d,H]  3 v.w  4 o.w [H,h*d]  5 post_norm.w  6 gate.w [F,H]
+ * 7 up.w [F,H]  8 down.w [H,F]; k|v and gate|up adjacent in the packed layout.  KV cache on the device, seq-major
+ * [smax][batch][kv_heads][head_dim], post-RoPE keys.  cos/sin: [max_pos][head_dim] bf16 tables. */
+typedef struct {
+  int hidden, heads, kv_heads, ffn;
+  float rms_eps;
+} lia_llama_desc;
+int lia_llama_pack_offsets(const lia_llama_desc* d, size_t offsets[9], size_t* total_bytes);
+size_t lia_llama_workspace_bytes(const lia_llama_desc* d, int max_rows);
+int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x, lia_bf16* y,
+                            lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int T, int pos0, int b0,
+                            void* stream);
+int lia_llama_embed(const int64_t* ids, const lia_bf16* tok, lia_bf16* y, int B, int T, int H, void* stream);
+int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* normw, const lia_bf16* lm,
+                      int vocab, float eps, int suppress_token, lia_bf16* logits, int64_t* next_ids, void* stream);
+
 /* ---- host side of the cooperative policies -------------------------------------------------------
  * Indirect-access-KV masked MHA, csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp:513-842: fp32
  * scores / softmax / weighted sum over a host cache, new K/V rows written in place.  q,k,v: [B,T,h*d]

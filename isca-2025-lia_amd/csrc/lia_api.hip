@@ -22,9 +22,11 @@ extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf
 extern "C" void lia_argmax_launch(const bf16_t* logits, int64_t* out, int B, int vocab, int suppress, hipStream_t st);
 extern "C" void lia_blit_launch(void* dst, const void* src, size_t bytes, hipStream_t st);
 extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
-                                       int B, int T, int heads, int d, int Bc, int b0, hipStream_t st);
+                                       int B, int T, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
+                                       hipStream_t st);
 extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
-                                      int B, int S, int heads, int d, int Bc, int b0, hipStream_t st);
+                                      int B, int S, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
+                                      hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -343,10 +345,10 @@ extern "C" int lia_attention(const lia_bf16* q, long ldq, const lia_bf16* kcache
   }
   int rc;
   if (T == 1) {
-    rc = lia_attn_decode_launch(q, ldq, kcache, vcache, out, ldo, B, S, heads, head_dim, cache_batch, b0, (hipStream_t)stream);
+    rc = lia_attn_decode_launch(q, ldq, kcache, vcache, out, ldo, B, S, heads, heads, head_dim, cache_batch, b0, 0, (hipStream_t)stream);
   } else {
     if (S != T) { lia_set_error("lia_attention: multi-token blocks only as a prefill (S == T), got S=%d T=%d", S, T); return LIA_ERR_INVALID; }
-    rc = lia_attn_prefill_launch(q, ldq, kcache, vcache, out, ldo, B, T, heads, head_dim, cache_batch, b0, (hipStream_t)stream);
+    rc = lia_attn_prefill_launch(q, ldq, kcache, vcache, out, ldo, B, T, heads, heads, head_dim, cache_batch, b0, 0, (hipStream_t)stream);
   }
   if (rc) { lia_set_error("lia_attention: head_dim %d unsupported (32/64/128) or S=%d too long", head_dim, S); return LIA_ERR_INVALID; }
   HIP_TRY(hipGetLastError());
@@ -507,8 +509,8 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
     lia_blit_launch(ao, ha, one, st);
   } else {
     // GPU attention (attentions.py:443-536)
-    int arc = T == 1 ? lia_attn_decode_launch(qb, H, kdst, vdst, ao, H, B, (int)S, d->heads, hd, dst_batch, dst_b0, st)
-                     : lia_attn_prefill_launch(qb, H, kdst, vdst, ao, H, B, T, d->heads, hd, dst_batch, dst_b0, st);
+    int arc = T == 1 ? lia_attn_decode_launch(qb, H, kdst, vdst, ao, H, B, (int)S, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st)
+                     : lia_attn_prefill_launch(qb, H, kdst, vdst, ao, H, B, T, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st);
     if (arc) { lia_set_error("attention: unsupported head_dim %d / S %zu", hd, S); return LIA_ERR_INVALID; }
     if (policy == 0) {
       // deliver rows [pos0, pos0+T) of batch rows [b0, b0+B) to the host cache
@@ -548,6 +550,178 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
     rc = gemm_checked(ctx, f1, F, W[14], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st);
     if (rc) return rc;
   }
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Llama-family layer (config 4, build-defined): RMSNorm, RoPE, grouped-query attention, SiLU-gated MLP
+// ------------------------------------------------------------------------------------------------
+extern "C" void lia_rmsnorm_launch(const bf16_t* x, long ldx, const bf16_t* w, bf16_t* y, long ldy, long rows, int H, float eps,
+                                   hipStream_t st);
+extern "C" void lia_rope_launch(bf16_t* x, long row_stride, const bf16_t* cosb, const bf16_t* sinb, long rows, int heads, int d,
+                                int pos0, int pos_mod, int pos_div, hipStream_t st);
+extern "C" void lia_silu_mul_launch(const bf16_t* gu, bf16_t* out, long M, int F, hipStream_t st);
+extern "C" void lia_embed_tokens_launch(const int64_t* ids, const bf16_t* tok, bf16_t* y, long rows, int H, hipStream_t st);
+
+static int check_llama_desc(const lia_llama_desc* d) {
+  if (!d) return LIA_ERR_INVALID;
+  if (d->hidden <= 0 || d->heads <= 0 || d->kv_heads <= 0 || d->ffn <= 0 || d->hidden % d->heads || d->heads % d->kv_heads) {
+    lia_set_error("llama desc: hidden=%d heads=%d kv_heads=%d ffn=%d", d->hidden, d->heads, d->kv_heads, d->ffn);
+    return LIA_ERR_INVALID;
+  }
+  int hd = d->hidden / d->heads;
+  if (!(hd == 32 || hd == 64 || hd == 128) || d->hidden % 128 || d->ffn % 128 || (d->kv_heads * hd) % 16) {
+    lia_set_error("llama desc: head_dim %d must be 32/64/128, hidden and ffn multiples of 128", hd);
+    return LIA_ERR_INVALID;
+  }
+  return LIA_OK;
+}
+
+extern "C" int lia_llama_pack_offsets(const lia_llama_desc* d, size_t off[9], size_t* total) {
+  int rc = check_llama_desc(d);
+  if (rc) return rc;
+  const size_t H = d->hidden, F = d->ffn, KD = (size_t)d->kv_heads * (H / d->heads);
+  size_t p = 0;
+  auto put = [&](int idx, size_t elems, bool align) { if (align) p = align_up(p, 256); off[idx] = p; p += elems * 2; };
+  put(1, H * H, true);                            // q
+  put(2, KD * H, true); put(3, KD * H, false);    // k | v adjacent: one [2*KD, H] GEMM
+  put(4, H * H, true);                            // o
+  put(6, F * H, true); put(7, F * H, false);      // gate | up adjacent: one [2F, H] GEMM
+  put(8, H * F, true);                            // down
+  put(0, H, true); put(5, H, true);               // the two RMSNorm weights
+  if (total) *total = align_up(p, 256);
+  return LIA_OK;
+}
+
+struct LlamaWs { size_t ln, q, attn, h1, gu, act, gemm, gemm_bytes, total; };
+static LlamaWs llama_ws(const lia_llama_desc* d, long rows) {
+  LlamaWs w;
+  const size_t H = d->hidden, F = d->ffn, R = (size_t)rows;
+  size_t p = 0;
+  auto take = [&](size_t bytes) { size_t o = p; p = align_up(p + bytes, 256); return o; };
+  w.ln = take(R * H * 2); w.q = take(R * H * 2); w.attn = take(R * H * 2); w.h1 = take(R * H * 2);
+  w.gu = take(R * 2 * F * 2); w.act = take(R * F * 2);
+  w.gemm_bytes = rows <= 256 ? (size_t)8 * R * 2 * F * 4 : 0;
+  w.gemm = take(w.gemm_bytes);
+  w.total = p;
+  return w;
+}
+
+extern "C" size_t lia_llama_workspace_bytes(const lia_llama_desc* d, int max_rows) {
+  if (check_llama_desc(d) || max_rows <= 0) return 0;
+  return llama_ws(d, max_rows).total;
+}
+
+extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x,
+                                       lia_bf16* y, lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int T,
+                                       int pos0, int b0, void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  int rc = check_llama_desc(d);
+  if (rc) return rc;
+  if (!weights || !x || !y || !kv || !kv->k || !kv->v || !cos_table || !sin_table) { lia_set_error("lia_llama_layer_forward: NULL tensor"); return LIA_ERR_MISSING; }
+  for (int i = 0; i < 9; ++i)
+    if (!weights[i]) { lia_set_error("lia_llama_layer_forward: weights[%d] is NULL", i); return LIA_ERR_MISSING; }
+  if (!kv->on_device) { lia_set_error("lia_llama_layer_forward: the KV cache must live on the device"); return LIA_ERR_INVALID; }
+  if (B <= 0 || T <= 0 || pos0 < 0 || b0 < 0 || b0 + B > kv->batch || pos0 + T > kv->smax || (T > 1 && pos0 != 0)) {
+    lia_set_error("lia_llama_layer_forward: B=%d T=%d pos0=%d b0=%d vs cache batch=%d smax=%d", B, T, pos0, b0, kv->batch, kv->smax);
+    return LIA_ERR_INVALID;
+  }
+  const int H = d->hidden, F = d->ffn, hd = H / d->heads, KD = d->kv_heads * hd;
+  const long M = (long)B * T;
+  const LlamaWs w = llama_ws(d, M);
+  if (w.total > ctx->ws_bytes) { lia_set_error("lia_llama_layer_forward: workspace %zu < %zu", ctx->ws_bytes, w.total); return LIA_ERR_MEMORY; }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = ctx->ws;
+  bf16_t *ln = (bf16_t*)(ws + w.ln), *qb = (bf16_t*)(ws + w.q), *ao = (bf16_t*)(ws + w.attn), *h1 = (bf16_t*)(ws + w.h1);
+  bf16_t *gu = (bf16_t*)(ws + w.gu), *act = (bf16_t*)(ws + w.act);
+  float* gws = (float*)(ws + w.gemm);
+  const bf16_t* const* W = (const bf16_t* const*)weights;
+  const LiaEpilogue none{nullptr, nullptr, 0, 0};
+
+  lia_rmsnorm_launch(x, H, W[0], ln, H, M, H, d->rms_eps, st);
+  {  // q projection
+    LiaOutMap om = plain_out(qb, H, H);
+    rc = gemm_checked(ctx, ln, H, W[1], (int)M, H, H, none, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  }
+  const bool fused_kv = W[3] == W[2] + (size_t)KD * H;
+  for (int part = 0; part < (fused_kv ? 1 : 2); ++part) {  // k | v projection, rows scattered into the seq-major cache
+    LiaOutMap om;
+    memset(&om, 0, sizeof(om));
+    if (fused_kv) { om.base[0] = kv->k; om.base[1] = kv->v; om.cache_mode[0] = om.cache_mode[1] = 1; om.ld[0] = om.ld[1] = KD; }
+    else { om.base[0] = part == 0 ? kv->k : kv->v; om.cache_mode[0] = 1; om.ld[0] = KD; }
+    om.seg_n = KD; om.T = T; om.Bc = kv->batch; om.b0 = b0; om.pos0 = pos0;
+    rc = gemm_checked(ctx, ln, H, fused_kv ? W[2] : W[2 + part], (int)M, fused_kv ? 2 * KD : KD, H, none, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  }
+  // RoPE on q (token rows b*T+t) and on the K rows just written (cache rows t*Bc + b); HF caches post-RoPE keys
+  lia_rope_launch(qb, H, cos_table, sin_table, M, d->heads, hd, pos0, T, 0, st);
+  if (b0 == 0 && B == kv->batch) {
+    lia_rope_launch(kv->k + (size_t)pos0 * kv->batch * KD, KD, cos_table, sin_table, (long)T * B, d->kv_heads, hd, pos0, 0, kv->batch, st);
+  } else {
+    for (int t = 0; t < T; ++t)  // minibatch slice of the cache rows: one launch per position
+      lia_rope_launch(kv->k + ((size_t)(pos0 + t) * kv->batch + b0) * KD, KD, cos_table, sin_table, B, d->kv_heads, hd, pos0 + t, 0,
+                      kv->batch + B, st);
+  }
+  int arc = T == 1 ? lia_attn_decode_launch(qb, H, kv->k, kv->v, ao, H, B, pos0 + 1, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st)
+                   : lia_attn_prefill_launch(qb, H, kv->k, kv->v, ao, H, B, T, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st);
+  if (arc) { lia_set_error("llama attention: unsupported head_dim %d / S %d", hd, pos0 + T); return LIA_ERR_INVALID; }
+  {  // o_proj + residual
+    LiaEpilogue ep{nullptr, x, H, 0};
+    LiaOutMap om = plain_out(h1, H, H);
+    rc = gemm_checked(ctx, ao, H, W[4], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  }
+  lia_rmsnorm_launch(h1, H, W[5], ln, H, M, H, d->rms_eps, st);
+  const bool fused_gu = W[7] == W[6] + (size_t)F * H;
+  if (fused_gu) {
+    LiaOutMap om = plain_out(gu, 2 * F, 2 * F);
+    rc = gemm_checked(ctx, ln, H, W[6], (int)M, 2 * F, H, none, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  } else {
+    for (int part = 0; part < 2; ++part) {
+      LiaOutMap om = plain_out(gu + (size_t)part * F, 2 * F, F);
+      rc = gemm_checked(ctx, ln, H, W[6 + part], (int)M, F, H, none, om, gws, w.gemm_bytes, 0, st);
+      if (rc) return rc;
+    }
+  }
+  lia_silu_mul_launch(gu, act, M, F, st);
+  {  // down_proj + residual
+    LiaEpilogue ep{nullptr, h1, H, 0};
+    LiaOutMap om = plain_out(y, H, H);
+    rc = gemm_checked(ctx, act, F, W[8], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+extern "C" int lia_llama_embed(const int64_t* ids, const lia_bf16* tok, lia_bf16* y, int B, int T, int H, void* stream) {
+  if (!ids || !tok || !y) return LIA_ERR_MISSING;
+  if (B <= 0 || T <= 0 || H % 8) return LIA_ERR_INVALID;
+  lia_embed_tokens_launch(ids, tok, y, (long)B * T, H, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* normw,
+                                 const lia_bf16* lm, int vocab, float eps, int suppress_token, lia_bf16* logits, int64_t* next_ids,
+                                 void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  if (!hidden || !normw || !lm || !logits || !next_ids) { lia_set_error("lia_llama_lm_head: NULL tensor"); return LIA_ERR_MISSING; }
+  if (B <= 0 || B > 256 || T <= 0 || vocab % 16) { lia_set_error("lia_llama_lm_head: B=%d T=%d vocab=%d", B, T, vocab); return LIA_ERR_INVALID; }
+  size_t scratch = align_up((size_t)B * H * 2, 256);
+  if (ctx->ws_bytes < scratch) { lia_set_error("lia_llama_lm_head: workspace too small"); return LIA_ERR_MEMORY; }
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* lno = (bf16_t*)ctx->ws;
+  lia_rmsnorm_launch(hidden + (long)(T - 1) * H, (long)T * H, normw, lno, H, B, H, eps, st);
+  LiaEpilogue ep{nullptr, nullptr, 0, 0};
+  LiaOutMap om = plain_out(logits, vocab, vocab);
+  size_t have = ctx->ws_bytes - scratch;
+  int rc = gemm_checked(ctx, lno, H, lm, B, vocab, H, ep, om, (float*)(ctx->ws + scratch), std::min(have, (size_t)8 * B * vocab * 4), 0, st);
+  if (rc) return rc;
+  lia_argmax_launch(logits, next_ids, B, vocab, suppress_token, st);
   HIP_TRY(hipGetLastError());
   return LIA_OK;
 }

@@ -28,7 +28,8 @@ template <int D>
 __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __restrict__ q, long ldq,
                                                                 const bf16_t* __restrict__ kc,
                                                                 const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
-                                                                long ldo, int T, int heads, int Bc, int b0, float scaling) {
+                                                                long ldo, int T, int heads, int kv_heads, int Bc, int b0,
+                                                                float scaling, int post_scale) {
   constexpr int CH = D / 8;              // 16-byte chunks per K row
   constexpr int RPB = 16 / CH;           // K rows per 256-byte LDS bank row
   constexpr int KSTEPS = D / 16;         // MFMA k-steps over d for S^T
@@ -42,10 +43,14 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
   const int hh = blockIdx.y, b = blockIdx.z;
   const int q_wg = blockIdx.x * 128;
   const int q_wave = q_wg + wave * 32;
-  const long hd = (long)heads * D;
-  const long kv_row = (long)Bc * hd;  // elements between consecutive sequence positions
-  const bf16_t* kbase = kc + ((long)(b0 + b) * heads + hh) * D;
-  const bf16_t* vbase = vc + ((long)(b0 + b) * heads + hh) * D;
+  // grouped-query attention (Llama family): query head hh reads K/V head hh / (heads / kv_heads); OPT: kv_heads == heads
+  const int kh = hh / (heads / kv_heads);
+  const long kv_row = (long)Bc * kv_heads * D;  // elements between consecutive sequence positions
+  const bf16_t* kbase = kc + ((long)(b0 + b) * kv_heads + kh) * D;
+  const bf16_t* vbase = vc + ((long)(b0 + b) * kv_heads + kh) * D;
+  // OPT rounds q * d^-0.5 before the product (attentions.py:456); HF Llama rounds the product, then scales it
+  // (eager_attention_forward: matmul(q, k^T) * scaling)
+  const float qscale = post_scale ? 1.0f : scaling;
 
   // Qs fragments: B operand, lane holds Qs[q_wave + r][16 s + 8 h + j]
   bf16x8 qf[KSTEPS];
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
       uint32_t o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf2f(w[j] & 0xffff) * scaling, bf2f(w[j] >> 16) * scaling);
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf2f(w[j] & 0xffff) * qscale, bf2f(w[j] >> 16) * qscale);
       qf[s] = __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
     }
   }
@@ -110,7 +115,9 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      sacc[i] = (key <= my_q && key < T) ? rbf(sacc[i]) : -INFINITY;
+      float sv = rbf(sacc[i]);
+      if (post_scale) sv = rbf(sv * scaling);
+      sacc[i] = (key <= my_q && key < T) ? sv : -INFINITY;
     }
   };
 
@@ -194,7 +201,8 @@ template <int D>
 __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __restrict__ q, long ldq,
                                                                const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
-                                                               long ldo, int S, int heads, int Bc, int b0, float scaling) {
+                                                               long ldo, int S, int heads, int kv_heads, int Bc, int b0,
+                                                               float scaling, int post_scale) {
   constexpr int LPK = D / 8;          // lanes per key
   constexpr int KPP = 256 / LPK;      // keys per pass of the workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -202,10 +210,11 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   float* red = (float*)(smem + (((size_t)S * 4 + 15) & ~(size_t)15));  // [KPP][D] partial outputs, [8] scratch after
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = blockIdx.x, b = blockIdx.y;
-  const long hd = (long)heads * D;
-  const long kv_row = (long)Bc * hd;
-  const bf16_t* kbase = kc + ((long)(b0 + b) * heads + hh) * D;
-  const bf16_t* vbase = vc + ((long)(b0 + b) * heads + hh) * D;
+  const int kh = hh / (heads / kv_heads);
+  const long kv_row = (long)Bc * kv_heads * D;
+  const bf16_t* kbase = kc + ((long)(b0 + b) * kv_heads + kh) * D;
+  const bf16_t* vbase = vc + ((long)(b0 + b) * kv_heads + kh) * D;
+  const float qscale = post_scale ? 1.0f : scaling;
   const int sub = tid % LPK, kslot = tid / LPK;
 
   float qs[8];
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
     uint4 v = *(const uint4*)(q + (long)b * ldq + (long)hh * D + 8 * sub);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { qs[2 * j] = rbf(bf2f(w[j] & 0xffff) * scaling); qs[2 * j + 1] = rbf(bf2f(w[j] >> 16) * scaling); }
+    for (int j = 0; j < 4; ++j) { qs[2 * j] = rbf(bf2f(w[j] & 0xffff) * qscale); qs[2 * j + 1] = rbf(bf2f(w[j] >> 16) * qscale); }
   }
   float lmax = -INFINITY;
   for (int j0 = 0; j0 < S; j0 += KPP) {
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
     for (int o = LPK / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     if (j < S) {
       a = rbf(a);
+      if (post_scale) a = rbf(a * scaling);
       if (sub == 0) sc[j] = a;
       lmax = fmaxf(lmax, a);
     }
@@ -268,31 +278,35 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
 }
 
 extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
-                                       int B, int T, int heads, int d, int Bc, int b0, hipStream_t st) {
+                                       int B, int T, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
+                                       hipStream_t st) {
   if (B <= 0 || T <= 0) return 0;
+  if (kv_heads <= 0 || heads % kv_heads) return -1;
   dim3 grid((T + 127) / 128, heads, B);
   const float scaling = 1.0f / sqrtf((float)d);
   switch (d) {
-    case 128: hipLaunchKernelGGL(lia_attn_prefill_kernel<128>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, Bc, b0, scaling); break;
-    case 64: hipLaunchKernelGGL(lia_attn_prefill_kernel<64>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, Bc, b0, scaling); break;
-    case 32: hipLaunchKernelGGL(lia_attn_prefill_kernel<32>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, Bc, b0, scaling); break;
+    case 128: hipLaunchKernelGGL(lia_attn_prefill_kernel<128>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
+    case 64: hipLaunchKernelGGL(lia_attn_prefill_kernel<64>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
+    case 32: hipLaunchKernelGGL(lia_attn_prefill_kernel<32>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
     default: return -1;
   }
   return 0;
 }
 
 extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
-                                      int B, int S, int heads, int d, int Bc, int b0, hipStream_t st) {
+                                      int B, int S, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
+                                      hipStream_t st) {
   if (B <= 0 || S <= 0) return 0;
+  if (kv_heads <= 0 || heads % kv_heads) return -1;
   dim3 grid(heads, B);
   const float scaling = 1.0f / sqrtf((float)d);
   const int kpp = 256 / (d / 8);
   size_t lds = (((size_t)S * 4 + 15) & ~(size_t)15) + (size_t)kpp * d * 4 + 64;
   if (lds > 160 * 1024) return -1;
   switch (d) {
-    case 128: hipLaunchKernelGGL(lia_attn_decode_kernel<128>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, Bc, b0, scaling); break;
-    case 64: hipLaunchKernelGGL(lia_attn_decode_kernel<64>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, Bc, b0, scaling); break;
-    case 32: hipLaunchKernelGGL(lia_attn_decode_kernel<32>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, Bc, b0, scaling); break;
+    case 128: hipLaunchKernelGGL(lia_attn_decode_kernel<128>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); break;
+    case 64: hipLaunchKernelGGL(lia_attn_decode_kernel<64>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); break;
+    case 32: hipLaunchKernelGGL(lia_attn_decode_kernel<32>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); break;
     default: return -1;
   }
   return 0;

@@ -1,0 +1,113 @@
+// Llama-family element-wise kernels (BASELINE.json config 4; a build-defined extension -- the reference has no LIA
+// Llama path, decoder.py:121-169).  Rounding points follow HF transformers' eager bf16 Llama (modeling_llama.py).
+#include "lia_common.h"
+
+// LlamaRMSNorm.forward: y = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) ); one wave per row, 16-byte accesses.
+__global__ __launch_bounds__(256) void lia_rmsnorm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ y, long ldy, long rows, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  const int nv = H >> 3;
+  float ss = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    uint4 v = *(const uint4*)(xr + 8 * i);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float a = bf2f(u[j] & 0xffff), c = bf2f(u[j] >> 16); ss += a * a + c * c; }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)H + eps);
+  bf16_t* yr = y + row * ldy;
+  for (int i = lane; i < nv; i += 64) {
+    uint4 v = *(const uint4*)(xr + 8 * i);
+    uint4 g = *(const uint4*)(w + 8 * i);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w}, gw[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf16x2(bf2f(gw[j] & 0xffff) * rbf(bf2f(u[j] & 0xffff) * rstd), bf2f(gw[j] >> 16) * rbf(bf2f(u[j] >> 16) * rstd));
+    *(uint4*)(yr + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+extern "C" void lia_rmsnorm_launch(const bf16_t* x, long ldx, const bf16_t* w, bf16_t* y, long ldy, long rows, int H, float eps,
+                                   hipStream_t st) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(lia_rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, w, y, ldy, rows, H, eps);
+}
+
+// apply_rotary_pos_emb in place: out = bf16( bf16(x*cos) + bf16(rotate_half(x)*sin) ), cos/sin tables [max_pos][d] bf16.
+// Rows are token rows of `heads` heads each; position of row r = pos0 + (pos_mod ? r % pos_mod : r / pos_div)
+// (q buffer: r = b*T + t -> pos_mod = T; cache slab: r = t*Bc + b -> pos_div = Bc).  One thread per (row, head, pair).
+__global__ __launch_bounds__(256) void lia_rope_kernel(bf16_t* __restrict__ x, long row_stride, const bf16_t* __restrict__ cosb,
+                                                        const bf16_t* __restrict__ sinb, long rows, int heads, int d, int pos0,
+                                                        int pos_mod, int pos_div) {
+  const int half = d >> 1;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = rows * heads * half;
+  if (idx >= total) return;
+  const int i = (int)(idx % half);
+  const long rh = idx / half;
+  const int h = (int)(rh % heads);
+  const long r = rh / heads;
+  const int pos = pos0 + (pos_mod ? (int)(r % pos_mod) : (int)(r / pos_div));
+  bf16_t* p = x + r * row_stride + (long)h * d;
+  const float a = bf2f(p[i]), b = bf2f(p[i + half]);
+  const float c0 = bf2f(cosb[(long)pos * d + i]), c1 = bf2f(cosb[(long)pos * d + i + half]);
+  const float s0 = bf2f(sinb[(long)pos * d + i]), s1 = bf2f(sinb[(long)pos * d + i + half]);
+  p[i] = f2bf(rbf(a * c0) + rbf(-b * s0));
+  p[i + half] = f2bf(rbf(b * c1) + rbf(a * s1));
+}
+
+extern "C" void lia_rope_launch(bf16_t* x, long row_stride, const bf16_t* cosb, const bf16_t* sinb, long rows, int heads, int d,
+                                int pos0, int pos_mod, int pos_div, hipStream_t st) {
+  const long total = rows * heads * (d / 2);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(lia_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, row_stride, cosb, sinb, rows, heads,
+                     d, pos0, pos_mod, pos_div);
+}
+
+// LlamaMLP: act_fn(gate) * up with gate|up side by side in one [M, 2F] buffer: m = bf16( bf16(silu(g)) * u ).
+__global__ __launch_bounds__(256) void lia_silu_mul_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int F) {
+  const long n8 = M * (F >> 3);
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  for (; i < n8; i += stride) {
+    const long m = i / (F >> 3);
+    const int c = (int)(i - m * (F >> 3)) * 8;
+    uint4 g = *(const uint4*)(gu + m * 2 * (long)F + c);
+    uint4 u = *(const uint4*)(gu + m * 2 * (long)F + F + c);
+    const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g0 = bf2f(gw[j] & 0xffff), g1 = bf2f(gw[j] >> 16);
+      float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
+      o[j] = pack_bf16x2(s0 * bf2f(uw[j] & 0xffff), s1 * bf2f(uw[j] >> 16));
+    }
+    *(uint4*)(out + m * (long)F + c) = uint4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+extern "C" void lia_silu_mul_launch(const bf16_t* gu, bf16_t* out, long M, int F, hipStream_t st) {
+  const long n8 = M * (F >> 3);
+  if (n8 <= 0) return;
+  long blocks = (n8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(lia_silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gu, out, M, F);
+}
+
+// token embedding only (Llama has no learned positions): y[row] = embed[ids[row]]
+__global__ __launch_bounds__(256) void lia_embed_tokens_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ tok,
+                                                                bf16_t* __restrict__ y, int H) {
+  const long row = blockIdx.x;
+  const bf16_t* te = tok + ids[row] * (long)H;
+  bf16_t* yo = y + row * (long)H;
+  for (int i = threadIdx.x; i < (H >> 3); i += 256) *(uint4*)(yo + 8 * i) = *(const uint4*)(te + 8 * i);
+}
+
+extern "C" void lia_embed_tokens_launch(const int64_t* ids, const bf16_t* tok, bf16_t* y, long rows, int H, hipStream_t st) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(lia_embed_tokens_kernel, dim3((unsigned)rows), dim3(256), 0, st, ids, tok, y, H);
+}

@@ -29,6 +29,10 @@ class ProfResult(ctypes.Structure):
                 ("tiled_launches", c_long), ("tiled_ms", c_double), ("tiled_bytes", c_double), ("tiled_flops", c_double)]
 
 
+class LlamaDesc(ctypes.Structure):
+    _fields_ = [("hidden", c_int), ("heads", c_int), ("kv_heads", c_int), ("ffn", c_int), ("rms_eps", c_float)]
+
+
 class KV(ctypes.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("smax", c_int), ("batch", c_int), ("on_device", c_int)]
 
@@ -62,6 +66,13 @@ SIGNATURES = {
                             c_int, c_void_p, c_void_p, c_void_p]),
     "lia_host_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int]),
+    "lia_llama_pack_offsets": (c_int, [ctypes.POINTER(LlamaDesc), ctypes.POINTER(c_size_t * 9), ctypes.POINTER(c_size_t)]),
+    "lia_llama_workspace_bytes": (c_size_t, [ctypes.POINTER(LlamaDesc), c_int]),
+    "lia_llama_layer_forward": (c_int, [c_void_p, ctypes.POINTER(LlamaDesc), ctypes.POINTER(c_void_p * 9), c_void_p, c_void_p,
+                                        ctypes.POINTER(KV), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lia_llama_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "lia_llama_lm_head": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p,
+                                  c_void_p, c_void_p]),
     "lia_host_layer_forward": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_void_p * 16), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "lia_host_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_int]),

@@ -25,7 +25,11 @@ LIA_KWARGS = ("prefill_policy", "decoding_policy", "no_overlap", "pin_weight", "
 
 def _scheduler_of(model):
     if getattr(model, "_lia_scheduler", None) is None:
-        model._lia_scheduler = OffloadScheduler(model)
+        if getattr(model, "family", "opt") == "llama":
+            from .llama import LlamaScheduler
+            model._lia_scheduler = LlamaScheduler(model)
+        else:
+            model._lia_scheduler = OffloadScheduler(model)
     return model._lia_scheduler
 
 
@@ -60,7 +64,11 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         raise ValueError(f"prompt {T} + max_new_tokens {max_new_tokens} exceeds max positions {model.shape.max_pos}")
     L = model.shape.layers
     n_gpu = int(L * lia["gpu_percentage"] / 100)
-    kv = KVState(model, n_gpu, B, T + max_new_tokens)   # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278
+    if getattr(model, "family", "opt") == "llama":
+        from .llama import LlamaKVState
+        kv = LlamaKVState(model, B, T + max_new_tokens)
+    else:
+        kv = KVState(model, n_gpu, B, T + max_new_tokens)   # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278
     unfinished = torch.ones(B, dtype=torch.int64)
     latency_list, logits_list = [], []
     cur = ids

@@ -423,3 +423,150 @@ void lia_oracle_lm_head(const bf16_t* hidden, const bf16_t* lnw, const bf16_t* l
   free(last);
   free(lno);
 }
+
+/* =====================================================================================================
+ * Llama-family layer (BASELINE.json config 4; a build-defined extension: the reference's
+ * LlamaDecoderLayer_forward, decoder.py:121-169, takes no policy).  The arithmetic
+ * restated here is stock HF transformers' eager Llama in bf16 (modeling_llama.py: LlamaRMSNorm.forward,
+ * apply_rotary_pos_emb, eager_attention_forward, LlamaMLP.forward), pinned by tests/golden/llama_*.npz.
+ * ===================================================================================================== */
+
+/* LlamaRMSNorm: y = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) ), statistics in fp32 -- two roundings. */
+void lia_oracle_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, long rows, int H, float eps) {
+#pragma omp parallel for schedule(static)
+  for (long r = 0; r < rows; ++r) {
+    const bf16_t* xr = x + r * (long)H;
+    bf16_t* yr = y + r * (long)H;
+    float ss = 0.f;
+    for (int i = 0; i < H; ++i) ss += bf2f(xr[i]) * bf2f(xr[i]);
+    float rstd = 1.0f / sqrtf(ss / (float)H + eps);
+    for (int i = 0; i < H; ++i) yr[i] = f2bf(bf2f(w[i]) * rbf(bf2f(xr[i]) * rstd));
+  }
+}
+
+/* apply_rotary_pos_emb on [rows_b][T][heads][d] in place, positions pos0..pos0+T-1; cos/sin tables [max_pos][d]
+ * in bf16 (emb = cat(freqs, freqs)).  out = bf16( bf16(x*cos) + bf16(rotate_half(x)*sin) ). */
+void lia_oracle_rope(bf16_t* x, const bf16_t* cosb, const bf16_t* sinb, int B, int T, int heads, int d, int pos0) {
+  const int half = d / 2;
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t) {
+      const bf16_t* c = cosb + (long)(pos0 + t) * d;
+      const bf16_t* s = sinb + (long)(pos0 + t) * d;
+      for (int h = 0; h < heads; ++h) {
+        bf16_t* p = x + (((long)b * T + t) * heads + h) * d;
+        float tmp[512];
+        for (int i = 0; i < d; ++i) {
+          float rot = i < half ? -bf2f(p[i + half]) : bf2f(p[i - half]);
+          tmp[i] = rbf(rbf(bf2f(p[i]) * bf2f(c[i])) + rbf(rot * bf2f(s[i])));
+        }
+        for (int i = 0; i < d; ++i) p[i] = f2bf(tmp[i]);
+      }
+    }
+}
+
+/* eager_attention_forward with grouped-query heads: s = bf16( bf16(q.k) * scaling ), causal mask, softmax in fp32
+ * rounded to bf16, o = bf16(P.v).  q [B,T,h,d]; K/V from the seq-major cache [S][B][kvh][d]. */
+void lia_oracle_attn_gqa(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* out, int B, int T, int S, int h, int kvh,
+                         int d, float scaling) {
+  const long qd = (long)h * d, kd = (long)kvh * d;
+  const int grp = h / kvh;
+#pragma omp parallel
+  {
+    float* s = (float*)malloc((size_t)S * sizeof(float));
+    float* o = (float*)malloc((size_t)d * sizeof(float));
+#pragma omp for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+      for (int hh = 0; hh < h; ++hh)
+        for (int t = 0; t < T; ++t) {
+          const bf16_t* qp = q + ((long)b * T + t) * qd + (long)hh * d;
+          const int kh = hh / grp;
+          const int lim = S - T + t;
+          float mx = -INFINITY;
+          for (int j = 0; j <= lim; ++j) {
+            const bf16_t* kp = kc + ((long)j * B + b) * kd + (long)kh * d;
+            float a = 0.f;
+            for (int i = 0; i < d; ++i) a += bf2f(qp[i]) * bf2f(kp[i]);
+            s[j] = rbf(rbf(a) * scaling);
+            if (s[j] > mx) mx = s[j];
+          }
+          float sum = 0.f;
+          for (int j = 0; j <= lim; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+          for (int i = 0; i < d; ++i) o[i] = 0.f;
+          for (int j = 0; j <= lim; ++j) {
+            float p = rbf(s[j] / sum);
+            const bf16_t* vp = vc + ((long)j * B + b) * kd + (long)kh * d;
+            for (int i = 0; i < d; ++i) o[i] += p * bf2f(vp[i]);
+          }
+          bf16_t* op = out + ((long)b * T + t) * qd + (long)hh * d;
+          for (int i = 0; i < d; ++i) op[i] = f2bf(o[i]);
+        }
+    free(s);
+    free(o);
+  }
+}
+
+/* LlamaMLP's act_fn(gate) * up: m = bf16( bf16(silu(g)) * u ), silu in fp32. */
+void lia_oracle_silu_mul(const bf16_t* g, const bf16_t* u, bf16_t* y, long n) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < n; ++i) {
+    float gv = bf2f(g[i]);
+    float s = rbf(gv / (1.0f + expf(-gv)));
+    y[i] = f2bf(s * bf2f(u[i]));
+  }
+}
+
+/* One Llama decoder layer (modeling_llama.py LlamaDecoderLayer.forward).  weights[9]: 0 input_norm.w  1 q.w [h*d,H]
+ * 2 k.w [kvh*d,H]  3 v.w [kvh*d,H]  4 o.w [H,h*d]  5 post_norm.w  6 gate.w [F,H]  7 up.w [F,H]  8 down.w [H,F].
+ * KV cache [Smax][B][kvh][d] (post-RoPE keys, as HF caches them). */
+void lia_oracle_llama_layer_forward(const bf16_t* const* weights, const bf16_t* x, bf16_t* y, bf16_t* kc, bf16_t* vc,
+                                    const bf16_t* cosb, const bf16_t* sinb, int B, int T, int pos0, int H, int heads,
+                                    int kv_heads, int F, float eps) {
+  const int d = H / heads;
+  const long M = (long)B * T;
+  const int KD = kv_heads * d;
+  bf16_t* ln = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* qb = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* kb = (bf16_t*)malloc((size_t)M * KD * 2);
+  bf16_t* vb = (bf16_t*)malloc((size_t)M * KD * 2);
+  bf16_t* ao = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* h1 = (bf16_t*)malloc((size_t)M * H * 2);
+  bf16_t* g = (bf16_t*)malloc((size_t)M * F * 2);
+  bf16_t* u = (bf16_t*)malloc((size_t)M * F * 2);
+  lia_oracle_rmsnorm(x, weights[0], ln, M, H, eps);
+  lia_oracle_linear(ln, weights[1], NULL, NULL, qb, M, H, H, 0, 1);
+  lia_oracle_linear(ln, weights[2], NULL, NULL, kb, M, KD, H, 0, 1);
+  lia_oracle_linear(ln, weights[3], NULL, NULL, vb, M, KD, H, 0, 1);
+  lia_oracle_rope(qb, cosb, sinb, B, T, heads, d, pos0);
+  lia_oracle_rope(kb, cosb, sinb, B, T, kv_heads, d, pos0);
+  lia_oracle_kv_store(kb, kc, B, T, KD, pos0);
+  lia_oracle_kv_store(vb, vc, B, T, KD, pos0);
+  lia_oracle_attn_gqa(qb, kc, vc, ao, B, T, pos0 + T, heads, kv_heads, d, 1.0f / sqrtf((float)d));
+  lia_oracle_linear(ao, weights[4], NULL, x, h1, M, H, H, 0, 1);
+  lia_oracle_rmsnorm(h1, weights[5], ln, M, H, eps);
+  lia_oracle_linear(ln, weights[6], NULL, NULL, g, M, F, H, 0, 1);
+  lia_oracle_linear(ln, weights[7], NULL, NULL, u, M, F, H, 0, 1);
+  lia_oracle_silu_mul(g, u, g, M * (long)F);
+  lia_oracle_linear(g, weights[8], NULL, h1, y, M, H, F, 0, 1);
+  free(ln); free(qb); free(kb); free(vb); free(ao); free(h1); free(g); free(u);
+}
+
+/* final RMSNorm on the last position + untied lm_head + greedy argmax */
+void lia_oracle_llama_lm_head(const bf16_t* hidden, const bf16_t* normw, const bf16_t* lm, bf16_t* logits, int64_t* next, int B,
+                              int T, int H, int vocab, float eps) {
+  bf16_t* last = (bf16_t*)malloc((size_t)B * H * 2);
+  bf16_t* lno = (bf16_t*)malloc((size_t)B * H * 2);
+  for (int b = 0; b < B; ++b) memcpy(last + (long)b * H, hidden + ((long)b * T + T - 1) * H, (size_t)H * 2);
+  lia_oracle_rmsnorm(last, normw, lno, B, H, eps);
+  lia_oracle_linear(lno, lm, NULL, NULL, logits, B, vocab, H, 0, 1);
+  for (int b = 0; b < B; ++b) {
+    int best = 0;
+    float bv = bf2f(logits[(long)b * vocab]);
+    for (int v = 1; v < vocab; ++v) {
+      float f = bf2f(logits[(long)b * vocab + v]);
+      if (f > bv) { bv = f; best = v; }
+    }
+    next[b] = best;
+  }
+  free(last);
+  free(lno);
+}

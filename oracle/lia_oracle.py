@@ -175,3 +175,110 @@ def generate(model, input_ids, max_new_tokens, heads, prefill_policy=1, decoding
     if return_logits:
         return ids, lat, all_logits
     return ids, lat
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Llama family (config 4, build-defined): HF transformers eager Llama in bf16 is what is restated
+# ---------------------------------------------------------------------------------------------------------
+LLAMA_TENSORS = ("in_norm_w", "q_w", "k_w", "v_w", "o_w", "post_norm_w", "gate_w", "up_w", "down_w")
+_llama_bound = False
+
+
+def _llama_lib():
+    global _llama_bound
+    L = lib()
+    if not _llama_bound:
+        vp, i, l, f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+        L.lia_oracle_rmsnorm.argtypes = [vp, vp, vp, l, i, f]
+        L.lia_oracle_rope.argtypes = [vp, vp, vp, i, i, i, i, i]
+        L.lia_oracle_attn_gqa.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, f]
+        L.lia_oracle_silu_mul.argtypes = [vp, vp, vp, l]
+        L.lia_oracle_llama_layer_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f]
+        L.lia_oracle_llama_lm_head.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, f]
+        for n in ("rmsnorm", "rope", "attn_gqa", "silu_mul", "llama_layer_forward", "llama_lm_head"):
+            getattr(L, "lia_oracle_" + n).restype = None
+        _llama_bound = True
+    return L
+
+
+def rope_tables(max_pos, d, theta):
+    """cos/sin [max_pos, d] as bf16 bits, computed like LlamaRotaryEmbedding.forward (fp32, then cast)."""
+    import torch
+    inv_freq = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+    freqs = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    to_bits = lambda t: t.to(torch.bfloat16).contiguous().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    return to_bits(emb.cos()), to_bits(emb.sin())
+
+
+def rmsnorm(x, w, eps=1e-5):
+    x = _c(x)
+    y = np.empty_like(x)
+    _llama_lib().lia_oracle_rmsnorm(_p(x), _p(_c(w)), _p(y), x.size // x.shape[-1], x.shape[-1], eps)
+    return y
+
+
+def rope(x, cosb, sinb, heads, pos0):
+    """x [B,T,heads*d] rotated in a copy."""
+    x = _c(x).copy()
+    B, T, HD = x.shape
+    _llama_lib().lia_oracle_rope(_p(x), _p(_c(cosb)), _p(_c(sinb)), B, T, heads, HD // heads, pos0)
+    return x
+
+
+def attention_gqa(q, kc, vc, S, heads, kv_heads):
+    q = _c(q)
+    B, T, H = q.shape
+    d = H // heads
+    out = np.empty_like(q)
+    _llama_lib().lia_oracle_attn_gqa(_p(q), _p(kc), _p(vc), _p(out), B, T, S, heads, kv_heads, d, float(d) ** -0.5)
+    return out
+
+
+def silu_mul(g, u):
+    g, u = _c(g), _c(u)
+    y = np.empty_like(g)
+    _llama_lib().lia_oracle_silu_mul(_p(g), _p(u), _p(y), g.size)
+    return y
+
+
+def llama_layer_forward(W, x, kc, vc, cosb, sinb, pos0, heads, kv_heads, eps=1e-5):
+    x = _c(x)
+    B, T, H = x.shape
+    F = W["gate_w"].shape[0]
+    ws = [_c(W[n]) for n in LLAMA_TENSORS]
+    arr = (ctypes.c_void_p * 9)(*[w.ctypes.data for w in ws])
+    y = np.empty_like(x)
+    _llama_lib().lia_oracle_llama_layer_forward(arr, _p(x), _p(y), _p(kc), _p(vc), _p(_c(cosb)), _p(_c(sinb)), B, T, pos0, H, heads,
+                                                kv_heads, F, eps)
+    return y
+
+
+def llama_generate(model, input_ids, max_new_tokens, heads, kv_heads, theta, eps=1e-5, return_logits=False):
+    """Greedy loop over a Llama-family model dict (synth.make_llama_model layout)."""
+    ids = np.ascontiguousarray(input_ids, dtype=np.int64)
+    B, T = ids.shape
+    L = len(model["layers"])
+    H = model["embed_tokens"].shape[1]
+    d = H // heads
+    vocab = model["lm_head"].shape[0]
+    Smax = T + max_new_tokens
+    cosb, sinb = rope_tables(Smax, d, theta)
+    kcs = [np.zeros((Smax, B, kv_heads, d), dtype=np.uint16) for _ in range(L)]
+    vcs = [np.zeros((Smax, B, kv_heads, d), dtype=np.uint16) for _ in range(L)]
+    lat, all_logits, past, cur = [], [], 0, ids
+    for step in range(max_new_tokens):
+        tic = time.time()
+        hid = np.ascontiguousarray(model["embed_tokens"][cur])          # no position embedding, no scaling
+        for li, W in enumerate(model["layers"]):
+            hid = llama_layer_forward(W, hid, kcs[li], vcs[li], cosb, sinb, past, heads, kv_heads, eps)
+        logits = np.empty((B, vocab), dtype=np.uint16)
+        nxt = np.empty((B,), dtype=np.int64)
+        _llama_lib().lia_oracle_llama_lm_head(_p(_c(hid)), _p(_c(model["final_norm_w"])), _p(_c(model["lm_head"])), _p(logits), _p(nxt),
+                                              B, hid.shape[1], H, vocab, eps)
+        past += cur.shape[1]
+        ids = np.concatenate([ids, nxt[:, None]], axis=1)
+        cur = nxt[:, None]
+        lat.append(time.time() - tic)
+        all_logits.append(logits)
+    return (ids, lat, all_logits) if return_logits else (ids, lat)

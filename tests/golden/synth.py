@@ -88,3 +88,32 @@ def make_model(seed, vocab, max_pos, H, F, L, w_std=0.02):
         "layers": [make_layer(seed * 1000 + 17 * (i + 1), H, F, w_std) for i in range(L)],
     }
     return m
+
+
+# ---- Llama family (config 4) ------------------------------------------------------------------------------------
+LLAMA_TENSORS = ("in_norm_w", "q_w", "k_w", "v_w", "o_w", "post_norm_w", "gate_w", "up_w", "down_w")
+
+
+def make_llama_layer(seed, H, heads, kv_heads, F, w_std=0.02):
+    d = H // heads
+    rs = np.random.RandomState(seed)
+    shapes = {"in_norm_w": (H,), "q_w": (H, H), "k_w": (kv_heads * d, H), "v_w": (kv_heads * d, H), "o_w": (H, H),
+              "post_norm_w": (H,), "gate_w": (F, H), "up_w": (F, H), "down_w": (H, F)}
+    out = {}
+    for n in LLAMA_TENSORS:
+        if n.endswith("norm_w"):
+            t = 1.0 + 0.1 * rs.standard_normal(shapes[n])
+        else:
+            t = w_std * rs.standard_normal(shapes[n])
+        out[n] = f32_to_bf16_bits(t.astype(np.float32))
+    return out
+
+
+def make_llama_model(seed, vocab, H, heads, kv_heads, F, L, w_std=0.02):
+    rs = np.random.RandomState(seed)
+    return {
+        "embed_tokens": f32_to_bf16_bits((w_std * rs.standard_normal((vocab, H))).astype(np.float32)),
+        "lm_head": f32_to_bf16_bits((w_std * rs.standard_normal((vocab, H))).astype(np.float32)),
+        "final_norm_w": f32_to_bf16_bits((1.0 + 0.1 * rs.standard_normal((H,))).astype(np.float32)),
+        "layers": [make_llama_layer(seed * 1000 + 31 * (i + 1), H, heads, kv_heads, F, w_std) for i in range(L)],
+    }

@@ -1,0 +1,79 @@
+"""-m gpu parity of the Llama-family layer (config 4, build-defined) through the C ABI: against the CPU oracle and the
+HF-eager goldens (tests/golden/llama_*.npz); end-to-end greedy ids bit-exact, resident and streamed weights."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from test_gpu_ops import assert_close, to_bits, to_dev
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LAYER_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "llama_layer_*.npz")))
+
+
+@pytest.mark.parametrize("name", LAYER_CASES)
+def test_llama_layer_forward(oracle, name):
+    import torch
+    from lia_amd import _native as N, ops
+    from lia_amd.llama import LiaLlamaModel, LlamaShape, rope_tables
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    H, heads, kvh, F, B, T, new, seed = [int(v) for v in z["cfg"]]
+    m = synth.make_llama_model(seed, 64, H, heads, kvh, F, 1, float(z["w_std"][0]))
+    shape = LlamaShape("t", H, heads, kvh, F, 1, 64, max_pos=T + new + 4, rope_theta=float(z["theta"][0]))
+    model = LiaLlamaModel.from_numpy(shape, m)
+    model.place(1, True, False)
+    d = H // heads
+    lib = N.lib()
+    ctx = ops.Context(0, max(lib.lia_llama_workspace_bytes(ctypes.byref(model.desc), B * T), 1 << 24))
+    cos, sin = rope_tables(T + new + 4, d, shape.rope_theta)
+    ocos, osin = oracle.rope_tables(T + new + 4, d, shape.rope_theta)
+    assert (to_bits(cos) == ocos).all() and (to_bits(sin) == osin).all()
+    kc = torch.zeros((T + new, B, kvh, d), dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    kv = N.KV(kc.data_ptr(), vc.data_ptr(), T + new, B, 1)
+    w = (ctypes.c_void_p * 9)(*[model.layers[0].device_ptr() + o for o in model.offsets])
+    fin = lambda t: oracle.rmsnorm(to_bits(t), m["final_norm_w"])  # noqa: E731  (goldens include HF's final norm)
+
+    def run(xbits, Tn, pos0):
+        x = to_dev(torch, xbits)
+        y = torch.empty_like(x)
+        N.check(lib.lia_llama_layer_forward(ctx.handle, ctypes.byref(model.desc), ctypes.byref(w), ctypes.c_void_p(x.data_ptr()),
+                                            ctypes.c_void_p(y.data_ptr()), ctypes.byref(kv), ctypes.c_void_p(cos.data_ptr()),
+                                            ctypes.c_void_p(sin.data_ptr()), B, Tn, pos0, 0, ctypes.c_void_p(ctx.stream)))
+        ctx.synchronize()
+        return y
+
+    y = run(synth.make_hidden(seed + 1, B, T, H), T, 0)
+    assert_close(fin(y), z["prefill_hidden"], 0.07, 0.016, 0.75, "llama prefill vs HF")
+    okc, ovc = np.zeros((T + new, B, kvh, d), np.uint16), np.zeros((T + new, B, kvh, d), np.uint16)
+    oy = oracle.llama_layer_forward(m["layers"][0], synth.make_hidden(seed + 1, B, T, H), okc, ovc, ocos, osin, 0, heads, kvh)
+    assert_close(to_bits(y), oy, 0.07, 0.016, 0.75, "llama prefill vs oracle")
+    for s in range(new):
+        ys = run(synth.make_hidden(seed + 100 + s, B, 1, H), 1, T + s)
+        assert_close(fin(ys), z[f"dec{s}_hidden"], 0.07, 0.016, 0.7, f"llama decode {s} vs HF")
+    assert_close(to_bits(kc), z["kcache"], 0.03, 0.008, 0.95, "post-RoPE K cache")
+    assert_close(to_bits(vc), z["vcache"], 0.03, 0.008, 0.95, "V cache")
+    ctx.close()
+    model.close()
+
+
+@pytest.mark.parametrize("gpu_pct,mb", [(100, 1), (34, 1), (0, 2)])
+def test_llama_generate_ids_match_hf(gpu_pct, mb):
+    import torch
+    from lia_amd.generation import generate
+    from lia_amd.llama import LiaLlamaModel, LlamaShape
+    z = np.load(os.path.join(GOLD, "llama_generate_h256.npz"))
+    vocab, H, heads, kvh, F, L, B, T, new, seed = [int(v) for v in z["cfg"]]
+    m = synth.make_llama_model(seed, vocab, H, heads, kvh, F, L, float(z["w_std"][0]))
+    ids = synth.make_prompt_ids(seed + 1, B, T, vocab)
+    shape = LlamaShape("t", H, heads, kvh, F, L, vocab, max_pos=64, rope_theta=float(z["theta"][0]))
+    model = LiaLlamaModel.from_numpy(shape, m)
+    out, lat = generate(model, torch.from_numpy(ids), max_new_tokens=new, min_new_tokens=new, token_latency=True,
+                        gpu_percentage=gpu_pct, num_minibatch=mb, pin_weight=True)
+    assert (out.numpy() == z["ids_bf16"]).all(), (out[0, T:].tolist(), z["ids_bf16"][0, T:].tolist())
+    model._lia_scheduler.close()
+    model.close()
