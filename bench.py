@@ -139,12 +139,17 @@ def main():
     from lia_amd.scheduler import KVState, OffloadScheduler
     from lia_amd import dp
 
-    shape = resolve_shape(a.model)
+    is_llama = "llama" in a.model.lower()
+    if is_llama:
+        from lia_amd.llama import LiaLlamaModel, LlamaKVState, LlamaScheduler, resolve_llama_shape
+        shape = resolve_llama_shape(a.model)
+    else:
+        shape = resolve_shape(a.model)
     B, T = a.batch, a.prompt
     new = 1 + a.warmup + a.steps
     if T + new > shape.max_pos:
         raise SystemExit("prompt + steps exceeds max positions")
-    n_gpu = int(shape.layers * a.gpu_percentage / 100)
+    n_gpu = shape.layers if (is_llama and a.gpu_percentage >= 100) else int(shape.layers * a.gpu_percentage / 100)
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
                  gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=a.enable_cxl, no_overlap=False)
     if a.cxl_nodes:
@@ -155,9 +160,14 @@ def main():
     group = dp.DataParallelGroup(dist, rank, world, local_rank) if dist is not None else None
     if group is not None and world > 1:
         group.pin_host_threads()
-    model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
-                                    host_owner=(group is None or group.is_root))
-    sched = OffloadScheduler(model, device=local_rank, dp_group=group)
+    if is_llama:
+        model = LiaLlamaModel.random_init(shape, seed=0, n_gpu_layers=n_gpu)
+        sched = LlamaScheduler(model, device=local_rank)
+        KVState = lambda mdl, ng, b, s: LlamaKVState(mdl, b, s)  # noqa: E731,F811
+    else:
+        model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
+                                        host_owner=(group is None or group.is_root))
+        sched = OffloadScheduler(model, device=local_rank, dp_group=group)
     from lia_amd import hostinfo
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
     g = torch.Generator().manual_seed(0)
@@ -174,7 +184,8 @@ def main():
     # untimed shake-out: allocations (pinned KV, workspace), page-in, clocks
     kv = KVState(model, n_gpu, B, T + new)
     sched.forward(ids, kv, max_new_tokens=new, **flags)
-    sched.ctx.set_host_threads(host_threads)
+    if not is_llama:
+        sched.ctx.set_host_threads(host_threads)
     cur = ids[:, -1:].clone()
     sched.forward(cur, kv, max_new_tokens=new, **flags)
 
@@ -247,7 +258,7 @@ def main():
                                "h2d_busy_ms": pre_h2d_ms, "h2d_gbs_while_busy": pre_h2d_bytes / max(pre_h2d_ms, 1e-9) / 1e6},
             "build_s": build_s,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not is_llama:
             out["cpu_baseline"] = cpu_baseline(shape, B, T)
     if dist is not None:
         dist.barrier()
