@@ -182,7 +182,8 @@ def main():
         torch.cuda.synchronize()
 
     # untimed shake-out: allocations (pinned KV, workspace), page-in, clocks
-    kv = KVState(model, n_gpu, B, T + new)
+    kv = (KVState(model, n_gpu, B, T + new) if is_llama else
+          KVState(model, n_gpu, B, T + new, all_on_device=(a.prefill_policy == 3 and a.decoding_policy == 3)))
     sched.forward(ids, kv, max_new_tokens=new, **flags)
     if not is_llama:
         sched.ctx.set_host_threads(host_threads)

@@ -68,7 +68,9 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         from .llama import LlamaKVState
         kv = LlamaKVState(model, B, T + max_new_tokens)
     else:
-        kv = KVState(model, n_gpu, B, T + max_new_tokens)   # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278
+        # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278; in HBM for every layer when both policies are 3
+        kv = KVState(model, n_gpu, B, T + max_new_tokens,
+                     all_on_device=(lia["prefill_policy"] == 3 and lia["decoding_policy"] == 3))
     unfinished = torch.ones(B, dtype=torch.int64)
     latency_list, logits_list = [], []
     cur = ids

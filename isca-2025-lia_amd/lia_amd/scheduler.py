@@ -120,9 +120,12 @@ class KVState:
     """Per-layer KV caches of one generation: seq-major [Smax,B,h,d] (attentions.py:462-476), in HBM for
     resident layers and in pinned host memory for streamed ones (lia/modeling_opt.py:1270-1281)."""
 
-    def __init__(self, model, n_gpu, B, smax):
+    def __init__(self, model, n_gpu, B, smax, all_on_device=False):
         sh = model.shape
         self.B, self.smax, self.len = B, smax, 0
+        self.all_on_device = all_on_device
+        if all_on_device:
+            n_gpu = sh.layers          # policy 3 for streamed layers too: every cache lives in HBM
         from . import hostinfo
         hostinfo.check_host_allocation(2 * (sh.layers - n_gpu) * smax * B * sh.hidden * 2, "host KV cache")
         self.tensors, self.kv = [], []
@@ -190,13 +193,16 @@ class OffloadScheduler:
         n_gpu = int(L * gpu_percentage / 100)                      # lia/modeling_opt.py:1182
         is_prefill = T != 1                                        # :1186-1188
         policy = prefill_policy if is_prefill else decoding_policy
-        if n_gpu < L and policy not in (0, 1, 2):
-            raise ValueError(f"unsupported policy {policy} (prefill: 0 or 1; decode: 0, 1 or 2)")
+        if n_gpu < L and policy not in (0, 1, 2, 3):
+            raise ValueError(f"unsupported policy {policy} (prefill: 0, 1 or 3; decode: 0, 1, 2 or 3)")
+        if n_gpu < L and (policy == 3) != bool(kv_state.all_on_device):
+            raise ValueError("policy 3 on streamed layers (KV cache in HBM, SURVEY.md section 8 f-1) must be chosen for BOTH "
+                             "phases: the cache of a generation lives either in HBM or on the host")
         if is_prefill and policy == 2 and n_gpu < L:
             raise ValueError("prefill policy must be 0 on the GPU path (the reference has no prefill-2 branch)")
         if B % num_minibatch:
             raise ValueError(f"batch {B} not divisible by num_minibatch {num_minibatch}")
-        mini = B // num_minibatch if (policy == 0) else B          # :1178 mini_bsz
+        mini = B // num_minibatch if (policy in (0, 3) and is_prefill) or policy == 0 else B   # :1178 mini_bsz
         overlap = not no_overlap
 
         m.place(n_gpu, pin_weight, enable_cxl)                    # move_gpu_layer / pin_memory, idempotent
@@ -240,10 +246,12 @@ class OffloadScheduler:
                     if nxt == idx or not pipe.can_prefetch():
                         break
                     pipe.prefetch(nxt)
-            if policy == 0:
-                for i in range(num_minibatch):                     # FlexGen-style minibatches (:1283-1365)
+            if policy in (0, 3):
+                # FlexGen-style minibatches (:1283-1365).  Policy 3 here = streamed weights with the cache kept in HBM
+                # (build-defined; the reference reserves 3 for resident layers, :1175-1176)
+                for i in range(B // mini):
                     sl = slice(i * mini, (i + 1) * mini)
-                    ctx.layer_forward(m.desc, 0, wptrs, x[sl], y[sl], kv_state.kv[idx], mini, T, pos0, i * mini)
+                    ctx.layer_forward(m.desc, policy, wptrs, x[sl], y[sl], kv_state.kv[idx], mini, T, pos0, i * mini)
             else:
                 ctx.layer_forward(m.desc, 2, wptrs, x, y, kv_state.kv[idx], B, T, pos0, 0)   # :1493-1543
             pipe.release(idx)

@@ -39,6 +39,7 @@ FLAG_SETS = [
     dict(prefill_policy=0, decoding_policy=2, gpu_percentage=99, pin_weight=True),                   # all but one resident
     dict(prefill_policy=0, decoding_policy=2, gpu_percentage=0, pin_weight=False),                   # pageable -> bounce
     dict(prefill_policy=0, decoding_policy=2, gpu_percentage=25, pin_weight=True, no_overlap=True),
+    dict(prefill_policy=3, decoding_policy=3, gpu_percentage=34, pin_weight=True, num_minibatch=2),  # streamed weights, KV in HBM
     dict(),                                                                                          # defaults 1/1: the IPEX baseline
     dict(prefill_policy=0, decoding_policy=1, gpu_percentage=34, pin_weight=True),                   # README online configs (0/1)
     dict(prefill_policy=1, decoding_policy=2, gpu_percentage=0, pin_weight=True),
