@@ -1,0 +1,29 @@
+"""The analytical planner reproduces the r01 measurements it is calibrated on and behaves
+monotonically."""
+from lia_amd import planner
+from lia_amd.model import resolve_shape
+
+BOX = planner.Box(host_threads=16, host_mem_gb=280.0)
+
+
+def test_headline_prediction_close_to_measurement():
+    sh = resolve_shape("opt-30b")
+    pre, dec, hbm, host, n_gpu = planner.estimate(sh, 64, 256, 32, 10, 2, BOX)
+    assert n_gpu == 4
+    assert abs(dec - 955.0) / 955.0 < 0.05          # measured 955 ms/step
+    assert abs(pre - 1050.0) / 1050.0 < 0.10        # measured 1050 ms
+    assert 50 < host < 90 and hbm < 30
+    pre_r, dec_r, *_ = planner.estimate(sh, 64, 256, 32, 100, 3, BOX)
+    assert abs(dec_r - 18.7) / 18.7 < 0.35          # measured 18.7 ms/step fully resident
+    assert abs(pre_r - 858.0) / 858.0 < 0.15
+
+
+def test_monotonic_in_gpu_percentage_and_plan_picks_resident_when_it_fits():
+    sh = resolve_shape("opt-30b")
+    decs = [planner.estimate(sh, 64, 256, 32, p, 2, BOX)[1] for p in (0, 10, 50, 90)]
+    assert decs == sorted(decs, reverse=True)
+    p = planner.plan(sh, 64, 256, 32, BOX)
+    assert p.n_gpu_layers == sh.layers and p.gpu_percentage == 100       # 59 GB fits 288 GB of HBM
+    big = resolve_shape("opt-175b")
+    p2 = planner.plan(big, 32, 256, 32, BOX)
+    assert 0 < p2.n_gpu_layers < big.layers and p2.host_gb <= 0.85 * BOX.host_mem_gb and p2.hbm_gb <= 0.92 * 288
