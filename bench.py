@@ -197,8 +197,11 @@ def main():
     sync()
     t0 = time.time()
     logits, nxt = sched.forward(ids, kv, max_new_tokens=new, **flags)
-    sync()
+    # the reference's first-token latency (greedy_search.py:145,424): wall clock until the iteration's tokens exist.
+    # forward() returns after its compute and K/V-delivery streams drained; a device-wide sync here would also wait
+    # for the weight prefetch of the NEXT step that the streamer has already started.
     prefill_ms = 1e3 * (time.time() - t0)
+    sync()
     prof_prefill = sched.ctx.prof_stop()
     pre_h2d_bytes, pre_h2d_ms = sched.stream_stats()
     cur = nxt.cpu()[:, None]

@@ -193,11 +193,12 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// decode (T == 1): one workgroup per (batch, head); KV-bandwidth bound.  LPK = D/8 lanes share one key
-// row (16 bytes each); scores are parked in LDS, then every thread accumulates its 8 output dims over
-// its share of the keys and the shares are combined through LDS.
+// decode (T == 1): one workgroup per (batch row, KV head); KV-bandwidth bound.  The G = heads / kv_heads query
+// heads that share a KV head (grouped-query attention; G = 1 for OPT) are served together, so every K/V row is
+// read from HBM once.  LPK = D/8 lanes share one key row (16 bytes each); scores are parked in LDS, then every
+// thread accumulates its 8 output dims over its share of the keys and the shares are combined through LDS.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int G>
 __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __restrict__ q, long ldq,
                                                                const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
@@ -206,74 +207,113 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   constexpr int LPK = D / 8;          // lanes per key
   constexpr int KPP = 256 / LPK;      // keys per pass of the workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sc = (float*)smem;                         // [S] scores -> probabilities
-  float* red = (float*)(smem + (((size_t)S * 4 + 15) & ~(size_t)15));  // [KPP][D] partial outputs, [8] scratch after
+  const int Spad = (S + 3) & ~3;
+  float* sc = (float*)smem;                                   // [G][Spad] scores -> probabilities
+  float* red = sc + (size_t)G * Spad;                         // [KPP][G][D] partial outputs
+  float* scratch = red + (size_t)KPP * G * D;                 // [G][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = blockIdx.x, b = blockIdx.y;
-  const int kh = hh / (heads / kv_heads);
+  const int kh = blockIdx.x, b = blockIdx.y;
   const long kv_row = (long)Bc * kv_heads * D;
   const bf16_t* kbase = kc + ((long)(b0 + b) * kv_heads + kh) * D;
   const bf16_t* vbase = vc + ((long)(b0 + b) * kv_heads + kh) * D;
   const float qscale = post_scale ? 1.0f : scaling;
   const int sub = tid % LPK, kslot = tid / LPK;
 
-  float qs[8];
-  {
-    uint4 v = *(const uint4*)(q + (long)b * ldq + (long)hh * D + 8 * sub);
+  float qs[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    uint4 v = *(const uint4*)(q + (long)b * ldq + (long)(kh * G + g) * D + 8 * sub);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { qs[2 * j] = rbf(bf2f(w[j] & 0xffff) * qscale); qs[2 * j + 1] = rbf(bf2f(w[j] >> 16) * qscale); }
+    for (int j = 0; j < 4; ++j) { qs[g][2 * j] = rbf(bf2f(w[j] & 0xffff) * qscale); qs[g][2 * j + 1] = rbf(bf2f(w[j] >> 16) * qscale); }
   }
-  float lmax = -INFINITY;
-  for (int j0 = 0; j0 < S; j0 += KPP) {
-    int j = j0 + kslot;
-    float a = 0.f;
-    if (j < S) {
-      uint4 v = *(const uint4*)(kbase + (long)j * kv_row + 8 * sub);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  float lmax[G];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a += qs[2 * e] * bf2f(w[e] & 0xffff) + qs[2 * e + 1] * bf2f(w[e] >> 16);
+  for (int g = 0; g < G; ++g) lmax[g] = -INFINITY;
+  constexpr int U = 4;   // key rows in flight per thread: KV reads are the whole cost, keep several 16-byte loads outstanding
+  for (int j0 = 0; j0 < S; j0 += U * KPP) {
+    uint4 kv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = min(j0 + u * KPP + kslot, S - 1);
+      kv[u] = *(const uint4*)(kbase + (long)j * kv_row + 8 * sub);
     }
 #pragma unroll
-    for (int o = LPK / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (j < S) {
-      a = rbf(a);
-      if (post_scale) a = rbf(a * scaling);
-      if (sub == 0) sc[j] = a;
-      lmax = fmaxf(lmax, a);
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * KPP + kslot;
+      const uint32_t w[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a += qs[g][2 * e] * bf2f(w[e] & 0xffff) + qs[g][2 * e + 1] * bf2f(w[e] >> 16);
+#pragma unroll
+        for (int o = LPK / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (j < S) {
+          float sv = rbf(a);
+          if (post_scale) sv = rbf(sv * scaling);
+          if (sub == 0) sc[g * Spad + j] = sv;
+          lmax[g] = fmaxf(lmax[g], sv);
+        }
+      }
     }
   }
-  float* scratch = red + KPP * D;
-  lmax = wave_max(lmax);
-  if (lane == 0) scratch[wave] = lmax;
-  __syncthreads();
-  const float m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
-  float ls = 0.f;
-  for (int j = tid; j < S; j += 256) {
-    float e = __expf(sc[j] - m);
-    sc[j] = e;
-    ls += e;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float m = wave_max(lmax[g]);
+    if (lane == 0) scratch[g * 8 + wave] = m;
   }
-  ls = wave_sum(ls);
-  if (lane == 0) scratch[4 + wave] = ls;
   __syncthreads();
-  const float l = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+  float mrow[G], lrow[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    mrow[g] = fmaxf(fmaxf(scratch[g * 8], scratch[g * 8 + 1]), fmaxf(scratch[g * 8 + 2], scratch[g * 8 + 3]));
+    float ls = 0.f;
+    for (int j = tid; j < S; j += 256) {
+      float e = __expf(sc[g * Spad + j] - mrow[g]);
+      sc[g * Spad + j] = e;
+      ls += e;
+    }
+    ls = wave_sum(ls);
+    if (lane == 0) scratch[g * 8 + 4 + wave] = ls;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; ++g) lrow[g] = scratch[g * 8 + 4] + scratch[g * 8 + 5] + scratch[g * 8 + 6] + scratch[g * 8 + 7];
 
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int j = kslot; j < S; j += KPP) {
-    float p = rbf(sc[j] / l);
-    uint4 v = *(const uint4*)(vbase + (long)j * kv_row + 8 * sub);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  float o[G][8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o[2 * e] += p * bf2f(w[e] & 0xffff); o[2 * e + 1] += p * bf2f(w[e] >> 16); }
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+  for (int j0 = kslot; j0 < S; j0 += U * KPP) {
+    uint4 vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) vv[u] = *(const uint4*)(vbase + (long)min(j0 + u * KPP, S - 1) * kv_row + 8 * sub);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * KPP;
+      if (j < S) {
+        const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float p = rbf(sc[g * Spad + j] / lrow[g]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[g][2 * e] += p * bf2f(w[e] & 0xffff); o[g][2 * e + 1] += p * bf2f(w[e] >> 16); }
+        }
+      }
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[kslot * D + 8 * sub + e] = o[e];
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[((size_t)kslot * G + g) * D + 8 * sub + e] = o[g][e];
   __syncthreads();
-  if (tid < D) {
-    float a = 0.f;
-    for (int k = 0; k < KPP; ++k) a += red[k * D + tid];
-    out[(long)b * ldo + (long)hh * D + tid] = f2bf(a);
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, dd = idx - g * D;
+    float acc = 0.f;
+    for (int k = 0; k < KPP; ++k) acc += red[((size_t)k * G + g) * D + dd];
+    out[(long)b * ldo + (long)(kh * G + g) * D + dd] = f2bf(acc);
   }
 }
 
@@ -293,21 +333,42 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
   return 0;
 }
 
+template <int D>
+static int launch_decode(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo, int B, int S, int heads,
+                         int kv_heads, int Bc, int b0, float scaling, int post_scale, hipStream_t st) {
+  const int G = heads / kv_heads;
+  dim3 grid(kv_heads, B);
+  const int kpp = 256 / (D / 8);
+  const int Spad = (S + 3) & ~3;
+  size_t lds = ((size_t)G * Spad + (size_t)kpp * G * D + (size_t)G * 8) * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+#define LIA_DEC(GV)                                                                                                            \
+  {                                                                                                                            \
+    static bool attr = false;                                                                                                  \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)lia_attn_decode_kernel<D, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((lia_attn_decode_kernel<D, GV>), grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); \
+  }
+  switch (G) {
+    case 1: LIA_DEC(1) break;
+    case 2: LIA_DEC(2) break;
+    case 4: LIA_DEC(4) break;
+    case 8: LIA_DEC(8) break;
+    default: return -1;
+  }
+#undef LIA_DEC
+  return 0;
+}
+
 extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
                                       int B, int S, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
                                       hipStream_t st) {
   if (B <= 0 || S <= 0) return 0;
   if (kv_heads <= 0 || heads % kv_heads) return -1;
-  dim3 grid(heads, B);
   const float scaling = 1.0f / sqrtf((float)d);
-  const int kpp = 256 / (d / 8);
-  size_t lds = (((size_t)S * 4 + 15) & ~(size_t)15) + (size_t)kpp * d * 4 + 64;
-  if (lds > 160 * 1024) return -1;
   switch (d) {
-    case 128: hipLaunchKernelGGL(lia_attn_decode_kernel<128>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); break;
-    case 64: hipLaunchKernelGGL(lia_attn_decode_kernel<64>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); break;
-    case 32: hipLaunchKernelGGL(lia_attn_decode_kernel<32>, grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); break;
+    case 128: return launch_decode<128>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, st);
+    case 64: return launch_decode<64>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, st);
+    case 32: return launch_decode<32>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, st);
     default: return -1;
   }
-  return 0;
 }

@@ -156,7 +156,7 @@ class LlamaKVState:
 class LlamaScheduler:
     """forward(ids, kv, gpu_percentage=..., num_minibatch=...) -> (logits, next ids) on the device."""
 
-    def __init__(self, model, device=0, n_slots=2):
+    def __init__(self, model, device=0, n_slots=4):
         self.model, self.device, self.n_slots = model, device, n_slots
         self.ctx = self.pipe = None
         self.hidden, self.resident, self.tables = {}, {}, None

@@ -148,7 +148,7 @@ class OffloadScheduler:
     def __init__(self, model, device=0, n_slots=None, dp_group=None):
         import os
         self.model, self.device, self.dp = model, device, dp_group
-        self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "2"))
+        self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "4"))
         self.ctx = None
         self.ws_rows = 0
         self.pipe = None
