@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
 
   struct Shape { const char* name; int N, K; };
   std::vector<Shape> shapes = {{"qkv", 21504, 7168}, {"out", 7168, 7168}, {"fc1", 28672, 7168}, {"fc2", 7168, 28672}, {"lm_head", 50272, 7168}};
+  if (getenv("KSWEEP")) shapes = {{"k1792", 7168, 1792}, {"k3584", 7168, 3584}, {"k7168", 7168, 7168}, {"k14336", 7168, 14336}, {"k28672", 7168, 28672}, {"dummy", 16, 128}};
   const int NBUF = 4;
   size_t maxw = (size_t)50272 * 7168;
   uint16_t* w[NBUF];
@@ -38,7 +39,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
   for (auto& s : shapes) {
-    LiaEpilogue ep{bias, res, s.N, 0};
+    LiaEpilogue ep{getenv("NOBIAS") ? nullptr : bias, getenv("NORES") ? nullptr : res, s.N, 0};
     LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
     const int iters = M > 256 ? 4 : 12;
     for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K, w[it % NBUF], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, force_split, st, nullptr, nullptr, nullptr);
