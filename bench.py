@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
     ap.add_argument("--cxl-nodes", default=None, help="NUMA nodes of the CXL tier, e.g. 2,3 (default LIA_CXL_NODES or 2,3)")
     ap.add_argument("--init", default="normal", choices=["normal", "uniform01"])
+    ap.add_argument("--stream-format", default=os.environ.get("LIA_STREAM_FORMAT", "pack12"), choices=["raw", "pack12"],
+                    help="wire format of the streamed layers: raw bf16, or the lossless 12-bit pack12 encoding")
     ap.add_argument("--host-threads", type=int, default=0)
     a = ap.parse_args()
 
@@ -165,9 +167,10 @@ def main():
         sched = LlamaScheduler(model, device=local_rank)
         KVState = lambda mdl, ng, b, s: LlamaKVState(mdl, b, s)  # noqa: E731,F811
     else:
+        pack12 = a.stream_format == "pack12" and not a.enable_cxl
         model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
-                                        host_owner=(group is None or group.is_root))
-        sched = OffloadScheduler(model, device=local_rank, dp_group=group)
+                                        host_owner=(group is None or group.is_root), pack12=pack12)
+        sched = OffloadScheduler(model, device=local_rank, dp_group=group, pack12=pack12)
     from lia_amd import hostinfo
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
     g = torch.Generator().manual_seed(0)
@@ -253,7 +256,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "launches": prof["skinny_launches"], "avg_launch_us": 1e3 * sk_ms / sk_n,
                          "algorithmic_bytes_per_launch": prof["skinny_bytes"] / sk_n},
-            "host_link": {"bound": "pcie", "achieved": h2d_bytes / (elapsed * 1e9), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+            "host_link": {"bound": "pcie", "stream_format": a.stream_format if not is_llama else "raw",
+                          "weight_bytes_per_step": float(getattr(model, "streamed_bytes", lambda n: 0)(n_gpu)) if not is_llama else None,
+                          "achieved": h2d_bytes / (elapsed * 1e9), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                           "frac": h2d_bytes / (elapsed * 1e9) / PCIE_PEAK_GBS,
                           "copy_engine_busy_frac": (h2d_ms * 1e-3) / elapsed, "bytes_per_step": h2d_bytes / a.steps},
             "prefill_detail": {"gemm_ms": prof_prefill["tiled_ms"], "gemm_launches": prof_prefill["tiled_launches"],

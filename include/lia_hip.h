@@ -189,6 +189,15 @@ int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t 
 int lia_stream_begin(lia_streamer* s, int slot);
 int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned);
 int lia_stream_mark_ready(lia_streamer* s, int slot);
+/* pack12: a lossless 12-bit wire format for the streamed bf16 layers (sign|mantissa byte + 4-bit exponent code, rare
+ * values as escape records; lia_pack12.hip).  The host keeps / ships the encoded bytes (75 % of the raw layer), a kernel
+ * on the copy stream rebuilds the exact bf16 layer in the slot.  Build-defined: the reference ships raw bf16. */
+size_t lia_pack12_bound(size_t n_values);
+int lia_pack12_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
+int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int pinned);
+int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned);
+int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values);
+void* lia_stream_staging_ptr(lia_streamer* s, int slot);
 int lia_stream_wait(lia_streamer* s, int slot, void* compute_stream);    /* compute waits for the copy  */
 int lia_stream_release(lia_streamer* s, int slot, void* compute_stream); /* slot reusable after this    */
 /* bytes copied and copy-engine busy milliseconds since the last reset (hipEvent timing on the copy stream) */

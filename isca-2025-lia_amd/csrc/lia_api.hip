@@ -729,11 +729,19 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
 // ------------------------------------------------------------------------------------------------
 // weight streamer
 // ------------------------------------------------------------------------------------------------
+extern "C" size_t lia_pack12_bound(size_t n_values);
+extern "C" void lia_pack12_decode_launch(const char* src, bf16_t* dst, size_t n_values, hipStream_t st);
+
 struct lia_streamer {
   lia_ctx* ctx;
   int n_slots;
   size_t slot_bytes;
   char* slots;
+  char* staging;          // per-slot landing area of pack12-encoded layers (lazily allocated)
+  size_t staging_bytes;
+  hipStream_t decode;     // pack12 decode kernels run here, ordered after the slot's copy by an event
+  std::vector<hipEvent_t> landed;
+  std::vector<char> decoded_on_side;
   hipStream_t copy;
   std::vector<hipEvent_t> copied, released, t0, t1;
   std::vector<char> has_release, timing_pending;
@@ -759,7 +767,7 @@ extern "C" int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, l
   *out = nullptr;
   lia_streamer* s = new lia_streamer();
   s->ctx = ctx; s->n_slots = n_slots; s->slot_bytes = align_up(slot_bytes, 256);
-  s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr;
+  s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr; s->staging = nullptr; s->staging_bytes = 0;
   HIP_TRY(hipMalloc((void**)&s->slots, s->slot_bytes * n_slots));
   HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
   s->copied.resize(n_slots); s->released.resize(n_slots); s->t0.resize(n_slots); s->t1.resize(n_slots);
@@ -783,6 +791,12 @@ extern "C" void lia_stream_destroy(lia_streamer* s) {
   }
   if (s->bounce) (void)hipHostFree(s->bounce);
   if (s->slots) (void)hipFree(s->slots);
+  if (s->staging) {
+    (void)hipStreamSynchronize(s->decode);
+    for (hipEvent_t e : s->landed) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(s->decode);
+    (void)hipFree(s->staging);
+  }
   (void)hipStreamDestroy(s->copy);
   delete s;
 }
@@ -824,8 +838,73 @@ extern "C" int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, c
   return LIA_OK;
 }
 
+// pack12 path: the encoded layer lands in the slot's staging area, then a kernel on the copy stream rebuilds the
+// bf16 layer in the slot itself (lia_pack12.hip).  begin -> copy_chunk_packed* -> decode_packed -> mark_ready.
+static int ensure_staging(lia_streamer* s) {
+  if (s->staging) return LIA_OK;
+  s->staging_bytes = lia_pack12_bound(s->slot_bytes / 2);
+  HIP_TRY(hipMalloc((void**)&s->staging, s->staging_bytes * s->n_slots));
+  HIP_TRY(hipStreamCreateWithFlags(&s->decode, hipStreamNonBlocking));
+  s->landed.resize(s->n_slots);
+  s->decoded_on_side.assign(s->n_slots, 0);
+  for (int i = 0; i < s->n_slots; ++i) HIP_TRY(hipEventCreateWithFlags(&s->landed[i], hipEventDisableTiming));
+  return LIA_OK;
+}
+
+extern "C" void* lia_stream_staging_ptr(lia_streamer* s, int slot) {
+  if (!s || slot < 0 || slot >= s->n_slots || ensure_staging(s)) return nullptr;
+  return s->staging + (size_t)slot * s->staging_bytes;
+}
+
+extern "C" int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned) {
+  if (!s || slot < 0 || slot >= s->n_slots || !host_ptr) return LIA_ERR_INVALID;
+  int rc = ensure_staging(s);
+  if (rc) return rc;
+  if (offset + bytes > s->staging_bytes) { lia_set_error("lia_stream_copy_chunk_packed: %zu + %zu > staging %zu", offset, bytes, s->staging_bytes); return LIA_ERR_INVALID; }
+  const void* src = host_ptr;
+  if (!pinned) {
+    if (!s->bounce) HIP_TRY(hipHostMalloc((void**)&s->bounce, s->slot_bytes, hipHostMallocDefault));
+    HIP_TRY(hipStreamSynchronize(s->copy));
+    memcpy(s->bounce, host_ptr, bytes);
+    src = s->bounce;
+  }
+  HIP_TRY(hipMemcpyAsync(s->staging + (size_t)slot * s->staging_bytes + offset, src, bytes, hipMemcpyHostToDevice, s->copy));
+  s->pending_bytes[slot] += bytes;
+  return LIA_OK;
+}
+
+extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values) {
+  if (!s || slot < 0 || slot >= s->n_slots || !s->staging || n_values * 2 > s->slot_bytes || (n_values % 16)) return LIA_ERR_INVALID;
+  // The decode runs on its own stream behind an event, so the copy engine moves on to the next layer at once.
+  // It must not start before the slot's previous consumer released it: begin() made the COPY stream wait for that,
+  // and `landed` is recorded on the copy stream after the copy, so the order is inherited.
+  HIP_TRY(hipEventRecord(s->t1[slot], s->copy));                       // copy-engine busy time ends here
+  HIP_TRY(hipEventRecord(s->landed[slot], s->copy));
+  HIP_TRY(hipStreamWaitEvent(s->decode, s->landed[slot], 0));
+  lia_pack12_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, s->decode);
+  HIP_TRY(hipGetLastError());
+  s->decoded_on_side[slot] = 1;
+  return LIA_OK;
+}
+
+extern "C" int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int pinned) {
+  int rc = lia_stream_begin(s, slot);
+  if (rc) return rc;
+  rc = lia_stream_copy_chunk_packed(s, slot, 0, host_ptr, packed_bytes, pinned);
+  if (rc) return rc;
+  rc = lia_stream_decode_packed(s, slot, n_values);
+  if (rc) return rc;
+  return lia_stream_mark_ready(s, slot);
+}
+
 extern "C" int lia_stream_mark_ready(lia_streamer* s, int slot) {
   if (!s || slot < 0 || slot >= s->n_slots) return LIA_ERR_INVALID;
+  if (s->staging && s->decoded_on_side[slot]) {
+    HIP_TRY(hipEventRecord(s->copied[slot], s->decode));              // ready = decoded
+    s->decoded_on_side[slot] = 0;
+    s->timing_pending[slot] = 1;
+    return LIA_OK;
+  }
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));
   HIP_TRY(hipEventRecord(s->copied[slot], s->copy));
   s->timing_pending[slot] = 1;

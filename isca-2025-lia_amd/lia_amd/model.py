@@ -66,7 +66,9 @@ class LayerStore:
 
     def __init__(self, desc, offsets, total_bytes):
         self.desc, self.offsets, self.nbytes = desc, offsets, total_bytes
-        self.tier = None          # "device" | "pinned" | "cxl" | "pageable"
+        self.tier = None          # "device" | "pinned" | "cxl" | "pageable" | "remote"
+        self.packed = False       # host copy holds the pack12 encoding (lia_pack12.hip) instead of raw bf16
+        self.stream_bytes = total_bytes   # bytes that cross the host link per use
         self._dev = None          # torch uint8 CUDA tensor
         self._np = None           # numpy uint8 (pageable)
         self._ptr = None          # raw host pointer (pinned / cxl)
@@ -117,21 +119,51 @@ class LayerStore:
         """move_gpu_layer (lia/modeling_opt.py:229-268), minus the un-blocking (weights are already row-major)."""
         if self.tier == "device":
             return
+        if self.packed:
+            raise ValueError("a pack12-encoded host layer cannot be promoted to the device tier (re-load the model)")
         dev = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
         N.check(self._lib.lia_memcpy_h2d(dev.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
         self._free()
         self._dev, self.tier = dev, "device"
 
-    def to_pinned(self):
-        """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227)."""
-        if self.tier == "pinned":
+    def _encode_pack12(self):
+        """-> (device uint8 tensor with the pack12 bytes, n bytes) or None when the layer does not fit the format."""
+        if self.tier != "device":
+            tmp = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
+            N.check(self._lib.lia_memcpy_h2d(tmp.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
+            src = tmp
+        else:
+            src = self._dev
+        cap = self._lib.lia_pack12_bound(self.nbytes // 2)
+        enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        out = ctypes.c_size_t()
+        rc = self._lib.lia_pack12_encode(ctypes.c_void_p(src.data_ptr()), self.nbytes // 2, ctypes.c_void_p(enc.data_ptr()), cap,
+                                         ctypes.byref(out))
+        if rc == 1:
+            return None            # too many out-of-window values: ship this layer raw
+        if rc != 0:
+            raise N.LiaHipError(f"lia_pack12_encode failed ({rc})")
+        return enc, out.value
+
+    def to_pinned(self, pack12=False):
+        """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227); with pack12 the pinned copy is
+        the lossless 12-bit encoding (75 % of the bytes)."""
+        if self.tier == "pinned" and self.packed == bool(pack12):
             return
-        ptr = self._lib.lia_host_alloc_pinned(self.nbytes)
+        if self.tier == "pinned" and pack12 != self.packed:
+            raise ValueError("layer is already pinned in the other stream format")
+        enc = self._encode_pack12() if (pack12 and self.nbytes % 32 == 0) else None
+        nbytes = enc[1] if enc else self.nbytes
+        ptr = self._lib.lia_host_alloc_pinned(nbytes)
         if not ptr:
             raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
-        self._fill_host(ptr)
+        if enc:
+            N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
+        else:
+            self._fill_host(ptr)
         self._free()
         self._ptr, self.tier = ptr, "pinned"
+        self.packed, self.stream_bytes = bool(enc), nbytes
 
     def to_cxl(self):
         """realloc_to_numa (lia/modeling_opt.py:168-175) + hipHostRegister so the copy engine can DMA from it
@@ -160,6 +192,7 @@ class LayerStore:
             self._lib.numa_free_node(self._ptr, self.nbytes)
         self._ptr = self._dev = self._np = None
         self.tier = None
+        self.packed, self.stream_bytes = False, self.nbytes
 
     def close(self):
         self._free()
@@ -202,7 +235,7 @@ class LiaOPTModel:
 
     @classmethod
     def random_init(cls, shape, seed=0, init="normal", n_gpu_layers=0, pin_weight=True, enable_cxl=False,
-                    host_owner=True):
+                    host_owner=True, pack12=False):
         """Random-init weights of the exact architecture, generated ON THE GPU one layer at a time and
         moved straight to their tier (an OPT-30B would take minutes to draw on the CPU).
         init="normal": HF _init_weights (lia/modeling_opt.py:895-904): Linear/Embedding ~ N(0, 0.02), zero
@@ -212,7 +245,8 @@ class LiaOPTModel:
         self = cls(shape)
         if host_owner:
             from . import hostinfo
-            hostinfo.check_host_allocation(self.streamed_bytes(n_gpu_layers), f"{shape.name}: {shape.layers - n_gpu_layers} streamed layers")
+            hostinfo.check_host_allocation(int(self.streamed_bytes(n_gpu_layers) * (0.76 if pack12 else 1.0)),
+                                           f"{shape.name}: {shape.layers - n_gpu_layers} streamed layers")
         g = torch.Generator(device="cuda")
         g.manual_seed(seed * 100003)
         H, F = shape.hidden, shape.ffn
@@ -248,7 +282,7 @@ class LiaOPTModel:
                 if enable_cxl:
                     st.to_cxl()
                 elif pin_weight:
-                    st.to_pinned()
+                    st.to_pinned(pack12)
                 else:
                     st.to_pinned()  # leave the device; demoted to pageable below
                     host = np.array(st._host_view(), copy=True)
@@ -259,7 +293,7 @@ class LiaOPTModel:
         return self
 
     # -- placement (first forward) ------------------------------------------------------------------
-    def place(self, n_gpu_layers, pin_weight, enable_cxl):
+    def place(self, n_gpu_layers, pin_weight, enable_cxl, pack12=False):
         """Idempotent tier assignment done on the first forward, as move_gpu_layer / pin_memory are
         (lia/modeling_opt.py:1182-1184, 1214-1217)."""
         key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
@@ -279,7 +313,8 @@ class LiaOPTModel:
             elif enable_cxl and pin_weight:
                 st.to_cxl()
             elif pin_weight:
-                st.to_pinned()
+                if st.tier != "pinned":
+                    st.to_pinned(pack12)
         torch.cuda.synchronize()
         self.placed_for = key
 

@@ -48,6 +48,15 @@ class WeightPipeline:
             from .dp import RawDeviceBuffer
             self.slot_tensors = [RawDeviceBuffer(p, model.layer_bytes).tensor() for p in self.slot_ptrs]
             self.copy_stream = torch.cuda.ExternalStream(self.lib.lia_stream_copy_stream(h))
+            self.staging_tensors = None
+            # the root tells every rank which layers travel pack12-encoded and how many bytes each one ships
+            meta = torch.zeros((len(model.layers), 2), dtype=torch.int64, device="cuda")
+            if dp_group.is_root:
+                for i, st in enumerate(model.layers):
+                    if st.tier not in ("device", None):
+                        meta[i, 0], meta[i, 1] = int(st.packed), int(st.stream_bytes)
+            dp_group.dist.broadcast(meta, src=dp_group.root)
+            self.layer_meta = meta.cpu().tolist()
 
     def can_prefetch(self):
         return len(self.inflight) + len(self.held) < self.n_slots
@@ -60,32 +69,44 @@ class WeightPipeline:
         st = self.model.layers[layer_idx]
         slot = self.next_slot
         self.next_slot = (slot + 1) % self.n_slots
-        if self.dp is None:
+        if self.dp is None and st.packed:
+            N.check(self.lib.lia_stream_prefetch_packed(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.stream_bytes, st.nbytes // 2,
+                                                        int(st.is_dma_able())), "lia_stream_prefetch_packed")
+        elif self.dp is None:
             N.check(self.lib.lia_stream_prefetch(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.nbytes, int(st.is_dma_able())),
                     "lia_stream_prefetch")
         else:
-            self._prefetch_broadcast(st, slot)
+            self._prefetch_broadcast(st, slot, layer_idx)
         self.inflight.append((layer_idx, slot))
 
-    def _prefetch_broadcast(self, st, slot):
+    def _prefetch_broadcast(self, st, slot, layer_idx):
         """Root: host -> slot in chunks, each chunk RCCL-broadcast over xGMI as soon as it is enqueued, so chunk
         k travels to the peers while chunk k+1 is still arriving over PCIe.  Peers: receive into the same slot.
         Everything is ordered on the copy stream; the slot is declared ready after the last broadcast."""
-        from .dp import broadcast_chunked
+        from .dp import RawDeviceBuffer, broadcast_chunked
         dp = self.dp
+        packed, nbytes = self.layer_meta[layer_idx]
         N.check(self.lib.lia_stream_begin(self.handle, slot), "lia_stream_begin")
+        if packed:
+            if self.staging_tensors is None:
+                cap = self.lib.lia_pack12_bound(self.model.layer_bytes // 2)
+                self.staging_tensors = [RawDeviceBuffer(self.lib.lia_stream_staging_ptr(self.handle, s), cap).tensor()
+                                        for s in range(self.n_slots)]
+            target, copy_fn = self.staging_tensors[slot][:nbytes], self.lib.lia_stream_copy_chunk_packed
+        else:
+            target, copy_fn = self.slot_tensors[slot][:self.model.layer_bytes], self.lib.lia_stream_copy_chunk
         before = None
         if dp.is_root:
             base, pinned = st.host_ptr(), int(st.is_dma_able())
 
             def before(off, n):
-                N.check(self.lib.lia_stream_copy_chunk(self.handle, slot, off, ctypes.c_void_p(base + off), n, pinned),
-                        "lia_stream_copy_chunk")
+                N.check(copy_fn(self.handle, slot, off, ctypes.c_void_p(base + off), n, pinned), "lia_stream_copy_chunk")
         with torch.cuda.stream(self.copy_stream):
-            works = broadcast_chunked(dp.dist, self.slot_tensors[slot][:self.model.layer_bytes], dp.root, dp.chunk_bytes,
-                                      before_chunk=before)
+            works = broadcast_chunked(dp.dist, target, dp.root, dp.chunk_bytes, before_chunk=before)
             for w in works:
                 w.wait()              # the copy stream waits for RCCL's stream; the host does not block
+        if packed:
+            N.check(self.lib.lia_stream_decode_packed(self.handle, slot, self.model.layer_bytes // 2), "lia_stream_decode_packed")
         N.check(self.lib.lia_stream_mark_ready(self.handle, slot), "lia_stream_mark_ready")
 
     def acquire(self, layer_idx):
@@ -145,10 +166,12 @@ class KVState:
 class OffloadScheduler:
     """forward(input_ids, kv_state, **lia flags) -> (logits [B,vocab], next_ids [B]) on the device."""
 
-    def __init__(self, model, device=0, n_slots=None, dp_group=None):
+    def __init__(self, model, device=0, n_slots=None, dp_group=None, pack12=None):
         import os
         self.model, self.device, self.dp = model, device, dp_group
         self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "4"))
+        # wire format of the streamed layers: "pack12" (lossless 12-bit encoding, lia_pack12.hip) or "raw" bf16
+        self.pack12 = os.environ.get("LIA_STREAM_FORMAT", "raw").lower() == "pack12" if pack12 is None else bool(pack12)
         self.ctx = None
         self.ws_rows = 0
         self.pipe = None
@@ -205,7 +228,9 @@ class OffloadScheduler:
         mini = B // num_minibatch if (policy in (0, 3) and is_prefill) or policy == 0 else B   # :1178 mini_bsz
         overlap = not no_overlap
 
-        m.place(n_gpu, pin_weight, enable_cxl)                    # move_gpu_layer / pin_memory, idempotent
+        # move_gpu_layer / pin_memory, idempotent.  The policy-1 host path reads the host copy directly, so the pack12
+        # wire format is only used when neither phase runs on the CPU.
+        m.place(n_gpu, pin_weight, enable_cxl, self.pack12 and prefill_policy != 1 and decoding_policy != 1)
         rows = B * T if n_gpu > 0 else mini * T                    # resident layers take the whole batch
         if policy == 0 and n_gpu < L:
             rows = max(rows, mini * kv_state.smax)                 # policy-0 decode parks the cached prefix in a slab
@@ -285,6 +310,9 @@ class OffloadScheduler:
         threads = hostinfo.default_host_threads(self.dp.world if self.dp else 1)
         for idx in range(n_gpu, sh.layers):
             st = m.layers[idx]
+            if st.packed:
+                raise ValueError("policy 1 needs the raw bf16 host copy, but the streamed layers were pinned in the pack12 wire "
+                                 "format by an earlier call; reload the model or set LIA_STREAM_FORMAT=raw")
             w = ops.weight_ptr_array(st.host_ptr(), m.offsets)
             kv = kv_state.kv[idx]
             N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx.data_ptr()),

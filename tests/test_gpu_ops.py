@@ -295,3 +295,52 @@ def test_layer_forward_error_codes(gpu):
         ctx.layer_forward(desc, 3, bad, x, y, kv, 2, 4, 0)
     with pytest.raises(ValueError):
         ctx.layer_forward(ops.make_desc(250, 5, 1024), 3, wptrs, x, y, kv, 2, 4, 0)  # head_dim 50
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide", "zeros", "specials"])
+def test_pack12_roundtrip_is_bit_exact(gpu, kind):
+    """pack12 (12-bit lossless wire format of the streamed weights): encode on the device, decode through the
+    streamer's staging path, every bf16 bit pattern must come back -- including -0, denormals, Inf, NaN payloads."""
+    import ctypes
+    ctx, ops, torch = gpu
+    from lia_amd import _native as N
+    L = N.lib()
+    n = 1 << 20
+    rs = np.random.RandomState(3)
+    if kind == "normal":
+        bits = synth.f32_to_bf16_bits((0.02 * rs.standard_normal(n)).astype(np.float32))
+    elif kind == "wide":      # heavy tails: thousands of escape records
+        bits = synth.f32_to_bf16_bits((rs.standard_normal(n) * np.exp(1.2 * rs.standard_normal(n))).astype(np.float32))
+    elif kind == "zeros":
+        bits = np.zeros(n, np.uint16)
+        bits[::7] = 0x8000
+        bits[5::11] = synth.f32_to_bf16_bits(np.float32([0.5]))[0]
+    else:
+        bits = rs.randint(0, 65536, size=n).astype(np.uint16)      # every pattern class, far too many escapes
+    src = to_dev(torch, bits)
+    cap = L.lia_pack12_bound(n)
+    enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    out = ctypes.c_size_t()
+    rc = L.lia_pack12_encode(ctypes.c_void_p(src.data_ptr()), n, ctypes.c_void_p(enc.data_ptr()), cap, ctypes.byref(out))
+    if kind == "specials":
+        assert rc == 1            # does not fit the format -> the caller ships the layer raw
+        return
+    assert rc == 0
+    if kind in ("normal", "zeros"):
+        assert out.value <= 0.76 * 2 * n + 4096, out.value        # 12 bits per value
+    # decode through the streamer (staging -> slot), as the scheduler does
+    h = ctypes.c_void_p()
+    N.check(L.lia_stream_create(ctx.handle, 1, 2 * n, ctypes.byref(h)))
+    host = torch.empty(out.value, dtype=torch.uint8, pin_memory=True)
+    host.copy_(enc[:out.value])
+    N.check(L.lia_stream_prefetch_packed(h, 0, ctypes.c_void_p(host.data_ptr()), out.value, n, 1))
+    N.check(L.lia_stream_wait(h, 0, ctypes.c_void_p(ctx.stream)))
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    slot = L.lia_stream_slot_ptr(h, 0)
+    back = torch.empty(n, dtype=torch.int16, device="cuda")
+    N.check(L.lia_memcpy_d2h(ctypes.c_void_p(back.data_ptr()), ctypes.c_void_p(slot), 0) if False else 0)
+    res = np.empty(n, np.uint16)
+    N.check(L.lia_memcpy_d2h(res.ctypes.data, ctypes.c_void_p(slot), 2 * n))
+    assert (res == bits).all(), int((res != bits).sum())
+    L.lia_stream_destroy(h)
