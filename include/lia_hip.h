@@ -194,9 +194,15 @@ int lia_stream_mark_ready(lia_streamer* s, int slot);
  * on the copy stream rebuilds the exact bf16 layer in the slot.  Build-defined: the reference ships raw bf16. */
 size_t lia_pack12_bound(size_t n_values);
 int lia_pack12_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
-int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int pinned);
+/* pack11: the denser sibling (3-bit primary exponent code in bit-planes + a 4-bit overflow stream located through a
+ * per-1024-value offset table): 11.1 bits per value for N(0,sigma) weights.  n_values must be a multiple of 1024. */
+size_t lia_pack11_bound(size_t n_values);
+int lia_pack11_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
+/* format: 11 or 12 */
+int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int format,
+                               int pinned);
 int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned);
-int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values);
+int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values, int format);
 void* lia_stream_staging_ptr(lia_streamer* s, int slot);
 int lia_stream_wait(lia_streamer* s, int slot, void* compute_stream);    /* compute waits for the copy  */
 int lia_stream_release(lia_streamer* s, int slot, void* compute_stream); /* slot reusable after this    */

@@ -215,7 +215,7 @@ extern "C" int lia_layer_pack_offsets(const lia_layer_desc* d, size_t off[16], s
   put(14, H * F, true); put(15, H, true);
   put(0, H, true);      put(1, H, true);
   put(10, H, true);     put(11, H, true);
-  if (total) *total = align_up(p, 256);
+  if (total) *total = align_up(p, 2048);   // 1024 bf16 values: the block size of the pack11 wire format
   return LIA_OK;
 }
 
@@ -590,7 +590,7 @@ extern "C" int lia_llama_pack_offsets(const lia_llama_desc* d, size_t off[9], si
   put(6, F * H, true); put(7, F * H, false);      // gate | up adjacent: one [2F, H] GEMM
   put(8, H * F, true);                            // down
   put(0, H, true); put(5, H, true);               // the two RMSNorm weights
-  if (total) *total = align_up(p, 256);
+  if (total) *total = align_up(p, 2048);
   return LIA_OK;
 }
 
@@ -730,7 +730,8 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
 // weight streamer
 // ------------------------------------------------------------------------------------------------
 extern "C" size_t lia_pack12_bound(size_t n_values);
-extern "C" void lia_pack12_decode_launch(const char* src, bf16_t* dst, size_t n_values, hipStream_t st);
+extern "C" size_t lia_pack11_bound(size_t n_values);
+extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st);
 
 struct lia_streamer {
   lia_ctx* ctx;
@@ -842,7 +843,7 @@ extern "C" int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, c
 // bf16 layer in the slot itself (lia_pack12.hip).  begin -> copy_chunk_packed* -> decode_packed -> mark_ready.
 static int ensure_staging(lia_streamer* s) {
   if (s->staging) return LIA_OK;
-  s->staging_bytes = lia_pack12_bound(s->slot_bytes / 2);
+  s->staging_bytes = std::max(lia_pack12_bound(s->slot_bytes / 2), lia_pack11_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024));
   HIP_TRY(hipMalloc((void**)&s->staging, s->staging_bytes * s->n_slots));
   HIP_TRY(hipStreamCreateWithFlags(&s->decode, hipStreamNonBlocking));
   s->landed.resize(s->n_slots);
@@ -873,26 +874,31 @@ extern "C" int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t of
   return LIA_OK;
 }
 
-extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values) {
-  if (!s || slot < 0 || slot >= s->n_slots || !s->staging || n_values * 2 > s->slot_bytes || (n_values % 16)) return LIA_ERR_INVALID;
+extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values, int format) {
+  if (!s || slot < 0 || slot >= s->n_slots || !s->staging || n_values * 2 > s->slot_bytes || (n_values % 16) ||
+      (format != 11 && format != 12) || (format == 11 && (n_values % 1024))) {
+    lia_set_error("lia_stream_decode_packed: slot=%d n_values=%zu format=%d", slot, n_values, format);
+    return LIA_ERR_INVALID;
+  }
   // The decode runs on its own stream behind an event, so the copy engine moves on to the next layer at once.
   // It must not start before the slot's previous consumer released it: begin() made the COPY stream wait for that,
   // and `landed` is recorded on the copy stream after the copy, so the order is inherited.
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));                       // copy-engine busy time ends here
   HIP_TRY(hipEventRecord(s->landed[slot], s->copy));
   HIP_TRY(hipStreamWaitEvent(s->decode, s->landed[slot], 0));
-  lia_pack12_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, s->decode);
+  lia_packed_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, format, s->decode);
   HIP_TRY(hipGetLastError());
   s->decoded_on_side[slot] = 1;
   return LIA_OK;
 }
 
-extern "C" int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int pinned) {
+extern "C" int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int format,
+                                          int pinned) {
   int rc = lia_stream_begin(s, slot);
   if (rc) return rc;
   rc = lia_stream_copy_chunk_packed(s, slot, 0, host_ptr, packed_bytes, pinned);
   if (rc) return rc;
-  rc = lia_stream_decode_packed(s, slot, n_values);
+  rc = lia_stream_decode_packed(s, slot, n_values, format);
   if (rc) return rc;
   return lia_stream_mark_ready(s, slot);
 }

@@ -87,9 +87,11 @@ SIGNATURES = {
     "lia_stream_mark_ready": (c_int, [c_void_p, c_int]),
     "lia_pack12_bound": (c_size_t, [c_size_t]),
     "lia_pack12_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
-    "lia_stream_prefetch_packed": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_size_t, c_int]),
+    "lia_pack11_bound": (c_size_t, [c_size_t]),
+    "lia_pack11_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
+    "lia_stream_prefetch_packed": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_size_t, c_int, c_int]),
     "lia_stream_copy_chunk_packed": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, c_int]),
-    "lia_stream_decode_packed": (c_int, [c_void_p, c_int, c_size_t]),
+    "lia_stream_decode_packed": (c_int, [c_void_p, c_int, c_size_t, c_int]),
     "lia_stream_staging_ptr": (c_void_p, [c_void_p, c_int]),
     "lia_stream_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lia_stream_release": (c_int, [c_void_p, c_int, c_void_p]),

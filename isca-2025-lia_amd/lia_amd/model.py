@@ -67,7 +67,7 @@ class LayerStore:
     def __init__(self, desc, offsets, total_bytes):
         self.desc, self.offsets, self.nbytes = desc, offsets, total_bytes
         self.tier = None          # "device" | "pinned" | "cxl" | "pageable" | "remote"
-        self.packed = False       # host copy holds the pack12 encoding (lia_pack12.hip) instead of raw bf16
+        self.packed = 0           # 0: host copy is raw bf16; 11 / 12: it holds that lossless encoding (lia_pack12.hip)
         self.stream_bytes = total_bytes   # bytes that cross the host link per use
         self._dev = None          # torch uint8 CUDA tensor
         self._np = None           # numpy uint8 (pageable)
@@ -126,33 +126,39 @@ class LayerStore:
         self._free()
         self._dev, self.tier = dev, "device"
 
-    def _encode_pack12(self):
-        """-> (device uint8 tensor with the pack12 bytes, n bytes) or None when the layer does not fit the format."""
+    def _encode_packed(self, fmt):
+        """-> (device uint8 tensor with the encoded bytes, n bytes) or None when the layer does not fit the format."""
         if self.tier != "device":
             tmp = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
             N.check(self._lib.lia_memcpy_h2d(tmp.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
             src = tmp
         else:
             src = self._dev
-        cap = self._lib.lia_pack12_bound(self.nbytes // 2)
+        bound, encode = ((self._lib.lia_pack11_bound, self._lib.lia_pack11_encode) if fmt == 11 else
+                         (self._lib.lia_pack12_bound, self._lib.lia_pack12_encode))
+        cap = bound(self.nbytes // 2)
         enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
         out = ctypes.c_size_t()
-        rc = self._lib.lia_pack12_encode(ctypes.c_void_p(src.data_ptr()), self.nbytes // 2, ctypes.c_void_p(enc.data_ptr()), cap,
-                                         ctypes.byref(out))
+        rc = encode(ctypes.c_void_p(src.data_ptr()), self.nbytes // 2, ctypes.c_void_p(enc.data_ptr()), cap, ctypes.byref(out))
         if rc == 1:
             return None            # too many out-of-window values: ship this layer raw
         if rc != 0:
-            raise N.LiaHipError(f"lia_pack12_encode failed ({rc})")
+            raise N.LiaHipError(f"lia_pack{fmt}_encode failed ({rc})")
         return enc, out.value
 
     def to_pinned(self, pack12=False):
         """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227); with pack12 the pinned copy is
         the lossless 12-bit encoding (75 % of the bytes)."""
-        if self.tier == "pinned" and self.packed == bool(pack12):
-            return
-        if self.tier == "pinned" and pack12 != self.packed:
-            raise ValueError("layer is already pinned in the other stream format")
-        enc = self._encode_pack12() if (pack12 and self.nbytes % 32 == 0) else None
+        fmt = {False: 0, True: 12, None: 0}.get(pack12, pack12)          # accepts False / True (= 12) / 11 / 12
+        if self.tier == "pinned":
+            if self.packed and not fmt:
+                raise ValueError("layer is pinned in a packed wire format but the raw bf16 copy was requested")
+            return            # already pinned (a raw copy also serves a packed request: it simply ships more bytes)
+        enc = None
+        if fmt == 11 and self.nbytes % 2048 == 0:
+            enc = self._encode_packed(11)
+        elif fmt == 12 and self.nbytes % 32 == 0:
+            enc = self._encode_packed(12)
         nbytes = enc[1] if enc else self.nbytes
         ptr = self._lib.lia_host_alloc_pinned(nbytes)
         if not ptr:
@@ -163,7 +169,7 @@ class LayerStore:
             self._fill_host(ptr)
         self._free()
         self._ptr, self.tier = ptr, "pinned"
-        self.packed, self.stream_bytes = bool(enc), nbytes
+        self.packed, self.stream_bytes = (fmt if enc else 0), nbytes
 
     def to_cxl(self):
         """realloc_to_numa (lia/modeling_opt.py:168-175) + hipHostRegister so the copy engine can DMA from it
@@ -192,7 +198,7 @@ class LayerStore:
             self._lib.numa_free_node(self._ptr, self.nbytes)
         self._ptr = self._dev = self._np = None
         self.tier = None
-        self.packed, self.stream_bytes = False, self.nbytes
+        self.packed, self.stream_bytes = 0, self.nbytes
 
     def close(self):
         self._free()

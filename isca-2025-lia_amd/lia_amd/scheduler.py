@@ -71,7 +71,7 @@ class WeightPipeline:
         self.next_slot = (slot + 1) % self.n_slots
         if self.dp is None and st.packed:
             N.check(self.lib.lia_stream_prefetch_packed(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.stream_bytes, st.nbytes // 2,
-                                                        int(st.is_dma_able())), "lia_stream_prefetch_packed")
+                                                        int(st.packed), int(st.is_dma_able())), "lia_stream_prefetch_packed")
         elif self.dp is None:
             N.check(self.lib.lia_stream_prefetch(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.nbytes, int(st.is_dma_able())),
                     "lia_stream_prefetch")
@@ -89,7 +89,7 @@ class WeightPipeline:
         N.check(self.lib.lia_stream_begin(self.handle, slot), "lia_stream_begin")
         if packed:
             if self.staging_tensors is None:
-                cap = self.lib.lia_pack12_bound(self.model.layer_bytes // 2)
+                cap = max(self.lib.lia_pack12_bound(self.model.layer_bytes // 2), self.lib.lia_pack11_bound(self.model.layer_bytes // 2))
                 self.staging_tensors = [RawDeviceBuffer(self.lib.lia_stream_staging_ptr(self.handle, s), cap).tensor()
                                         for s in range(self.n_slots)]
             target, copy_fn = self.staging_tensors[slot][:nbytes], self.lib.lia_stream_copy_chunk_packed
@@ -106,7 +106,7 @@ class WeightPipeline:
             for w in works:
                 w.wait()              # the copy stream waits for RCCL's stream; the host does not block
         if packed:
-            N.check(self.lib.lia_stream_decode_packed(self.handle, slot, self.model.layer_bytes // 2), "lia_stream_decode_packed")
+            N.check(self.lib.lia_stream_decode_packed(self.handle, slot, self.model.layer_bytes // 2, int(packed)), "lia_stream_decode_packed")
         N.check(self.lib.lia_stream_mark_ready(self.handle, slot), "lia_stream_mark_ready")
 
     def acquire(self, layer_idx):
@@ -171,7 +171,8 @@ class OffloadScheduler:
         self.model, self.device, self.dp = model, device, dp_group
         self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "4"))
         # wire format of the streamed layers: "pack12" (lossless 12-bit encoding, lia_pack12.hip) or "raw" bf16
-        self.pack12 = os.environ.get("LIA_STREAM_FORMAT", "raw").lower() == "pack12" if pack12 is None else bool(pack12)
+        fmt = os.environ.get("LIA_STREAM_FORMAT", "raw").lower() if pack12 is None else pack12
+        self.pack12 = {"raw": 0, "pack12": 12, "pack11": 11, False: 0, True: 12, 0: 0, 11: 11, 12: 12}[fmt]
         self.ctx = None
         self.ws_rows = 0
         self.pipe = None

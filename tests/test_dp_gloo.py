@@ -125,6 +125,8 @@ def test_weight_pipeline_slot_order(monkeypatch, n_slots):
 
     class Store:
         nbytes = 64
+        packed = 0
+        stream_bytes = 64
 
         def host_ptr(self):
             return 0x9000

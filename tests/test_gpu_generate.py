@@ -48,13 +48,13 @@ FLAG_SETS = [
 
 @pytest.mark.parametrize("name", GEN_CASES)
 @pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k[:4]}{int(v)}" for k, v in f.items()) or "defaults")
-@pytest.mark.parametrize("fmt", ["raw", "pack12"])
+@pytest.mark.parametrize("fmt", ["raw", "pack12", "pack11"])
 def test_generate_ids_match_hf_golden(name, flags, fmt, monkeypatch):
     import torch
     from lia_amd.generation import generate
     monkeypatch.setenv("LIA_STREAM_FORMAT", fmt)
-    if fmt == "pack12" and (not flags.get("pin_weight") or flags.get("gpu_percentage", 0) >= 99):
-        pytest.skip("pack12 applies to pinned streamed layers")
+    if fmt != "raw" and (not flags.get("pin_weight") or flags.get("gpu_percentage", 0) >= 99):
+        pytest.skip("the packed formats apply to pinned streamed layers")
     z, m, ids, c = _load(name)
     if flags.get("num_minibatch", 1) > 1 and c["B"] % flags["num_minibatch"]:
         pytest.skip("batch not divisible")
