@@ -129,7 +129,9 @@ __device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char
 // S-1 chunks stay in flight per workgroup behind a COUNTED vmcnt and a raw s_barrier
 // (cdna_hip_programming.md "Pipelining across barriers").  Workgroup = 8 waves = 128 weight rows x all M
 // rows: the x chunk (L2-resident) is shared by 8 waves, so LDS-DMA moves 1.5 bytes per weight byte.
-// Measured on MI355X (tools/gemm_bench.hip, cold weights, M = 64): 4.6-5.1 TB/s on the OPT-30B shapes.
+// Measured on MI355X (tools/gemm_bench.hip, cold weights, M = 64): 4.6-5.1 TB/s on the OPT-30B shapes with 128-row
+// workgroups; RT = 2 (256 weight rows per workgroup, 1.25 LDS-DMA bytes per weight byte) 5.4-5.6 TB/s on qkv/fc1/fc2
+// (fit: 6.7 TB/s asymptotic + 14 us fixed per launch), which the launcher picks when the coarser grid still fills the chip.
 // History: a first version kept W in a 4-deep VGPR ring (plain loads) and staged x through registers;
 // x and W then share one in-order vmcnt queue and the ring's depth collapses to one chunk (2.9 TB/s).
 // A 64-row workgroup moves 2 LDS-DMA bytes per weight byte and saturates the CU's ~34 GB/s LDS-DMA path
@@ -155,19 +157,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "add the immediate");
 }
 
-template <int MT, int S, int NT, int WAVES>
+template <int MT, int S, int NT, int WAVES, int RT = 1>
 __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                        const bf16_t* __restrict__ W, long ldw, int M, int N,
                                                                        int K, int chunks_per_split,
                                                                        float* __restrict__ partial, LiaEpilogue ep,
                                                                        LiaOutMap om) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BN = 16 * WAVES;                    // W rows per workgroup (16 per wave)
+  constexpr int BN = 16 * WAVES * RT;               // W rows per workgroup (RT MFMA row tiles of 16 per wave)
   constexpr int RR = 8 * WAVES;                     // rows one LDS-DMA round of the workgroup covers (128 B each)
   constexpr int RB = RR * 128;                      // bytes per round
+  constexpr int WL = BN / RR;                       // W rounds per chunk
   constexpr int XR = 16 * MT;                       // x rows in a stage
   constexpr int XL = (XR + RR - 1) / RR;            // x rounds per chunk
-  constexpr int NL = 2 + XL;                        // LDS-DMA instructions per thread per chunk (2 rounds of W)
+  constexpr int NL = WL + XL;                       // LDS-DMA instructions per thread per chunk
   constexpr int WTILE = BN * 128, STAGE = WTILE + XL * RB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
 
   // per-thread source rows (clamped: out-of-range rows re-read a valid one and are never stored)
   const int srow = tid >> 3, sc = tid & 7;
-  const bf16_t* wsrc[2];
+  const bf16_t* wsrc[WL];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < WL; ++r) {
     int row = srow + RR * r;
     wsrc[r] = W + (long)min(n_tile + row, N - 1) * ldw + ((sc ^ tl_swz(row)) << 3);
   }
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
     char* st = smem + stage * STAGE;
     const long koff = (long)c * S2_BK;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < WL; ++r) {
       // weights are read once by one workgroup: non-temporal (aux = 2) keeps them from evicting x in L2
       if constexpr (NT) __builtin_amdgcn_global_load_lds(GL_AS1(wsrc[r] + koff), LDS_AS3(st + r * RB + wave * 1024), 16, 0, 2);
       else __builtin_amdgcn_global_load_lds(GL_AS1(wsrc[r] + koff), LDS_AS3(st + r * RB + wave * 1024), 16, 0, 0);
@@ -205,15 +208,17 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
       __builtin_amdgcn_global_load_lds(GL_AS1(xsrc[r] + koff), LDS_AS3(st + WTILE + r * RB + wave * 1024), 16, 0, 0);
   };
 
-  f32x4 acc[MT];
+  f32x4 acc[RT][MT];
 #pragma unroll
-  for (int p = 0; p < MT; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int p = 0; p < MT; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (n > 0) {
     const int c_last = c_end - 1;
 #pragma unroll
     for (int j = 0; j < S - 1; ++j) issue(min(c_begin + j, c_last), j);
-    const int wrow = wave * 16 + l15;
+    const int wrow = wave * 16 * RT + l15;
     for (int i = 0; i < n; ++i) {
       // retire chunk i (issued S-1 groups ago); the groups behind it stay in flight
       const int behind = min(S - 2, n - 1 - i);       // groups issued after chunk i that may still be pending
@@ -227,12 +232,18 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
       const char* xt = wt + WTILE;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + wrow * 128 + (((4 * ks + lq) ^ tl_swz(wrow)) << 4)));
+        bf16x8 a[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const int row = wrow + 16 * t;
+          a[t] = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
+        }
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
           int row = 16 * p + l15;
           bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(xt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
-          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[p], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < RT; ++t) acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][p], 0, 0, 0);
         }
       }
     }
@@ -240,21 +251,24 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
   // keep the last MFMA well clear of the accumulator reads below (see the note in v1)
   __builtin_amdgcn_s_barrier();
 
-  const int n_wave = n_tile + wave * 16;
-  if (n_wave >= N) return;
-  const int nn = n_wave + 4 * lq;
-  if (partial != nullptr) {
-    float* pp = partial + (long)blockIdx.y * M * N;
 #pragma unroll
-    for (int p = 0; p < MT; ++p) {
-      int m = 16 * p + l15;
-      if (m < M) *(f32x4*)(pp + (long)m * N + nn) = acc[p];
-    }
-  } else {
+  for (int t = 0; t < RT; ++t) {
+    const int n_wave = n_tile + (wave * RT + t) * 16;
+    if (n_wave >= N) continue;
+    const int nn = n_wave + 4 * lq;
+    if (partial != nullptr) {
+      float* pp = partial + (long)blockIdx.y * M * N;
 #pragma unroll
-    for (int p = 0; p < MT; ++p) {
-      int m = 16 * p + l15;
-      if (m < M) store_quad(acc[p], m, nn, ep, om);
+      for (int p = 0; p < MT; ++p) {
+        int m = 16 * p + l15;
+        if (m < M) *(f32x4*)(pp + (long)m * N + nn) = acc[t][p];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < MT; ++p) {
+        int m = 16 * p + l15;
+        if (m < M) store_quad(acc[t][p], m, nn, ep, om);
+      }
     }
   }
 }
@@ -444,21 +458,25 @@ extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
   return (size_t)8 * M * N * sizeof(float);
 }
 
-template <int MT, int S, int NT, int WAVES>
+template <int MT, int S, int NT, int WAVES, int RT = 1>
 static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K, int split, int cps,
                            float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
-  constexpr int BN = 16 * WAVES, RR = 8 * WAVES;
+  constexpr int BN = 16 * WAVES * RT, RR = 8 * WAVES;
   constexpr int XL = (16 * MT + RR - 1) / RR;
   dim3 grid((N + BN - 1) / BN, split);
   size_t lds = (size_t)S * (BN * 128 + XL * RR * 128);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lia_gemm_skinny2_kernel<MT, S, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)lia_gemm_skinny2_kernel<MT, S, NT, WAVES, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((lia_gemm_skinny2_kernel<MT, S, NT, WAVES>), grid, dim3(64 * WAVES), lds, st, x, ldx, W, ldw, M, N, K, cps,
+  hipLaunchKernelGGL((lia_gemm_skinny2_kernel<MT, S, NT, WAVES, RT>), grid, dim3(64 * WAVES), lds, st, x, ldx, W, ldw, M, N, K, cps,
                      split > 1 ? partial : nullptr, ep, om);
 }
+
+// experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row
+static int g_skinny_variant = 0;
+extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
 
 // Returns 0 on success, -1 on unsupported shape.  workspace is only touched when split-K is chosen.
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
@@ -470,21 +488,40 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N % 16) != 0 || (om->seg_n % 4) != 0) return -1;
   if (M <= 256 && (K % (2 * S2_BK)) == 0) {
-    constexpr int WAVES = 8, BN = 16 * WAVES;
+    constexpr int WAVES = 8;
     const int nchunks = K / S2_BK;
-    const int tiles = (N + BN - 1) / BN;
-    // M <= 64: 3 stages x 24 KB -> two 8-wave workgroups per CU = 512 slots on the chip
-    const int slots = M <= 64 ? 512 : 256;
-    int split = 1;
-    if (force_split > 0) {
-      split = force_split;
-    } else {
-      // fill the slots once; beyond 4 slices the fp32 slab traffic (2 x M x BN x 4 B per workgroup) costs more
-      // than the idle CUs it recovers (measured on OPT-30B shapes, tools/gemm_bench.hip)
-      split = (slots + tiles / 2) / tiles;
-      if (tiles * 10 > slots * 6 && tiles < slots) split = 3;   // 0.6..1 waves: three slices balance better than one
-      split = split < 1 ? 1 : (split > 4 ? 4 : split);
-      while (split > 1 && nchunks / split < 8) --split;
+    // Two workgroup shapes.  RT = 1: 128 weight rows, LDS-DMA moves (128 + 16 MT)/128 bytes per weight byte, two
+    // workgroups per CU up to M = 64.  RT = 2 (32 < M <= 128): 256 weight rows per workgroup halve the x share of
+    // the LDS-DMA traffic (OPT-30B fc1 at M = 64: 4.9 -> 5.5 TB/s) but leave a quarter as many workgroups, so it is
+    // chosen only when tiles x slices still fill the 256 CUs and every slice keeps >= 32 chunks of pipeline.
+    int rt = 1, split = 1;
+    {
+      const int tiles2 = (N + 255) / 256;
+      int split2 = (256 + tiles2 / 2) / tiles2;
+      split2 = split2 < 1 ? 1 : (split2 > 8 ? 8 : split2);
+      while (split2 > 1 && nchunks / split2 < 32) --split2;
+      const double waves2 = tiles2 * split2 / 256.0;
+      const double fill2 = waves2 / (double)(int)(waves2 + 0.999999);
+      const bool fits = (size_t)split2 * M * N * sizeof(float) <= workspace_bytes || split2 == 1;
+      if (M > 32 && M <= 128 && fill2 >= 0.85 && nchunks / split2 >= 32 && fits && force_split <= 0) { rt = 2; split = split2; }
+      if (g_skinny_variant == 1) rt = 1;
+      if (g_skinny_variant == 2 && M > 32 && M <= 128) { rt = 2; split = split2; }
+    }
+    if (rt == 1) {
+      const int BN = 16 * WAVES;
+      const int tiles = (N + BN - 1) / BN;
+      // M <= 64: 3 stages x 24 KB -> two 8-wave workgroups per CU = 512 slots on the chip
+      const int slots = M <= 64 ? 512 : 256;
+      if (force_split > 0) {
+        split = force_split;
+      } else {
+        // fill the slots once; beyond 4 slices the fp32 slab traffic (2 x M x BN x 4 B per workgroup) costs more
+        // than the idle CUs it recovers (measured on OPT-30B shapes, tools/gemm_bench.hip)
+        split = (slots + tiles / 2) / tiles;
+        if (tiles * 10 > slots * 6 && tiles < slots) split = 3;   // 0.6..1 waves: three slices balance better than one
+        split = split < 1 ? 1 : (split > 4 ? 4 : split);
+        while (split > 1 && nchunks / split < 8) --split;
+      }
     }
     if (split > nchunks) split = nchunks;
     if (split > 1 && (size_t)split * M * N * sizeof(float) > workspace_bytes) split = 1;
@@ -494,8 +531,13 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     if (ev0) (void)hipEventRecord(ev0, st);
     if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-    else if (M <= 64) launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-    else if (M <= 128) launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 64) {
+      if (rt == 2) launch_skinny2<4, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+      else launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    } else if (M <= 128) {
+      if (rt == 2) launch_skinny2<8, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+      else launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    }
     else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     if (split > 1) {

@@ -76,6 +76,8 @@ def test_layernorm(gpu, oracle, rows, H):
     # tiled (prefill) regime, ragged edges included
     (257, 384, 512, False, True, 0), (512, 1024, 768, True, False, 0), (1000, 272, 320, False, True, 0),
     (1024, 2304, 768, False, False, 0),
+    # 256-row skinny workgroups (chosen when tiles x slices fill the chip): ragged M and N, split-K 2 and 3
+    (100, 28672, 4096, True, False, 0), (50, 21520, 6144, False, True, 0),
 ])
 def test_linear(gpu, oracle, M, N, K, relu, res, split):
     ctx, ops, torch = gpu

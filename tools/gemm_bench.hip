@@ -21,20 +21,22 @@ int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 64;
   int force_split = argc > 2 ? atoi(argv[2]) : 0;
   if (argc > 3) lia_gemm_set_tiled_variant(atoi(argv[3]));
+  if (getenv("SKV")) lia_gemm_set_skinny_variant(atoi(getenv("SKV")));
 
   struct Shape { const char* name; int N, K; };
   std::vector<Shape> shapes = {{"qkv", 21504, 7168}, {"out", 7168, 7168}, {"fc1", 28672, 7168}, {"fc2", 7168, 28672}, {"lm_head", 50272, 7168}};
+  if (getenv("LLAMA")) shapes = {{"qkv", 6144, 4096}, {"o", 4096, 4096}, {"gate_up", 28672, 4096}, {"down", 4096, 14336}, {"lm_head", 128256, 4096}};
   if (getenv("KSWEEP")) shapes = {{"k1792", 7168, 1792}, {"k3584", 7168, 3584}, {"k7168", 7168, 7168}, {"k14336", 7168, 14336}, {"k28672", 7168, 28672}, {"dummy", 16, 128}};
   const int NBUF = 4;
-  size_t maxw = (size_t)50272 * 7168;
+  size_t maxw = (size_t)128256 * 4096;
   uint16_t* w[NBUF];
   for (int i = 0; i < NBUF; ++i) { CK(hipMalloc(&w[i], maxw * 2)); fill_kernel<<<2048, 256>>>(w[i], maxw, 17 + i); }
   uint16_t *x, *y, *bias, *res; float* ws;
   CK(hipMalloc(&x, (size_t)M * 28672 * 2)); fill_kernel<<<2048, 256>>>(x, (size_t)M * 28672, 3);
-  CK(hipMalloc(&y, (size_t)M * 50272 * 2)); CK(hipMalloc(&bias, 50272 * 2)); CK(hipMalloc(&res, (size_t)M * 50272 * 2));
-  fill_kernel<<<256, 256>>>(bias, 50272, 5); fill_kernel<<<2048, 256>>>(res, (size_t)M * 50272, 7);
+  CK(hipMalloc(&y, (size_t)M * 128256 * 2)); CK(hipMalloc(&bias, 128256 * 2)); CK(hipMalloc(&res, (size_t)M * 128256 * 2));
+  fill_kernel<<<256, 256>>>(bias, 128256, 5); fill_kernel<<<2048, 256>>>(res, (size_t)M * 128256, 7);
   if (M > 256) shapes.pop_back();  // no lm_head in prefill (last position only)
-  size_t ws_bytes = (size_t)8 * (M <= 256 ? M : 1) * 50272 * 4; CK(hipMalloc(&ws, ws_bytes));
+  size_t ws_bytes = (size_t)8 * (M <= 256 ? M : 1) * 128256 * 4; CK(hipMalloc(&ws, ws_bytes));
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
