@@ -92,9 +92,11 @@ def pmc_traffic(kernel_substr):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        for k, v in d["kernels"].items():
-            if kernel_substr in k:
-                return v["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        # every instantiation of the kernel (128- and 256-row workgroups), weighted by its launches
+        hits = [v for k, v in d["kernels"].items() if kernel_substr in k and "traffic_bytes_per_launch" in v]
+        calls = sum(v["calls"] for v in hits)
+        if calls:
+            return sum(v["traffic_bytes_per_launch"] * v["calls"] for v in hits) / calls, os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
         pass
     return None, None
@@ -252,7 +254,7 @@ def main():
             "prefill_ms": prefill_ms,
             "decode_latency_ms": {"mean": 1e3 * sum(step_lat) / len(step_lat), "p90": 1e3 * sorted(step_lat)[int(0.9 * (len(step_lat) - 1))],
                                   "max": 1e3 * max(step_lat)},
-            "roofline": {"bound": "hbm", "kernel": "lia_gemm_skinny2_kernel<4,3,1,8> (decode linears + lm_head)",
+            "roofline": {"bound": "hbm", "kernel": "lia_gemm_skinny2_kernel<4,3,1,8,RT> (RT = 1 and 2; decode linears + lm_head)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "launches": prof["skinny_launches"], "avg_launch_us": 1e3 * sk_ms / sk_n,
                          "algorithmic_bytes_per_launch": prof["skinny_bytes"] / sk_n},
