@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
     ap.add_argument("--cxl-nodes", default=None, help="NUMA nodes of the CXL tier, e.g. 2,3 (default LIA_CXL_NODES or 2,3)")
     ap.add_argument("--init", default="normal", choices=["normal", "uniform01"])
-    ap.add_argument("--stream-format", default=os.environ.get("LIA_STREAM_FORMAT", "pack11"), choices=["raw", "pack12", "pack11"],
+    ap.add_argument("--stream-format", default=os.environ.get("LIA_STREAM_FORMAT", "pack10"), choices=["raw", "pack12", "pack11", "pack10"],
                     help="wire format of the streamed layers: raw bf16, or the lossless 12-bit / 11.1-bit encodings")
     ap.add_argument("--host-threads", type=int, default=0)
     a = ap.parse_args()
@@ -169,7 +169,7 @@ def main():
         sched = LlamaScheduler(model, device=local_rank)
         KVState = lambda mdl, ng, b, s: LlamaKVState(mdl, b, s)  # noqa: E731,F811
     else:
-        pack12 = {"raw": 0, "pack12": 12, "pack11": 11}[a.stream_format] if not a.enable_cxl else 0
+        pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[a.stream_format] if not a.enable_cxl else 0
         model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
                                         host_owner=(group is None or group.is_root), pack12=pack12)
         sched = OffloadScheduler(model, device=local_rank, dp_group=group, pack12=pack12)

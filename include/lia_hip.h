@@ -198,7 +198,12 @@ int lia_pack12_encode(const lia_bf16* src_device, size_t n_values, char* dst_dev
  * per-1024-value offset table): 11.1 bits per value for N(0,sigma) weights.  n_values must be a multiple of 1024. */
 size_t lia_pack11_bound(size_t n_values);
 int lia_pack11_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
-/* format: 11 or 12 */
+/* pack10: three-level exponent code (2-bit level-1 planes for the three most frequent exponents, a compacted 2-bit
+ * level 2 for the next three, pack12's 4-bit alphabet as level 3; two per-1024-value offset tables): 10.8 bits per value
+ * for N(0,sigma) weights, against an exponent-entropy bound of 10.55.  n_values must be a multiple of 1024. */
+size_t lia_pack10_bound(size_t n_values);
+int lia_pack10_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
+/* format: 10, 11 or 12 */
 int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int format,
                                int pinned);
 int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned);

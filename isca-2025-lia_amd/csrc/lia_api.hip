@@ -731,6 +731,7 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
 // ------------------------------------------------------------------------------------------------
 extern "C" size_t lia_pack12_bound(size_t n_values);
 extern "C" size_t lia_pack11_bound(size_t n_values);
+extern "C" size_t lia_pack10_bound(size_t n_values);
 extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st);
 
 struct lia_streamer {
@@ -843,7 +844,8 @@ extern "C" int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, c
 // bf16 layer in the slot itself (lia_pack12.hip).  begin -> copy_chunk_packed* -> decode_packed -> mark_ready.
 static int ensure_staging(lia_streamer* s) {
   if (s->staging) return LIA_OK;
-  s->staging_bytes = std::max(lia_pack12_bound(s->slot_bytes / 2), lia_pack11_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024));
+  s->staging_bytes = std::max({lia_pack12_bound(s->slot_bytes / 2), lia_pack11_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024),
+                               lia_pack10_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024)});
   HIP_TRY(hipMalloc((void**)&s->staging, s->staging_bytes * s->n_slots));
   HIP_TRY(hipStreamCreateWithFlags(&s->decode, hipStreamNonBlocking));
   s->landed.resize(s->n_slots);
@@ -876,7 +878,7 @@ extern "C" int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t of
 
 extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values, int format) {
   if (!s || slot < 0 || slot >= s->n_slots || !s->staging || n_values * 2 > s->slot_bytes || (n_values % 16) ||
-      (format != 11 && format != 12) || (format == 11 && (n_values % 1024))) {
+      (format != 10 && format != 11 && format != 12) || (format != 12 && (n_values % 1024))) {
     lia_set_error("lia_stream_decode_packed: slot=%d n_values=%zu format=%d", slot, n_values, format);
     return LIA_ERR_INVALID;
   }

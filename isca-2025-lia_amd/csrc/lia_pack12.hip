@@ -378,6 +378,19 @@ __global__ __launch_bounds__(256) void lia_pack11_patch_kernel(const char* __res
   }
 }
 
+// Move `bytes` at dst+from down to dst+to (to <= from) on the device; overlapping ranges go through a temporary
+// (a device-to-device hipMemcpy of overlapping ranges is undefined).
+static bool lp_move_down(char* dst, size_t to, size_t from, size_t bytes) {
+  if (to == from || bytes == 0) return true;
+  if (to + bytes <= from) return hipMemcpy(dst + to, dst + from, bytes, hipMemcpyDeviceToDevice) == hipSuccess;
+  void* tmp = nullptr;
+  if (hipMalloc(&tmp, bytes) != hipSuccess) return false;
+  const bool ok = hipMemcpy(tmp, dst + from, bytes, hipMemcpyDeviceToDevice) == hipSuccess &&
+                  hipMemcpy(dst + to, tmp, bytes, hipMemcpyDeviceToDevice) == hipSuccess;
+  (void)hipFree(tmp);
+  return ok;
+}
+
 // room an encode may need: overflow capacity n/4 nibbles (25 % of the values), escapes n/16 records
 extern "C" size_t lia_pack11_bound(size_t n_values) {
   return 256 + lp12_align(n_values) + 3 * lp12_align(n_values / 8) + lp12_align((n_values / 1024) * 4 + 16) +
@@ -423,10 +436,327 @@ extern "C" int lia_pack11_encode(const bf16_t* src, size_t n_values, char* dst, 
   // compact: escape records directly after the overflow nibbles actually used
   const size_t used_ovf = lp12_align((size_t)((hd.n_ovf + 1) / 2) + 16);
   const size_t new_esc = hd.off_ovf + used_ovf;
-  if (new_esc != hd.off_esc && hd.n_esc) {
-    if (hipMemcpy(dst + new_esc, dst + hd.off_esc, (size_t)hd.n_esc * 8, hipMemcpyDeviceToDevice) != hipSuccess) return -3;
-  }
+  if (!lp_move_down(dst, new_esc, hd.off_esc, (size_t)hd.n_esc * 8)) return -3;
   hd.off_esc = new_esc;
+  if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
+  *out_bytes = (size_t)hd.off_esc + lp12_align((size_t)hd.n_esc * 8);
+  return 0;
+}
+
+// =====================================================================================================
+// "pack10": three-level exponent code, the closest of the three to the exponent entropy (10.55 bits per value for
+// N(0, sigma) weights).  Level 1: 2 bits per value as two bit-planes - codes 0..2 = the three most frequent
+// exponents of the layer, 3 = "see level 2".  Level 2: 2 bits per level-1 escape, compacted in value order - codes
+// 0..2 = the next three exponents, 3 = "see level 3".  Level 3: pack12's 4-bit alphabet per level-2 escape (14-binade
+// window, 14 = exponent 0 i.e. +-0 and denormals, 15 = escape record).  The symbol sets are arbitrary exponents
+// (header tables), so +-0 and denormals need no special case.  Two u32 offset tables (one entry per 1024 values each)
+// + two wave prefix sums of popcounts locate every lane's level-2 / level-3 codes.
+// 8 + 2 + 0.274*2 + 0.041*4 + 0.06 = 10.77 bits per value for N(0, sigma) = 67.3 % of the raw bytes.
+// Buffer: [header 256][plane A: n][b0: n/8][b1: n/8][tab2: n/1024 u32][tab3: n/1024 u32][level 2][level 3][escapes]
+// =====================================================================================================
+struct LiaPack10Header {
+  uint32_t magic;        // 'LP10'
+  uint32_t sym1;         // bytes 0..2: exponents of level-1 codes 0..2
+  uint32_t sym2;         // bytes 0..2: exponents of level-2 codes 0..2
+  uint32_t e3;           // first exponent of the 14-binade level-3 window
+  uint64_t n;            // values, multiple of 1024
+  uint64_t n_l2;         // level-2 codes (2 bits each)
+  uint64_t n_l3;         // level-3 codes (4 bits each)
+  uint64_t off_a, off_b0, off_b1, off_tab2, off_tab3, off_l2, off_l3, off_esc;
+  uint64_t l2_cap, l3_cap;
+  uint32_t n_esc, esc_cap;
+  uint32_t overflow;
+  uint32_t pad[31];
+};
+static_assert(sizeof(LiaPack10Header) == 256, "header is 256 bytes");
+constexpr uint32_t LP10_MAGIC = 0x3031504cu;
+
+struct Lp10Codes {
+  uint32_t a[4];       // sign|mantissa bytes
+  uint32_t b0, b1;     // level-1 planes (16 bits)
+  uint32_t l2;         // level-2 codes of the level-1 escapes, 2 bits each, in value order
+  uint64_t l3;         // level-3 nibbles of the level-2 escapes, in value order
+  int n2, n3;
+  uint32_t esc_mask;   // values that need an escape record
+};
+
+__device__ __forceinline__ Lp10Codes lp10_codes(const uint32_t (&w)[8], uint32_t sym1, uint32_t sym2, uint32_t e3) {
+  Lp10Codes r;
+  r.a[0] = r.a[1] = r.a[2] = r.a[3] = 0; r.b0 = r.b1 = 0; r.l2 = 0; r.l3 = 0; r.n2 = r.n3 = 0; r.esc_mask = 0;
+  const uint32_t s10 = sym1 & 0xff, s11 = (sym1 >> 8) & 0xff, s12 = (sym1 >> 16) & 0xff;
+  const uint32_t s20 = sym2 & 0xff, s21 = (sym2 >> 8) & 0xff, s22 = (sym2 >> 16) & 0xff;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t x = (w[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+    const uint32_t ex = (x >> 7) & 0xff;
+    const uint32_t c1 = ex == s10 ? 0u : ex == s11 ? 1u : ex == s12 ? 2u : 3u;
+    r.b0 |= (c1 & 1) << k; r.b1 |= (c1 >> 1) << k;
+    if (c1 == 3) {
+      const uint32_t c2 = ex == s20 ? 0u : ex == s21 ? 1u : ex == s22 ? 2u : 3u;
+      r.l2 |= c2 << (2 * r.n2);
+      ++r.n2;
+      if (c2 == 3) {
+        uint32_t nib = ex - e3;
+        if (ex == 0) nib = 14;
+        else if (nib > 13) { nib = 15; r.esc_mask |= 1u << k; }
+        r.l3 |= (uint64_t)nib << (4 * r.n3);
+        ++r.n3;
+      }
+    }
+    r.a[k >> 2] |= (((x >> 8) & 0x80) | (x & 0x7f)) << ((k & 3) * 8);
+  }
+  return r;
+}
+
+__device__ __forceinline__ void lp10_load16(const bf16_t* p, uint32_t (&w)[8]) {
+  const uint4 v0 = *(const uint4*)p, v1 = *(const uint4*)(p + 8);
+  w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+}
+
+// pass 1: level-2 and level-3 code counts per 1024-value block
+__global__ __launch_bounds__(256) void lia_pack10_count_kernel(const bf16_t* __restrict__ src, char* __restrict__ dst) {
+  LiaPack10Header* hd = (LiaPack10Header*)dst;
+  const size_t nblk = hd->n / 1024;
+  uint32_t* tab2 = (uint32_t*)(dst + hd->off_tab2);
+  uint32_t* tab3 = (uint32_t*)(dst + hd->off_tab3);
+  const uint32_t sym1 = hd->sym1, sym2 = hd->sym2, e3 = hd->e3;
+  const int lane = threadIdx.x & 63;
+  size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t stride = (size_t)gridDim.x * 4;
+  for (; blk < nblk; blk += stride) {
+    uint32_t w[8];
+    lp10_load16(src + blk * 1024 + lane * 16, w);
+    const Lp10Codes c = lp10_codes(w, sym1, sym2, e3);
+    int t2, t3;
+    (void)wave_excl_scan(c.n2, lane, t2);
+    (void)wave_excl_scan(c.n3, lane, t3);
+    if (lane == 0) { tab2[blk] = (uint32_t)t2; tab3[blk] = (uint32_t)t3; }
+  }
+}
+
+// exclusive scan of one offset table in place (one workgroup); the total goes to *total_out
+__global__ __launch_bounds__(1024) void lia_pack10_scan_kernel(char* __restrict__ dst, int which) {
+  LiaPack10Header* hd = (LiaPack10Header*)dst;
+  const size_t nblk = hd->n / 1024;
+  uint32_t* tab = (uint32_t*)(dst + (which == 2 ? hd->off_tab2 : hd->off_tab3));
+  __shared__ uint32_t wsum[16];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t base = 0; base < nblk; base += 1024) {
+    const size_t i = base + threadIdx.x;
+    int v = i < nblk ? (int)tab[i] : 0;
+    int wtot;
+    int ex = wave_excl_scan(v, lane, wtot);
+    if (lane == 63) wsum[wave] = (uint32_t)wtot;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < wave; ++k) woff += wsum[k];
+    const unsigned long long c = carry;
+    if (i < nblk) tab[i] = (uint32_t)(c + woff + ex);
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + woff + ex + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { if (which == 2) hd->n_l2 = carry; else hd->n_l3 = carry; }
+}
+
+// OR `bits` (nbits <= 64 significant) into a zeroed 32-bit-word stream at bit offset `bitoff`
+__device__ __forceinline__ void lp10_or_bits(uint32_t* stream, uint64_t bitoff, uint64_t bits, int nbits) {
+  const uint64_t word = bitoff >> 5;
+  const int sh = (int)(bitoff & 31);
+  atomicOr(&stream[word], (uint32_t)(bits << sh));
+  const uint64_t rest = sh ? (bits >> (32 - sh)) : (bits >> 32);
+  if (nbits + sh > 32) atomicOr(&stream[word + 1], (uint32_t)rest);
+  if (nbits + sh > 64) atomicOr(&stream[word + 2], (uint32_t)(rest >> 32));
+}
+
+// pass 2: planes, level-2 / level-3 streams (atomicOr into zeroed streams), escape records
+__global__ __launch_bounds__(256) void lia_pack10_encode_kernel(const bf16_t* __restrict__ src, char* __restrict__ dst) {
+  LiaPack10Header* hd = (LiaPack10Header*)dst;
+  const size_t nblk = hd->n / 1024;
+  uint8_t* pa = (uint8_t*)(dst + hd->off_a);
+  uint16_t *p0 = (uint16_t*)(dst + hd->off_b0), *p1 = (uint16_t*)(dst + hd->off_b1);
+  const uint32_t* tab2 = (const uint32_t*)(dst + hd->off_tab2);
+  const uint32_t* tab3 = (const uint32_t*)(dst + hd->off_tab3);
+  uint32_t* l2w = (uint32_t*)(dst + hd->off_l2);
+  uint32_t* l3w = (uint32_t*)(dst + hd->off_l3);
+  uint2* esc = (uint2*)(dst + hd->off_esc);
+  const uint32_t sym1 = hd->sym1, sym2 = hd->sym2, e3 = hd->e3;
+  const int lane = threadIdx.x & 63;
+  size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t stride = (size_t)gridDim.x * 4;
+  for (; blk < nblk; blk += stride) {
+    const size_t g = blk * 64 + lane;           // 16-value group index
+    uint32_t w[8];
+    lp10_load16(src + g * 16, w);
+    const Lp10Codes c = lp10_codes(w, sym1, sym2, e3);
+    *(uint4*)(pa + g * 16) = uint4{c.a[0], c.a[1], c.a[2], c.a[3]};
+    p0[g] = (uint16_t)c.b0; p1[g] = (uint16_t)c.b1;
+    int t2, t3;
+    const int ex2 = wave_excl_scan(c.n2, lane, t2);
+    const int ex3 = wave_excl_scan(c.n3, lane, t3);
+    if (c.n2) {
+      const uint64_t off = (uint64_t)tab2[blk] + ex2;
+      if (off + c.n2 > hd->l2_cap) hd->overflow = 1;
+      else lp10_or_bits(l2w, off * 2, c.l2, 2 * c.n2);
+    }
+    if (c.n3) {
+      const uint64_t off = (uint64_t)tab3[blk] + ex3;
+      if (off + c.n3 > hd->l3_cap) hd->overflow = 1;
+      else lp10_or_bits(l3w, off * 4, c.l3, 4 * c.n3);
+    }
+    uint32_t m = c.esc_mask;
+    while (m) {
+      const int k = __ffs(m) - 1;
+      m &= m - 1;
+      const uint32_t x = (w[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+      unsigned slot = atomicAdd(&hd->n_esc, 1u);
+      if (slot < hd->esc_cap) esc[slot] = uint2{(uint32_t)(g * 16 + k), x};
+      else hd->overflow = 1;
+    }
+  }
+}
+
+// up to 64 bits starting at any bit of a 32-bit-word stream (the stream is padded by >= 16 bytes)
+__device__ __forceinline__ uint64_t lp10_get_bits(const uint32_t* stream, uint64_t bitoff, int nbits) {
+  const uint64_t word = bitoff >> 5;
+  const int sh = (int)(bitoff & 31);
+  const uint64_t lo = (uint64_t)stream[word] | ((uint64_t)stream[word + 1] << 32);
+  uint64_t v = lo >> sh;
+  if (sh && nbits + sh > 64) v |= (uint64_t)stream[word + 2] << (64 - sh);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void lia_pack10_decode_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
+  const LiaPack10Header* hd = (const LiaPack10Header*)src;
+  const size_t nblk = hd->n / 1024;
+  const uint32_t sym1 = hd->sym1, sym2 = hd->sym2, e3 = hd->e3;
+  const uint8_t* pa = (const uint8_t*)(src + hd->off_a);
+  const uint16_t *p0 = (const uint16_t*)(src + hd->off_b0), *p1 = (const uint16_t*)(src + hd->off_b1);
+  const uint32_t* tab2 = (const uint32_t*)(src + hd->off_tab2);
+  const uint32_t* tab3 = (const uint32_t*)(src + hd->off_tab3);
+  const uint32_t* l2w = (const uint32_t*)(src + hd->off_l2);
+  const uint32_t* l3w = (const uint32_t*)(src + hd->off_l3);
+  const int lane = threadIdx.x & 63;
+  size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t stride = (size_t)gridDim.x * 4;
+  for (; blk < nblk; blk += stride) {
+    const size_t g = blk * 64 + lane;
+    const uint4 av = *(const uint4*)(pa + g * 16);
+    const uint32_t a[4] = {av.x, av.y, av.z, av.w};
+    const uint32_t b0 = p0[g], b1 = p1[g];
+    const uint32_t esc1 = b0 & b1;
+    const int n2 = __popc(esc1);
+    int t2;
+    const int ex2 = wave_excl_scan(n2, lane, t2);
+    uint32_t l2 = 0;
+    if (n2) l2 = (uint32_t)lp10_get_bits(l2w, ((uint64_t)tab2[blk] + ex2) * 2, 2 * n2);
+    if (n2 < 16) l2 &= (1u << (2 * n2)) - 1u;
+    const int n3 = __popc(l2 & (l2 >> 1) & 0x55555555u);
+    int t3;
+    const int ex3 = wave_excl_scan(n3, lane, t3);
+    uint64_t l3 = 0;
+    if (n3) l3 = lp10_get_bits(l3w, ((uint64_t)tab3[blk] + ex3) * 4, 4 * n3);
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t sm = (a[k >> 2] >> ((k & 3) * 8)) & 0xff;
+      const uint32_t c1 = ((b0 >> k) & 1) | (((b1 >> k) & 1) << 1);
+      uint32_t ex;
+      if (c1 < 3) ex = (sym1 >> (8 * c1)) & 0xff;
+      else {
+        const uint32_t c2 = l2 & 3;
+        l2 >>= 2;
+        if (c2 < 3) ex = (sym2 >> (8 * c2)) & 0xff;
+        else {
+          const uint32_t nib = (uint32_t)(l3 & 0xf);
+          l3 >>= 4;
+          ex = nib < 14 ? e3 + nib : 0;      // 14: exponent 0; 15: placeholder, patched from the escape records
+        }
+      }
+      const uint32_t x = ((sm & 0x80) << 8) | (ex << 7) | (sm & 0x7f);
+      if (k & 1) o[k >> 1] |= x << 16; else o[k >> 1] = x;
+    }
+    *(uint4*)(dst + g * 16) = uint4{o[0], o[1], o[2], o[3]};
+    *(uint4*)(dst + g * 16 + 8) = uint4{o[4], o[5], o[6], o[7]};
+  }
+}
+
+__global__ __launch_bounds__(256) void lia_pack10_patch_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
+  const LiaPack10Header* hd = (const LiaPack10Header*)src;
+  const uint2* esc = (const uint2*)(src + hd->off_esc);
+  const unsigned n = hd->n_esc;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    uint2 r = esc[i];
+    dst[r.x] = (bf16_t)r.y;
+  }
+}
+
+// room an encode may need: level 2 up to n codes, level 3 up to n/2 nibbles, escapes n/16 records
+extern "C" size_t lia_pack10_bound(size_t n_values) {
+  return 256 + lp12_align(n_values) + 2 * lp12_align(n_values / 8) + 2 * lp12_align((n_values / 1024) * 4 + 16) +
+         2 * lp12_align(n_values / 4 + 16) + lp12_align((n_values / 16) * 8);
+}
+
+// Same contract as lia_pack12_encode; n_values must be a multiple of 1024.  Returns 1 when the layer does not fit.
+extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, size_t dst_capacity, size_t* out_bytes) {
+  if (!src || !dst || !out_bytes || (n_values % 1024) || dst_capacity < lia_pack10_bound(n_values)) return -1;
+  unsigned* hist = nullptr;
+  if (hipMalloc((void**)&hist, 256 * sizeof(unsigned)) != hipSuccess) return -2;
+  (void)hipMemset(hist, 0, 256 * sizeof(unsigned));
+  hipLaunchKernelGGL(lia_pack12_hist_kernel, dim3(1024), dim3(256), 0, 0, src, n_values, hist);
+  unsigned h[256];
+  if (hipMemcpy(h, hist, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(hist); return -3; }
+  (void)hipFree(hist);
+  // the six most frequent exponents, by count (ties: lower exponent first); never the same exponent twice
+  int top[6];
+  bool used[256] = {false};
+  for (int t = 0; t < 6; ++t) {
+    int best = -1;
+    for (int e = 0; e < 256; ++e)
+      if (!used[e] && (best < 0 || h[e] > h[best])) best = e;
+    top[t] = best; used[best] = true;
+  }
+  // level-3 window: the 14 consecutive exponents (>= 1) that cover most of what is left
+  int e3 = 1;
+  {
+    unsigned long long best = 0;
+    for (int s = 1; s <= 255 - 14 + 1; ++s) {
+      unsigned long long cur = 0;
+      for (int k = 0; k < 14; ++k) cur += used[s + k] ? 0 : h[s + k];
+      if (cur > best) { best = cur; e3 = s; }
+    }
+  }
+  LiaPack10Header hd;
+  memset(&hd, 0, sizeof(hd));
+  hd.magic = LP10_MAGIC;
+  hd.sym1 = (uint32_t)top[0] | ((uint32_t)top[1] << 8) | ((uint32_t)top[2] << 16);
+  hd.sym2 = (uint32_t)top[3] | ((uint32_t)top[4] << 8) | ((uint32_t)top[5] << 16);
+  hd.e3 = (uint32_t)e3; hd.n = n_values;
+  hd.esc_cap = (uint32_t)(n_values / 16); hd.l2_cap = n_values; hd.l3_cap = n_values / 2;
+  const size_t tab_bytes = lp12_align((n_values / 1024) * 4 + 16);
+  const size_t l2_bytes = lp12_align(n_values / 4 + 16), l3_bytes = lp12_align(n_values / 4 + 16);
+  hd.off_a = 256; hd.off_b0 = hd.off_a + lp12_align(n_values); hd.off_b1 = hd.off_b0 + lp12_align(n_values / 8);
+  hd.off_tab2 = hd.off_b1 + lp12_align(n_values / 8); hd.off_tab3 = hd.off_tab2 + tab_bytes;
+  // provisional stream positions at full capacity; compacted below once the real sizes are known
+  hd.off_l2 = hd.off_tab3 + tab_bytes; hd.off_l3 = hd.off_l2 + l2_bytes; hd.off_esc = hd.off_l3 + l3_bytes;
+  if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
+  (void)hipMemset(dst + hd.off_l2, 0, l2_bytes + l3_bytes);
+  hipLaunchKernelGGL(lia_pack10_count_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
+  hipLaunchKernelGGL(lia_pack10_scan_kernel, dim3(1), dim3(1024), 0, 0, dst, 2);
+  hipLaunchKernelGGL(lia_pack10_scan_kernel, dim3(1), dim3(1024), 0, 0, dst, 3);
+  hipLaunchKernelGGL(lia_pack10_encode_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
+  if (hipMemcpy(&hd, dst, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  if (hd.overflow || hd.n_esc > hd.esc_cap || hd.n_l2 > hd.l2_cap || hd.n_l3 > hd.l3_cap) return 1;
+  // compact: level 3 right behind the level-2 bytes in use, escape records right behind level 3 (downward moves, in order)
+  const size_t used_l2 = lp12_align((size_t)((hd.n_l2 + 3) / 4) + 16);
+  const size_t used_l3 = lp12_align((size_t)((hd.n_l3 + 1) / 2) + 16);
+  const size_t new_l3 = hd.off_l2 + used_l2, new_esc = new_l3 + used_l3;
+  if (!lp_move_down(dst, new_l3, hd.off_l3, used_l3)) return -3;
+  if (!lp_move_down(dst, new_esc, hd.off_esc, (size_t)hd.n_esc * 8)) return -3;
+  hd.off_l3 = new_l3; hd.off_esc = new_esc;
   if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
   *out_bytes = (size_t)hd.off_esc + lp12_align((size_t)hd.n_esc * 8);
   return 0;
@@ -434,7 +764,14 @@ extern "C" int lia_pack11_encode(const bf16_t* src, size_t n_values, char* dst, 
 
 // Decode either format (the header's magic says which); asynchronous on `st`.
 extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st) {
-  if (format == 11) {
+  if (format == 10) {
+    size_t nblk = n_values / 1024;
+    unsigned blocks = (unsigned)((nblk + 3) / 4);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(lia_pack10_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
+    hipLaunchKernelGGL(lia_pack10_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
+  } else if (format == 11) {
     size_t nblk = n_values / 1024;
     unsigned blocks = (unsigned)((nblk + 3) / 4);
     if (blocks > 8192) blocks = 8192;

@@ -134,8 +134,9 @@ class LayerStore:
             src = tmp
         else:
             src = self._dev
-        bound, encode = ((self._lib.lia_pack11_bound, self._lib.lia_pack11_encode) if fmt == 11 else
-                         (self._lib.lia_pack12_bound, self._lib.lia_pack12_encode))
+        bound, encode = {10: (self._lib.lia_pack10_bound, self._lib.lia_pack10_encode),
+                         11: (self._lib.lia_pack11_bound, self._lib.lia_pack11_encode),
+                         12: (self._lib.lia_pack12_bound, self._lib.lia_pack12_encode)}[fmt]
         cap = bound(self.nbytes // 2)
         enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
         out = ctypes.c_size_t()
@@ -144,6 +145,8 @@ class LayerStore:
             return None            # too many out-of-window values: ship this layer raw
         if rc != 0:
             raise N.LiaHipError(f"lia_pack{fmt}_encode failed ({rc})")
+        if out.value >= self.nbytes:
+            return None            # the encoding is no smaller than the raw layer (very wide distribution): ship raw
         return enc, out.value
 
     def to_pinned(self, pack12=False):
@@ -155,8 +158,8 @@ class LayerStore:
                 raise ValueError("layer is pinned in a packed wire format but the raw bf16 copy was requested")
             return            # already pinned (a raw copy also serves a packed request: it simply ships more bytes)
         enc = None
-        if fmt == 11 and self.nbytes % 2048 == 0:
-            enc = self._encode_packed(11)
+        if fmt in (10, 11) and self.nbytes % 2048 == 0:
+            enc = self._encode_packed(fmt)
         elif fmt == 12 and self.nbytes % 32 == 0:
             enc = self._encode_packed(12)
         nbytes = enc[1] if enc else self.nbytes

@@ -89,7 +89,8 @@ class WeightPipeline:
         N.check(self.lib.lia_stream_begin(self.handle, slot), "lia_stream_begin")
         if packed:
             if self.staging_tensors is None:
-                cap = max(self.lib.lia_pack12_bound(self.model.layer_bytes // 2), self.lib.lia_pack11_bound(self.model.layer_bytes // 2))
+                cap = max(self.lib.lia_pack12_bound(self.model.layer_bytes // 2), self.lib.lia_pack11_bound(self.model.layer_bytes // 2),
+                          self.lib.lia_pack10_bound(self.model.layer_bytes // 2))
                 self.staging_tensors = [RawDeviceBuffer(self.lib.lia_stream_staging_ptr(self.handle, s), cap).tensor()
                                         for s in range(self.n_slots)]
             target, copy_fn = self.staging_tensors[slot][:nbytes], self.lib.lia_stream_copy_chunk_packed
@@ -172,7 +173,7 @@ class OffloadScheduler:
         self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "4"))
         # wire format of the streamed layers: "pack12" (lossless 12-bit encoding, lia_pack12.hip) or "raw" bf16
         fmt = os.environ.get("LIA_STREAM_FORMAT", "raw").lower() if pack12 is None else pack12
-        self.pack12 = {"raw": 0, "pack12": 12, "pack11": 11, False: 0, True: 12, 0: 0, 11: 11, 12: 12}[fmt]
+        self.pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, False: 0, True: 12, 0: 0, 10: 10, 11: 11, 12: 12}[fmt]
         self.ctx = None
         self.ws_rows = 0
         self.pipe = None

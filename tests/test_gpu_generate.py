@@ -48,7 +48,7 @@ FLAG_SETS = [
 
 @pytest.mark.parametrize("name", GEN_CASES)
 @pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k[:4]}{int(v)}" for k, v in f.items()) or "defaults")
-@pytest.mark.parametrize("fmt", ["raw", "pack12", "pack11"])
+@pytest.mark.parametrize("fmt", ["raw", "pack12", "pack11", "pack10"])
 def test_generate_ids_match_hf_golden(name, flags, fmt, monkeypatch):
     import torch
     from lia_amd.generation import generate
