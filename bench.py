@@ -129,14 +129,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    # LIA_DP_SAME_GPU=1 (validation only, with LIA_DP_BACKEND=gloo): several ranks share one GPU, so the whole
+    # batch-shard path (remote tiers, chunked broadcast into staging, decode on non-root ranks) runs on a 1-GPU box
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if os.environ.get("LIA_DP_SAME_GPU") == "1" else local_rank
+    backend = os.environ.get("LIA_DP_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     dist = None
     force_dp = os.environ.get("LIA_FORCE_DP") == "1"      # exercise the broadcast path on a single GPU (world 1)
     if world > 1 or force_dp:
         import torch.distributed as dist
         if "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from lia_amd.model import LiaOPTModel, resolve_shape
     from lia_amd.generation import LIA_KWARGS  # noqa: F401
@@ -166,13 +173,13 @@ def main():
         group.pin_host_threads()
     if is_llama:
         model = LiaLlamaModel.random_init(shape, seed=0, n_gpu_layers=n_gpu)
-        sched = LlamaScheduler(model, device=local_rank)
+        sched = LlamaScheduler(model, device=dev_index)
         KVState = lambda mdl, ng, b, s: LlamaKVState(mdl, b, s)  # noqa: E731,F811
     else:
         pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[a.stream_format] if not a.enable_cxl else 0
         model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
                                         host_owner=(group is None or group.is_root), pack12=pack12)
-        sched = OffloadScheduler(model, device=local_rank, dp_group=group, pack12=pack12)
+        sched = OffloadScheduler(model, device=dev_index, dp_group=group, pack12=pack12)
     from lia_amd import hostinfo
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
     g = torch.Generator().manual_seed(0)
@@ -229,7 +236,7 @@ def main():
     h2d_bytes, h2d_ms = sched.stream_stats()
 
     if dist is not None:
-        tmax = torch.tensor([elapsed, prefill_ms], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed, prefill_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, prefill_ms = float(tmax[0]), float(tmax[1])
 

@@ -1,0 +1,76 @@
+"""-m gpu: the batch-shard data-parallel path end to end with TWO ranks sharing the one GPU of the test box.
+Each rank runs the real OffloadScheduler (HIP kernels, streamer, staging + decode of the packed wire formats); the
+root owns the host copy of the streamed layers, the other rank's layers are "remote" and arrive only through the
+chunked per-layer broadcast.  The collective backend here is gloo (RCCL refuses two ranks on one device); the
+scheduler code is the same one `bench.py --gpus N` runs over RCCL.  The gathered ids must equal the HF golden ids."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage):
+    for p in (ROOT, os.path.join(ROOT, "isca-2025-lia_amd"), GOLD):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIA_DP_CHUNK_BYTES=str(96 * 1024))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth
+        from lia_amd import dp
+        from lia_amd.generation import generate
+        from lia_amd.model import LiaOPTModel, OPTShape
+        from lia_amd.scheduler import OffloadScheduler
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        vocab, max_pos, H, heads, F, L, B, T, new, seed = [int(v) for v in z["cfg"]]
+        m = synth.make_model(seed, vocab, max_pos, H, F, L, float(z["w_std"][0]))
+        ids = synth.make_prompt_ids(seed + 1, B, T, vocab)
+        shape = OPTShape("test", H, heads, F, L, vocab=vocab, max_pos=max_pos)
+        model = LiaOPTModel.from_numpy(shape, m)
+        n_gpu = int(L * gpu_percentage / 100)
+        g = dp.DataParallelGroup(dist, rank, world, rank)
+        if not g.is_root:
+            for li, st in enumerate(model.layers):
+                if li >= n_gpu:
+                    st._free()
+                    st._np = None
+                    st.tier = "remote"          # this rank never sees the host copy
+        model._lia_scheduler = OffloadScheduler(model, device=0, dp_group=g, pack12=fmt)
+        mine = g.shard(torch.from_numpy(ids))
+        lo, hi = dp.shard_rows(B, rank, world)
+        out = generate(model, mine, max_new_tokens=new, min_new_tokens=new, prefill_policy=0, decoding_policy=2,
+                       gpu_percentage=gpu_percentage, pin_weight=True)
+        assert (out.numpy() == z["ids_bf16"][lo:hi]).all(), (rank, out[:, T:].tolist())
+        full = g.gather_ids(out, B)
+        assert (full.numpy() == z["ids_bf16"]).all()
+        if not g.is_root:
+            assert all(st.tier == "remote" for st in model.layers[n_gpu:])
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+        model._lia_scheduler.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fmt", ["raw", "pack10"])
+@pytest.mark.parametrize("gpu_percentage", [0, 50])
+def test_two_ranks_one_gpu_match_golden(tmp_path, fmt, gpu_percentage):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), fmt, "generate_h256", gpu_percentage), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
