@@ -14,6 +14,7 @@
 //   * tiled   (prefill, M in the thousands): MFMA bound.  128x128x64 tiles, LDS-DMA staging
 //     (global_load_lds, 16 B/lane) with the XOR swizzle applied on the SOURCE address
 //     (cdna_hip_programming.md rule 21), double-buffered, XCD-aware tile order.
+#include <cstdio>
 #include "lia_common.h"
 
 #define GL_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -447,9 +448,161 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// tiled regime, large, staggered ("ping-pong") schedule.  Same 256 x 256 x 64 tile, wave layout, swizzle idea and
+// epilogue as lia_gemm_tiled256_kernel, but the K-tile is staged as two 32-deep halves (64-byte LDS rows) and the
+// two wave groups (waves 0-3 = m rows 0-127, waves 4-7 = m rows 128-255; waves w and w+4 share a SIMD) run half a
+// phase apart: while one group issues the 32 MFMAs of a k-step the other reads its 12 fragments and issues LDS-DMA,
+// so the MFMA pipe of every SIMD always has a wave to serve.  Four raw s_barriers per K-tile, no vmcnt(0) drain:
+//   R(t,0): ds_read k-step 0 | LDS-DMA pieces 4-7 of my half of tile t+1 | lgkmcnt(0) | barrier
+//   M(t,0): 32 MFMA | barrier
+//   R(t,1): ds_read k-step 1 | lgkmcnt(0) | barrier
+//   M(t,1): LDS-DMA pieces 0-3 of my half of tile t+2 | 32 MFMA | vmcnt(4): tile t+1 has landed | barrier
+// Group 0 stages the k-step-0 halves, group 1 the k-step-1 halves; group 1 starts one barrier late.
+// Ordering (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  a half is read at the earliest in the interval after the barrier that follows its stager's vmcnt;
+//   WAR  a region is re-staged only after a barrier that every reader passed with lgkmcnt(0) already done.
+// LDS: 2 buffers x 2 halves x (W 256 rows x 64 B + x 256 rows x 64 B) = 128 KB.
+// ---------------------------------------------------------------------------------------------
+constexpr int T3_HALF_BYTES = 2 * 256 * 64;   // one k-half of a tile: W part 16 KB + x part 16 KB
+
+__global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                  const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
+                                                                  int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buffer][half][W rows | x rows], 64-byte rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wn = wave & 3, wm = wave >> 2;   // wave tile: n rows [64 wn, +64), m rows [128 wm, +128)
+  const int grp = wm;                        // stagger group = the half of the tile's m rows
+  const int wg = wave & 3;                   // wave index inside its group
+
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  constexpr int GM = 8;
+  const int group = lin / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int in_g = lin - group * GM * tiles_n;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  const int m0 = tm * T2_BM, n0 = tn * T2_BN;
+
+  f32x4 acc[4][8];  // [n-block][m-block]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // -- staging: piece p (0..7) of a half = 64 rows of W (p < 4) or x (p >= 4); my wave moves rows [16 wg, +16) of
+  // it.  A lane carries 16 B: row lane>>2, LDS slot lane&3, which holds global chunk slot ^ swz(row), swz(row) =
+  // (-(row>>2)) & 3 (rows are 64 B, four to a 256-byte bank row; see the bank check at the fragment reads).
+  const int srow = wg * 16 + (lane >> 2);
+  const int schunk = (lane & 3) ^ ((-(lane >> 4)) & 3);
+  const long khalf = grp * 32 + schunk * 8;    // my group's k-half + the lane's chunk, in elements
+  const bf16_t* const wsrc0 = W + (long)min(n0 + srow, N - 1) * ldw + khalf;
+  const bf16_t* const wsrc1 = W + (long)min(n0 + 64 + srow, N - 1) * ldw + khalf;
+  const bf16_t* const wsrc2 = W + (long)min(n0 + 128 + srow, N - 1) * ldw + khalf;
+  const bf16_t* const wsrc3 = W + (long)min(n0 + 192 + srow, N - 1) * ldw + khalf;
+  const bf16_t* const xsrc0 = x + (long)min(m0 + srow, M - 1) * ldx + khalf;
+  const bf16_t* const xsrc1 = x + (long)min(m0 + 64 + srow, M - 1) * ldx + khalf;
+  const bf16_t* const xsrc2 = x + (long)min(m0 + 128 + srow, M - 1) * ldx + khalf;
+  const bf16_t* const xsrc3 = x + (long)min(m0 + 192 + srow, M - 1) * ldx + khalf;
+  char* const my_half = smem + grp * T3_HALF_BYTES + wg * 1024;
+  // (macros, not lambdas: a lambda that captures the fragment / accumulator arrays sends them to scratch)
+#define T3_STAGE_W(t)                                                                                                    \
+  do {                                                                                                                    \
+    char* dst_ = my_half + ((t) & 1) * 2 * T3_HALF_BYTES;                                                                 \
+    const long k0_ = (long)(t) * T2_BK;                                                                                   \
+    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc0 + k0_), LDS_AS3(dst_), 16, 0, 0);                                       \
+    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc1 + k0_), LDS_AS3(dst_ + 4096), 16, 0, 0);                                \
+    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc2 + k0_), LDS_AS3(dst_ + 8192), 16, 0, 0);                                \
+    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc3 + k0_), LDS_AS3(dst_ + 12288), 16, 0, 0);                               \
+  } while (0)
+#define T3_STAGE_X(t)                                                                                                    \
+  do {                                                                                                                    \
+    char* dst_ = my_half + ((t) & 1) * 2 * T3_HALF_BYTES + 16384;                                                         \
+    const long k0_ = (long)(t) * T2_BK;                                                                                   \
+    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc0 + k0_), LDS_AS3(dst_), 16, 0, 0);                                       \
+    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc1 + k0_), LDS_AS3(dst_ + 4096), 16, 0, 0);                                \
+    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc2 + k0_), LDS_AS3(dst_ + 8192), 16, 0, 0);                                \
+    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc3 + k0_), LDS_AS3(dst_ + 12288), 16, 0, 0);                               \
+  } while (0)
+
+  // -- fragment reads: lane (l15, lq) reads chunk lq of row 16 i + l15: slot lq ^ swz(row).  ds_read_b128 lane groups
+  // hold rows {0-3, 12-15} with chunk c and rows {4-11} with chunk c ^ 1; 16-byte slot in the bank row =
+  // 4 (row & 3) + (chunk ^ swz), and swz = (0, 3, 2, 1) per row quad makes the four quads land on four different slots.
+  const int frag_off = l15 * 64 + ((lq ^ ((-(l15 >> 2)) & 3)) << 4);
+  const char* const wfrag = smem + wn * 4096 + frag_off;
+  const char* const xfrag = smem + 16384 + wm * 8192 + frag_off;
+  bf16x8 a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7;
+#define T3_LD(p) __builtin_bit_cast(bf16x8, *(const uint4*)(p))
+#define T3_READ(t, half)                                                                                                 \
+  do {                                                                                                                    \
+    const int off_ = (((t) & 1) * 2 + (half)) * T3_HALF_BYTES;                                                            \
+    a0 = T3_LD(wfrag + off_); a1 = T3_LD(wfrag + off_ + 1024); a2 = T3_LD(wfrag + off_ + 2048); a3 = T3_LD(wfrag + off_ + 3072); \
+    b0 = T3_LD(xfrag + off_); b1 = T3_LD(xfrag + off_ + 1024); b2 = T3_LD(xfrag + off_ + 2048); b3 = T3_LD(xfrag + off_ + 3072); \
+    b4 = T3_LD(xfrag + off_ + 4096); b5 = T3_LD(xfrag + off_ + 5120); b6 = T3_LD(xfrag + off_ + 6144); b7 = T3_LD(xfrag + off_ + 7168); \
+  } while (0)
+#define T3_ROW(i, ai)                                                                                                    \
+  acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b0, acc[i][0], 0, 0, 0);                                        \
+  acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b1, acc[i][1], 0, 0, 0);                                        \
+  acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b2, acc[i][2], 0, 0, 0);                                        \
+  acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b3, acc[i][3], 0, 0, 0);                                        \
+  acc[i][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b4, acc[i][4], 0, 0, 0);                                        \
+  acc[i][5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b5, acc[i][5], 0, 0, 0);                                        \
+  acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b6, acc[i][6], 0, 0, 0);                                        \
+  acc[i][7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b7, acc[i][7], 0, 0, 0);
+#define T3_MMA()                                                                                                         \
+  do {                                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                                        \
+    T3_ROW(0, a0) T3_ROW(1, a1) T3_ROW(2, a2) T3_ROW(3, a3)                                                               \
+    __builtin_amdgcn_s_setprio(0);                                                                                        \
+  } while (0)
+#define T3_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define T3_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+  const int nk = K / T2_BK;
+  T3_STAGE_W(0); T3_STAGE_X(0);
+  if (nk > 1) { T3_STAGE_W(1); wait_vmcnt<4>(); } else wait_vmcnt<0>();
+  T3_BARRIER();
+  if (grp == 1) T3_BARRIER();      // the stagger
+  for (int t = 0; t < nk; ++t) {
+    // R(t,0)
+    T3_READ(t, 0);
+    if (t + 1 < nk) T3_STAGE_X(t + 1);
+    T3_LGKM0();
+    T3_BARRIER();
+    // M(t,0)
+    T3_MMA();
+    T3_BARRIER();
+    // R(t,1)
+    T3_READ(t, 1);
+    T3_LGKM0();
+    T3_BARRIER();
+    // M(t,1)
+    if (t + 2 < nk) T3_STAGE_W(t + 2);
+    T3_MMA();                        // (never inside a branch: hipcc then copies the accumulators and spills)
+    if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    if (t + 1 < nk || grp == 0) T3_BARRIER();
+  }
+#undef T3_BARRIER
+#undef T3_LGKM0
+#undef T3_MMA
+#undef T3_ROW
+#undef T3_READ
+#undef T3_LD
+#undef T3_STAGE_W
+#undef T3_STAGE_X
+  // group 0's last barrier is group 1's R(nk-1,1) barrier: every LDS read of the workgroup is complete, no LDS-DMA is
+  // pending, and each wave's epilogue region is its own
+  epilogue_via_lds<8>(acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, M, N, ep, om, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------------------------
-static int g_tiled_variant = 256;
+// 256: one-barrier-per-K-tile kernel; 257: staggered kernel.  LIA_GEMM_TILED_VARIANT overrides (A/B runs, tests).
+static int g_tiled_variant = [] { const char* e = getenv("LIA_GEMM_TILED_VARIANT"); return e ? atoi(e) : 256; }();
 extern "C" void lia_gemm_set_tiled_variant(int v) { g_tiled_variant = v; }
 
 extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
@@ -549,6 +702,19 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   }
   if ((K % TL_BK) != 0) return -1;
   if (regime) *regime = 2;
+  if (M >= 1024 && N >= 512 && g_tiled_variant == 257) {
+    int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T3_HALF_BYTES);
+      attr_set = true;
+    }
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL(lia_gemm_tiled256s_kernel, dim3(tiles_m * tiles_n), dim3(512), 4 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N,
+                       K, tiles_m, tiles_n, *ep, *om);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    return 0;
+  }
   if (M >= 1024 && N >= 512 && g_tiled_variant == 256) {
     int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
     static bool attr_set = false;

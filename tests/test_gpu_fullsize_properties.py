@@ -56,12 +56,15 @@ def _x(big, B, T, identical=False, seed=1):
     torch = big["torch"]
     g = torch.Generator(device="cuda").manual_seed(seed)
     x = torch.randn((1 if identical else B, T, H), generator=g, device="cuda").to(torch.bfloat16)
-    return x.repeat(B, 1, 1).contiguous() if identical else x.contiguous()
+    x = x.repeat(B, 1, 1).contiguous() if identical else x.contiguous()
+    torch.cuda.synchronize()     # torch filled x on its own stream; the context launches on its compute stream
+    return x
 
 
 def _run(big, policy, x, kv, T, pos0, b0=0, rows=None):
     y = big["torch"].empty_like(x)
     B = x.shape[0]
+    big["torch"].cuda.synchronize()      # inputs / caches prepared by torch on its stream
     big["ctx"].layer_forward(big["desc"], policy, big["w"], x, y, kv, B, T, pos0, b0)
     big["ctx"].synchronize()
     if policy == 0:
@@ -132,6 +135,7 @@ def test_gemm_regimes_agree(big):
     x = torch.randn((1280, H), generator=g, device="cuda").to(torch.bfloat16)
     w = (0.02 * torch.randn((2048, H), generator=g, device="cuda")).to(torch.bfloat16)
     bias = (0.1 * torch.randn((2048,), generator=g, device="cuda")).to(torch.bfloat16)
+    torch.cuda.synchronize()     # the operands come from torch's stream, the GEMMs run on the context's
     y_big = ctx.linear(x, w, bias)
     y_mid = ctx.linear(x[:300].contiguous(), w, bias)
     y_small = ctx.linear(x[:256].contiguous(), w, bias)

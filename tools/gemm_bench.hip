@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
   struct Shape { const char* name; int N, K; };
   std::vector<Shape> shapes = {{"qkv", 21504, 7168}, {"out", 7168, 7168}, {"fc1", 28672, 7168}, {"fc2", 7168, 28672}, {"lm_head", 50272, 7168}};
   if (getenv("LLAMA")) shapes = {{"qkv", 6144, 4096}, {"o", 4096, 4096}, {"gate_up", 28672, 4096}, {"down", 4096, 14336}, {"lm_head", 128256, 4096}};
+  if (getenv("SHAPE")) { int n_, k_; sscanf(getenv("SHAPE"), "%d,%d", &n_, &k_); shapes = {{"custom", n_, k_}, {"dummy", 16, 128}}; }
   if (getenv("KSWEEP")) shapes = {{"k1792", 7168, 1792}, {"k3584", 7168, 3584}, {"k7168", 7168, 7168}, {"k14336", 7168, 14336}, {"k28672", 7168, 28672}, {"dummy", 16, 128}};
   const int NBUF = 4;
   size_t maxw = (size_t)128256 * 4096;
@@ -37,9 +38,35 @@ int main(int argc, char** argv) {
   fill_kernel<<<256, 256>>>(bias, 128256, 5); fill_kernel<<<2048, 256>>>(res, (size_t)M * 128256, 7);
   if (M > 256) shapes.pop_back();  // no lm_head in prefill (last position only)
   size_t ws_bytes = (size_t)8 * (M <= 256 ? M : 1) * 128256 * 4; CK(hipMalloc(&ws, ws_bytes));
+  if (getenv("ZERO")) { for (int i = 0; i < NBUF; ++i) CK(hipMemset(w[i], 0, maxw * 2)); CK(hipMemset(x, 0, (size_t)M * 28672 * 2)); }
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
+  if (getenv("CHECK")) {
+    // variant 257 against variant 256 on the same operands: the two kernels add the same products in the same order
+    // (k ascending inside one accumulator), so the outputs must be bit-identical
+    uint16_t* y2; CK(hipMalloc(&y2, (size_t)M * 50272 * 2));
+    std::vector<uint16_t> h1, h2;
+    for (auto& s : shapes) {
+      LiaEpilogue ep{bias, res, s.N, 0};
+      LiaOutMap om; memset(&om, 0, sizeof(om)); om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
+      for (int rep = 0; rep < 3; ++rep) {
+        om.base[0] = y; lia_gemm_set_tiled_variant(256);
+        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, 0, st, nullptr, nullptr, nullptr);
+        om.base[0] = y2; lia_gemm_set_tiled_variant(257);
+        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, 0, st, nullptr, nullptr, nullptr);
+        CK(hipStreamSynchronize(st));
+        size_t n = (size_t)M * s.N; h1.resize(n); h2.resize(n);
+        CK(hipMemcpy(h1.data(), y, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), y2, n * 2, hipMemcpyDeviceToHost));
+        size_t bad = 0, first = 0;
+        for (size_t i = 0; i < n; ++i) if (h1[i] != h2[i]) { if (!bad) first = i; ++bad; }
+        printf("%-8s M=%d N=%d K=%d rep %d: %zu mismatches", s.name, M, s.N, s.K, rep, bad);
+        if (bad) printf(" (first at m=%zu n=%zu: %04x vs %04x)", first / s.N, first % s.N, h1[first], h2[first]);
+        printf("\n");
+      }
+    }
+    return 0;
+  }
   for (auto& s : shapes) {
     LiaEpilogue ep{getenv("NOBIAS") ? nullptr : bias, getenv("NORES") ? nullptr : res, s.N, 0};
     LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
