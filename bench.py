@@ -246,7 +246,7 @@ def main():
         achieved = prof["skinny_bytes"] / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
         traffic, traffic_src = (pmc_traffic("lia_gemm_skinny2_kernel<4") if (a.model == "opt-30b" and B == 64) else (None, None))
         out = {
-            "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if (a.model == "opt-30b" and B == 64 and T == 256)
+            "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if (a.model == "opt-30b" and B == 64 and T == 256 and a.gpu_percentage == 10)
                       else f"decode tokens/s (+ prefill ms), {a.model} bs={B} in{T} gpu%={a.gpu_percentage}",
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Spad = (S + 3) & ~3;
   float* sc = (float*)smem;                                   // [G][Spad] scores -> probabilities
-  float* red = sc + (size_t)G * Spad;                         // [KPP][G][D] partial outputs
-  float* scratch = red + (size_t)KPP * G * D;                 // [G][8]
+  float* red = sc + (size_t)G * Spad;                         // [4 waves][G][D] partial outputs
+  float* scratch = red + (size_t)4 * G * D;                   // [G][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kh = blockIdx.x, b = blockIdx.y;
   const long kv_row = (long)Bc * kv_heads * D;
@@ -304,15 +304,28 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
       }
     }
   }
+  // the key slots of one wave are folded with shuffles (a [KPP][G][D] LDS slab would cap the CU at three workgroups;
+  // with [4][G][D] a B = 128, 8-kv-head launch is resident in one round), then the four waves through LDS
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[((size_t)kslot * G + g) * D + 8 * sub + e] = o[g][e];
+    for (int e = 0; e < 8; ++e) {
+      float v = o[g][e];
+#pragma unroll
+      for (int off = LPK; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+      o[g][e] = v;
+    }
+  if (lane < LPK) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[((size_t)wave * G + g) * D + 8 * sub + e] = o[g][e];
+  }
   __syncthreads();
   for (int idx = tid; idx < G * D; idx += 256) {
     const int g = idx / D, dd = idx - g * D;
-    float acc = 0.f;
-    for (int k = 0; k < KPP; ++k) acc += red[((size_t)k * G + g) * D + dd];
+    const float acc = (red[(size_t)g * D + dd] + red[((size_t)G + g) * D + dd]) +
+                      (red[((size_t)2 * G + g) * D + dd] + red[((size_t)3 * G + g) * D + dd]);
     out[(long)b * ldo + (long)(kh * G + g) * D + dd] = f2bf(acc);
   }
 }
@@ -340,7 +353,8 @@ static int launch_decode(const bf16_t* q, long ldq, const bf16_t* kc, const bf16
   dim3 grid(kv_heads, B);
   const int kpp = 256 / (D / 8);
   const int Spad = (S + 3) & ~3;
-  size_t lds = ((size_t)G * Spad + (size_t)kpp * G * D + (size_t)G * 8) * sizeof(float);
+  (void)kpp;
+  size_t lds = ((size_t)G * Spad + (size_t)4 * G * D + (size_t)G * 8) * sizeof(float);
   if (lds > 160 * 1024) return -1;
 #define LIA_DEC(GV)                                                                                                            \
   {                                                                                                                            \
