@@ -94,9 +94,23 @@ __global__ __launch_bounds__(256) void lia_argmax_kernel(const bf16_t* __restric
   const bf16_t* row = logits + (long)blockIdx.x * vocab;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < vocab; i += 256) {
-    float f = i == suppress ? -INFINITY : bf2f(row[i]);
-    if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+  if ((vocab & 7) == 0) {
+    // rows are 16-byte aligned: 8 logits per load, indices ascending inside a lane so ties keep the first one
+    for (int i = threadIdx.x * 8; i < vocab; i += 256 * 8) {
+      const uint4 v = *(const uint4*)(row + i);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = i + e;
+        const float f = idx == suppress ? -INFINITY : bf2f((w[e >> 1] >> ((e & 1) * 16)) & 0xffff);
+        if (f > best || (f == best && idx < bi)) { best = f; bi = idx; }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < vocab; i += 256) {
+      float f = i == suppress ? -INFINITY : bf2f(row[i]);
+      if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -176,6 +176,9 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int n_tile = blockIdx.x * BN;
+  const int m_base = blockIdx.z * XR;               // grid.z > 1: the x rows are cut into blocks of 16 MT
+  x += (long)m_base * ldx;
+  const int Mloc = M - m_base;
   const int nchunks = K / S2_BK;
   const int c_begin = blockIdx.y * chunks_per_split;
   const int c_end = min(nchunks, c_begin + chunks_per_split);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
 #pragma unroll
   for (int r = 0; r < XL; ++r) {
     int row = srow + RR * r;
-    xsrc[r] = x + (long)min(min(row, XR - 1), M - 1) * ldx + ((sc ^ tl_swz(row)) << 3);
+    xsrc[r] = x + (long)min(min(row, XR - 1), Mloc - 1) * ldx + ((sc ^ tl_swz(row)) << 3);
   }
   auto issue = [&](int c, int stage) {
     char* st = smem + stage * STAGE;
@@ -261,13 +264,13 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
       float* pp = partial + (long)blockIdx.y * M * N;
 #pragma unroll
       for (int p = 0; p < MT; ++p) {
-        int m = 16 * p + l15;
+        int m = m_base + 16 * p + l15;
         if (m < M) *(f32x4*)(pp + (long)m * N + nn) = acc[t][p];
       }
     } else {
 #pragma unroll
       for (int p = 0; p < MT; ++p) {
-        int m = 16 * p + l15;
+        int m = m_base + 16 * p + l15;
         if (m < M) store_quad(acc[t][p], m, nn, ep, om);
       }
     }
@@ -616,7 +619,7 @@ static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw,
                            float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
   constexpr int BN = 16 * WAVES * RT, RR = 8 * WAVES;
   constexpr int XL = (16 * MT + RR - 1) / RR;
-  dim3 grid((N + BN - 1) / BN, split);
+  dim3 grid((N + BN - 1) / BN, split, (M + 16 * MT - 1) / (16 * MT));
   size_t lds = (size_t)S * (BN * 128 + XL * RR * 128);
   static bool attr_set = false;
   if (!attr_set) {
@@ -627,7 +630,8 @@ static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw,
                      split > 1 ? partial : nullptr, ep, om);
 }
 
-// experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row
+// experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row,
+// 3 = force the two-block x cut at 64 < M <= 128, 4 = forbid it
 static int g_skinny_variant = 0;
 extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
 
@@ -660,11 +664,19 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
       if (g_skinny_variant == 1) rt = 1;
       if (g_skinny_variant == 2 && M > 32 && M <= 128) { rt = 2; split = split2; }
     }
+    // 64 < M <= 128 with 128-row workgroups: cut the x rows into two blocks of 64 (grid.z = 2, MT = 4).  Each
+    // workgroup then stages half the x bytes, two fit a CU, and the second read of a weight tile comes from L2 / the
+    // Infinity Cache.  Worth it when the one-block grid cannot fill the chip (Llama-3-8B q/k/v, o, down at B = 128).
+    bool mcut = false;
     if (rt == 1) {
       const int BN = 16 * WAVES;
-      const int tiles = (N + BN - 1) / BN;
+      int tiles = (N + BN - 1) / BN;
+      if (M > 64 && M <= 128 && force_split <= 0 && (tiles * 4 <= 256 || g_skinny_variant == 3) && g_skinny_variant != 4) {
+        mcut = true;
+        tiles *= 2;
+      }
       // M <= 64: 3 stages x 24 KB -> two 8-wave workgroups per CU = 512 slots on the chip
-      const int slots = M <= 64 ? 512 : 256;
+      const int slots = (M <= 64 || mcut) ? 512 : 256;
       if (force_split > 0) {
         split = force_split;
       } else {
@@ -689,6 +701,7 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
       else launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     } else if (M <= 128) {
       if (rt == 2) launch_skinny2<8, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+      else if (mcut) launch_skinny2<4, 3, 0, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);   // default cache policy: the other x block re-reads W
       else launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     }
     else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);

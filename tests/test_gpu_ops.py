@@ -78,6 +78,8 @@ def test_layernorm(gpu, oracle, rows, H):
     (1024, 2304, 768, False, False, 0),
     # 256-row skinny workgroups (chosen when tiles x slices fill the chip): ragged M and N, split-K 2 and 3
     (100, 28672, 4096, True, False, 0), (50, 21520, 6144, False, True, 0),
+    # 64 < M <= 128 on a small grid: x rows cut into two blocks of 64 (grid.z = 2)
+    (100, 768, 1024, True, True, 0), (128, 4096, 2048, False, True, 0), (65, 272, 512, False, False, 0),
 ])
 def test_linear(gpu, oracle, M, N, K, relu, res, split):
     ctx, ops, torch = gpu
