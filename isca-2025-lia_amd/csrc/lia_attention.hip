@@ -14,6 +14,7 @@
 // the q|k|v GEMM epilogue has already scattered the fresh rows there -- so one kernel serves the
 // resident layers (device cache) and the streamed prefill (staging slab that is then copied to the
 // host cache).
+#include <cstdlib>
 #include "lia_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -193,6 +194,212 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// prefill, d = 128, second generation.  The arithmetic -- every product, rounding, max / sum update and its order -- is
+// that of lia_attn_prefill_kernel<128>, so the two kernels agree bit for bit; what changes is how the bytes move:
+//   * 64-key tiles (two 32-key blocks per barrier pair instead of one);
+//   * register-staged prefetch: the global loads of tile t+1 are issued before tile t is computed and written to LDS
+//     after the next barrier (cdna_hip_programming.md T14), so HBM / L2 latency hides behind the MFMAs;
+//   * V is staged row-major like K (two ds_write_b128 per thread instead of sixteen ds_write_b16) in the dual-use image
+//     off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) of T10, and the V^T operand is read with
+//     ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4-key x 16-dim block and
+//     receives one dim of the four keys.
+// ---------------------------------------------------------------------------------------------
+typedef short lia_v4s __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* __restrict__ q, long ldq,
+                                                                   const bf16_t* __restrict__ kc,
+                                                                   const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
+                                                                   long ldo, int T, int heads, int kv_heads, long kv_row,
+                                                                   long kv_batch, int b0, float scaling, int post_scale) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(16))) char k_lds[64 * 256];
+  __shared__ __attribute__((aligned(16))) char v_lds[64 * 256];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int hh = blockIdx.y, b = blockIdx.z;
+  const int q_wg = blockIdx.x * 128;
+  const int q_wave = q_wg + wave * 32;
+  const int kh = hh / (heads / kv_heads);
+  // kv_row / kv_batch: elements between consecutive positions / batch rows of K and V.  Seq-major cache [S][Bc][h][d]:
+  // (Bc h d, h d); token-major projection output [B][T][h][d]: (h d, T h d)
+  const bf16_t* kbase = kc + (long)(b0 + b) * kv_batch + (long)kh * D;
+  const bf16_t* vbase = vc + (long)(b0 + b) * kv_batch + (long)kh * D;
+  const float qscale = post_scale ? 1.0f : scaling;
+
+  bf16x8 qf[8];
+  {
+    const int qrow = min(q_wave + r, T - 1);
+    const bf16_t* qp = q + ((long)b * T + qrow) * ldq + (long)hh * D;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      uint4 v = *(const uint4*)(qp + 16 * s + 8 * h);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf2f(w[j] & 0xffff) * qscale, bf2f(w[j] >> 16) * qscale);
+      qf[s] = __builtin_bit_cast(bf16x8, uint4{o[0], o[1], o[2], o[3]});
+    }
+  }
+
+  const int n32 = min((q_wg + 128 + 31) / 32, (T + 31) / 32);   // 32-key blocks the workgroup needs (causal)
+  const int n64 = (n32 + 1) / 2;
+  const int my_q = q_wave + r;
+
+  // staging: thread -> key rr*16 + tid/16 of the tile, chunk tid%16 (a key row = 256 contiguous bytes over 16 lanes)
+  const int skey = tid >> 4, sc = tid & 15;
+  const int k_wr = skey * 256 + ((sc ^ skey) << 4);                                   // + rr * 4096 (key & 15 == skey)
+  const int v_wr = skey * 256 + ((sc ^ (((skey & 3) << 2) | ((skey >> 2) & 3))) << 4);  // + rr * 4096 (16 rr keeps both fields)
+  // K^T fragment read: key row 32 sb + r, chunk 2 s + h
+  const int k_rd = r * 256;
+  // V^T transposed read: group g1 = (lane >> 4) & 1 takes dims 16 g1 .. +15 of the 32-dim block; lane i = lane & 15 of the
+  // group addresses key q = i >> 2, columns 4 p .. 4 p + 3 (p = i & 3)
+  const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
+  int v_rd[2][4];     // [u][d]: byte offset of (key 4 h + 8 u + q, dims 32 d + 16 g1 + 4 p) in the swizzled image
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int key = 4 * h + 8 * u + tq;
+      const int ch = 4 * d + 2 * g1 + (tp >> 1);
+      v_rd[u][d] = 256 * key + 16 * (ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) + 8 * (tp & 1);
+    }
+
+#define P2_SCORES(kt32, sb, sacc)                                                                                     \
+  do {                                                                                                                \
+    sacc = f32x16{0};                                                                                                 \
+    _Pragma("unroll") for (int ss_ = 0; ss_ < 8; ++ss_) {                                                             \
+      uint4 kv_ = *(const uint4*)(k_lds + (sb) * 8192 + k_rd + (((2 * ss_ + h) ^ (r & 15)) << 4));                    \
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv_), qf[ss_], sacc, 0, 0, 0);        \
+    }                                                                                                                 \
+    const bool inside_ = (kt32) * 32 + 31 <= q_wave && (kt32) * 32 + 31 < T;   /* wave-uniform: nothing to mask */     \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                  \
+      int key_ = (kt32) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;                                                        \
+      float sv_ = rbf(sacc[i]);                                                                                       \
+      if (post_scale) sv_ = rbf(sv_ * scaling);                                                                       \
+      sacc[i] = (inside_ || (key_ <= my_q && key_ < T)) ? sv_ : -INFINITY;                                            \
+    }                                                                                                                 \
+  } while (0)
+
+  // (named registers and unconditional loads: an array filled under `if (t + 1 < n64)` is kept in scratch by hipcc)
+  uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
+#define P2_LD(base, t, rr) (*(const uint4*)((base) + (long)min((t) * 64 + (rr) * 16 + skey, T - 1) * kv_row + 8 * sc))
+#define P2_LOAD_K(t) do { const int t_ = min((t), n64 - 1); kreg0 = P2_LD(kbase, t_, 0); kreg1 = P2_LD(kbase, t_, 1); kreg2 = P2_LD(kbase, t_, 2); kreg3 = P2_LD(kbase, t_, 3); } while (0);
+#define P2_LOAD_V(t) do { const int t_ = min((t), n64 - 1); vreg0 = P2_LD(vbase, t_, 0); vreg1 = P2_LD(vbase, t_, 1); vreg2 = P2_LD(vbase, t_, 2); vreg3 = P2_LD(vbase, t_, 3); } while (0);
+#define P2_STORE_K() do { *(uint4*)(k_lds + k_wr) = kreg0; *(uint4*)(k_lds + 4096 + k_wr) = kreg1; *(uint4*)(k_lds + 8192 + k_wr) = kreg2; *(uint4*)(k_lds + 12288 + k_wr) = kreg3; } while (0);
+#define P2_STORE_V() do { *(uint4*)(v_lds + v_wr) = vreg0; *(uint4*)(v_lds + 4096 + v_wr) = vreg1; *(uint4*)(v_lds + 8192 + v_wr) = vreg2; *(uint4*)(v_lds + 12288 + v_wr) = vreg3; } while (0);
+
+  // ---- sweep 1: row max and sum of exp over all keys <= query ----
+  float m = -INFINITY, l = 0.f;
+  P2_LOAD_K(0)
+  for (int t = 0; t < n64; ++t) {
+    __syncthreads();
+    P2_STORE_K()
+    __syncthreads();
+    P2_LOAD_K(t + 1)      // (clamped: the last iteration re-reads its own tile)
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int kt = 2 * t + sb;
+      if (kt < n32 && kt * 32 <= q_wave + 31) {  // wave-uniform: block exists and is not entirely above the diagonal
+        f32x16 s;
+        P2_SCORES(kt, sb, s);
+        float tm = s[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tm = fmaxf(tm, s[i]);
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        float mn = fmaxf(m, tm);
+        if (mn > -INFINITY) {
+          float ts = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ts += __expf(s[i] - mn);
+          ts += __shfl_xor(ts, 32, 64);
+          l = l * __expf(m - mn) + ts;
+          m = mn;
+        }
+      }
+    }
+  }
+
+  // ---- sweep 2: P = bf16(exp(s - m) / l), O^T += V^T . P^T ----
+  // e / l for the 16 e of a block share l: the reciprocal and its Newton step are hoisted, the per-element part is
+  // the quotient + two residual corrections of the IEEE sequence hipcc emits for `/` (v_div_scale is the identity here:
+  // 1 <= l <= T, 0 <= e <= 1), i.e. the same correctly rounded quotient in 5 FMAs instead of ~11 instructions.
+  // (lia_attn_prefill_kernel keeps the plain `/`; tools/attn_ab.py compares the two kernels bit for bit.)
+  const float rl0 = __builtin_amdgcn_rcpf(l);
+  const float rl = __builtin_fmaf(__builtin_fmaf(-l, rl0, 1.0f), rl0, rl0);
+#define P2_DIV(e_, out_)                                                                                              \
+  do {                                                                                                                \
+    const float n_ = (e_);                                                                                            \
+    float q_ = n_ * rl;                                                                                               \
+    q_ = __builtin_fmaf(__builtin_fmaf(-l, q_, n_), rl, q_);                                                          \
+    out_ = __builtin_fmaf(__builtin_fmaf(-l, q_, n_), rl, q_);                                                        \
+  } while (0)
+  f32x16 oacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) oacc[d] = f32x16{0};
+  P2_LOAD_K(0)
+  P2_LOAD_V(0)
+  for (int t = 0; t < n64; ++t) {
+    __syncthreads();
+    P2_STORE_K()
+    P2_STORE_V()
+    __syncthreads();
+    P2_LOAD_K(t + 1)
+    P2_LOAD_V(t + 1)
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int kt = 2 * t + sb;
+      if (kt < n32 && kt * 32 <= q_wave + 31) {
+        f32x16 s;
+        P2_SCORES(kt, sb, s);
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float p0, p1;
+          P2_DIV(__expf(s[2 * i] - m), p0);
+          P2_DIV(__expf(s[2 * i + 1] - m), p1);
+          pk[i] = pack_bf16x2(p0, p1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[4 * ks], pk[4 * ks + 1], pk[4 * ks + 2], pk[4 * ks + 3]});
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            // keys 32 sb + 16 ks + 4 h + (0..3) -> elements 0..3, the same + 8 -> elements 4..7 (the k order of an
+            // accumulator tile used as an operand)
+            const char* vb = v_lds + (32 * sb + 16 * ks) * 256;
+            lia_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[0][d]));
+            lia_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[1][d]));
+            bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#undef P2_SCORES
+#undef P2_DIV
+#undef P2_LOAD_K
+#undef P2_LOAD_V
+#undef P2_LD
+#undef P2_STORE_K
+#undef P2_STORE_V
+
+  if (my_q < T) {
+    bf16_t* op = out + ((long)b * T + my_q) * ldo + (long)hh * D;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 o;
+        o.x = pack_bf16x2(oacc[d][4 * g], oacc[d][4 * g + 1]);
+        o.y = pack_bf16x2(oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
+        *(uint2*)(op + 32 * d + 8 * g + 4 * h) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // decode (T == 1): one workgroup per (batch row, KV head); KV-bandwidth bound.  The G = heads / kv_heads query
 // heads that share a KV head (grouped-query attention; G = 1 for OPT) are served together, so every K/V row is
 // read from HBM once.  LPK = D/8 lanes share one key row (16 bytes each); scores are parked in LDS, then every
@@ -330,6 +537,12 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   }
 }
 
+// 1: first-generation kernel, 2: lia_attn_prefill128_kernel (d = 128).  LIA_ATTN_PREFILL_VARIANT overrides.
+static int g_prefill_variant = [] { const char* e = getenv("LIA_ATTN_PREFILL_VARIANT"); return e ? atoi(e) : 2; }();
+extern "C" void lia_attn_set_prefill_variant(int v) { g_prefill_variant = v; }
+static int g_kv_token_major = 0;   // experiment (tools/attn_ab.py): K/V given as [B][T][h][d]
+extern "C" void lia_attn_set_kv_token_major(int v) { g_kv_token_major = v; }
+
 extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
                                        int B, int T, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
                                        hipStream_t st) {
@@ -338,7 +551,14 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
   dim3 grid((T + 127) / 128, heads, B);
   const float scaling = 1.0f / sqrtf((float)d);
   switch (d) {
-    case 128: hipLaunchKernelGGL(lia_attn_prefill_kernel<128>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
+    case 128:
+      if (g_prefill_variant == 2) {
+        const long hd = (long)kv_heads * 128;
+        if (g_kv_token_major) hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, hd, (long)T * hd, b0, scaling, post_scale);
+        else hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, post_scale);
+      }
+      else hipLaunchKernelGGL(lia_attn_prefill_kernel<128>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale);
+      break;
     case 64: hipLaunchKernelGGL(lia_attn_prefill_kernel<64>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
     case 32: hipLaunchKernelGGL(lia_attn_prefill_kernel<32>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
     default: return -1;
