@@ -176,7 +176,7 @@ def main():
         sched = LlamaScheduler(model, device=dev_index)
         KVState = lambda mdl, ng, b, s: LlamaKVState(mdl, b, s)  # noqa: E731,F811
     else:
-        pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[a.stream_format] if not a.enable_cxl else 0
+        pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[a.stream_format]
         model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
                                         host_owner=(group is None or group.is_root), pack12=pack12)
         sched = OffloadScheduler(model, device=dev_index, dp_group=group, pack12=pack12)
@@ -275,6 +275,7 @@ def main():
                                "mfma_frac": prof_prefill["tiled_flops"] / max(prof_prefill["tiled_ms"], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS,
                                "h2d_busy_ms": pre_h2d_ms, "h2d_gbs_while_busy": pre_h2d_bytes / max(pre_h2d_ms, 1e-9) / 1e6},
             "build_s": build_s,
+            "host_memory_gib": {k: (None if v is None else round(v / 2**30, 2)) for k, v in hostinfo.cgroup_memory().items()},
         }
         if world == 1 and not a.no_cpu_baseline and not is_llama:
             out["cpu_baseline"] = cpu_baseline(shape, B, T)

@@ -90,6 +90,30 @@ def host_memory_budget():
     return min(vals) if vals else None
 
 
+def cgroup_memory():
+    """{"current", "peak", "max"} bytes of the cgroup (None where unreadable): what a run really pinned / may pin."""
+    out = {}
+    for k in ("current", "peak", "max"):
+        try:
+            v = open(f"/sys/fs/cgroup/memory.{k}").read().strip()
+            out[k] = None if v == "max" else int(v)
+        except (OSError, ValueError):
+            out[k] = None
+    return out
+
+
+def guard_host_allocation(nbytes, what, ceiling=0.93):
+    """Per-allocation guard for pinned / registered host memory: refuse (MemoryError) when the cgroup would end up
+    above `ceiling` of its limit.  check_host_allocation() judges a plan up front; this one is called right before every
+    large pinned allocation, so an underestimated plan ends in an exception, never in a dead container."""
+    m = cgroup_memory()
+    if m["max"] is None or m["current"] is None:
+        return
+    if m["current"] + nbytes > ceiling * m["max"]:
+        raise MemoryError(f"{what}: {nbytes / 2**30:.2f} GiB more would put the container at "
+                          f"{(m['current'] + nbytes) / 2**30:.1f} GiB of its {m['max'] / 2**30:.1f} GiB limit; refusing")
+
+
 def check_host_allocation(nbytes, what, safety=0.85):
     """Refuse (MemoryError) a planned host allocation that would not fit: pinned / registered pages cannot be
     reclaimed, so overshooting a cgroup limit takes the whole container down instead of failing one malloc."""

@@ -163,6 +163,8 @@ class LayerStore:
         elif fmt == 12 and self.nbytes % 32 == 0:
             enc = self._encode_packed(12)
         nbytes = enc[1] if enc else self.nbytes
+        from . import hostinfo
+        hostinfo.guard_host_allocation(nbytes, "pinning a streamed layer")
         ptr = self._lib.lia_host_alloc_pinned(nbytes)
         if not ptr:
             raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
@@ -174,21 +176,34 @@ class LayerStore:
         self._ptr, self.tier = ptr, "pinned"
         self.packed, self.stream_bytes = (fmt if enc else 0), nbytes
 
-    def to_cxl(self):
+    def to_cxl(self, pack=0):
         """realloc_to_numa (lia/modeling_opt.py:168-175) + hipHostRegister so the copy engine can DMA from it
-        (the reference leaves the CXL copy pageable, lia/cxl/numa_alloc.py:49)."""
+        (the reference leaves the CXL copy pageable, lia/cxl/numa_alloc.py:49).  pack = 10 / 11 / 12: the tier holds
+        that lossless wire format instead of raw bf16 (fewer bytes in the tier AND on the link)."""
         if self.tier == "cxl":
             return
-        ptr = self._lib.numa_alloc_interleave(self.nbytes)
+        enc = None
+        if pack in (10, 11) and self.nbytes % 2048 == 0:
+            enc = self._encode_packed(pack)
+        elif pack == 12 and self.nbytes % 32 == 0:
+            enc = self._encode_packed(12)
+        nbytes = enc[1] if enc else self.nbytes
+        from . import hostinfo
+        hostinfo.guard_host_allocation(nbytes, "CXL-tier copy of a streamed layer")
+        ptr = self._lib.numa_alloc_interleave(nbytes)
         if not ptr:
             raise MemoryError("Fail to allocate CXL memory!")  # same text as lia/modeling_opt.py:175
-        rc = self._lib.lia_numa_register(ptr, self.nbytes)      # register first: the fill below then runs at DMA speed
+        rc = self._lib.lia_numa_register(ptr, nbytes)           # register first: the fill below then runs at DMA speed
         if rc != 0:
-            self._lib.numa_free_node(ptr, self.nbytes)
+            self._lib.numa_free_node(ptr, nbytes)
             N.check(rc, "lia_numa_register")
-        self._fill_host(ptr)
+        if enc:
+            N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
+        else:
+            self._fill_host(ptr)
         self._free()
         self._ptr, self.tier = ptr, "cxl"
+        self.packed, self.stream_bytes = (pack if enc else 0), nbytes
 
     def is_dma_able(self):
         return self.tier in ("pinned", "cxl")
@@ -198,7 +213,7 @@ class LayerStore:
             self._lib.lia_host_free_pinned(self._ptr)
         elif self.tier == "cxl" and self._ptr:
             self._lib.lia_numa_unregister(self._ptr)
-            self._lib.numa_free_node(self._ptr, self.nbytes)
+            self._lib.numa_free_node(self._ptr, self.stream_bytes)      # the size it was allocated with
         self._ptr = self._dev = self._np = None
         self.tier = None
         self.packed, self.stream_bytes = 0, self.nbytes
@@ -289,7 +304,7 @@ class LiaOPTModel:
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu_layers:
                 if enable_cxl:
-                    st.to_cxl()
+                    st.to_cxl(pack12 if pack12 not in (False, None) else 0)
                 elif pin_weight:
                     st.to_pinned(pack12)
                 else:
@@ -320,7 +335,7 @@ class LiaOPTModel:
             elif st.tier == "device":
                 raise ValueError("gpu_percentage shrank between calls: resident layers cannot be demoted")
             elif enable_cxl and pin_weight:
-                st.to_cxl()
+                st.to_cxl({False: 0, True: 12, None: 0}.get(pack12, pack12))
             elif pin_weight:
                 if st.tier != "pinned":
                     st.to_pinned(pack12)

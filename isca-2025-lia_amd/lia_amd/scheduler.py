@@ -138,6 +138,44 @@ class WeightPipeline:
             self.handle = None
 
 
+class PinnedPool:
+    """Exact-size pinned host blocks with a per-size free list.  torch's pin_memory=True rounds every block up to a
+    power of two (a 264 MB OPT-30B cache tensor takes 512 MB, 23 GB of host KV become 45 GB) -- on a box whose container
+    limit decides which model fits, the caches are allocated here instead and recycled across generate() calls."""
+    _free = {}
+
+    @classmethod
+    def acquire(cls, nbytes):
+        lst = cls._free.get(nbytes)
+        if lst:
+            return lst.pop()
+        from . import hostinfo
+        hostinfo.guard_host_allocation(nbytes, "pinned host KV cache")
+        ptr = N.lib().lia_host_alloc_pinned(nbytes)
+        if not ptr:
+            raise MemoryError("Fail to allocate pinned memory: " + N.lib().lia_last_error().decode())
+        return ptr
+
+    @classmethod
+    def release(cls, ptr, nbytes):
+        cls._free.setdefault(nbytes, []).append(ptr)
+
+    @classmethod
+    def trim(cls):
+        for lst in cls._free.values():
+            for ptr in lst:
+                N.lib().lia_host_free_pinned(ptr)
+        cls._free.clear()
+
+    @staticmethod
+    def as_tensor(ptr, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        buf = (ctypes.c_char * (2 * n)).from_address(ptr)
+        return torch.frombuffer(buf, dtype=torch.int16).view(torch.bfloat16).view(*shape)
+
+
 class KVState:
     """Per-layer KV caches of one generation: seq-major [Smax,B,h,d] (attentions.py:462-476), in HBM for
     resident layers and in pinned host memory for streamed ones (lia/modeling_opt.py:1270-1281)."""
@@ -150,18 +188,36 @@ class KVState:
             n_gpu = sh.layers          # policy 3 for streamed layers too: every cache lives in HBM
         from . import hostinfo
         hostinfo.check_host_allocation(2 * (sh.layers - n_gpu) * smax * B * sh.hidden * 2, "host KV cache")
-        self.tensors, self.kv = [], []
+        self.tensors, self.kv, self._pinned = [], [], []
+        shape = (smax, B, sh.heads, sh.head_dim)
+        nbytes = 2 * smax * B * sh.heads * sh.head_dim
         for i in range(sh.layers):
             if i < n_gpu:
-                k = torch.empty((smax, B, sh.heads, sh.head_dim), dtype=torch.bfloat16, device="cuda")
+                k = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
                 v = torch.empty_like(k)
                 on_dev = 1
             else:
-                k = torch.empty((smax, B, sh.heads, sh.head_dim), dtype=torch.bfloat16, pin_memory=True)
-                v = torch.empty((smax, B, sh.heads, sh.head_dim), dtype=torch.bfloat16, pin_memory=True)
+                pk, pv = PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes)
+                self._pinned += [(pk, nbytes), (pv, nbytes)]
+                k, v = PinnedPool.as_tensor(pk, shape), PinnedPool.as_tensor(pv, shape)
                 on_dev = 0
             self.tensors.append((k, v))
             self.kv.append(N.KV(k.data_ptr(), v.data_ptr(), smax, B, on_dev))
+
+    def close(self):
+        """Hand the pinned blocks back to the pool (the tensors over them must not be used afterwards)."""
+        if self._pinned and torch.cuda.is_available():
+            torch.cuda.synchronize()      # policy-0 K/V deliveries may still be landing in these blocks
+        self.tensors, self.kv = [], []
+        for ptr, nbytes in self._pinned:
+            PinnedPool.release(ptr, nbytes)
+        self._pinned = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class OffloadScheduler:
