@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--stream-format", default=os.environ.get("LIA_STREAM_FORMAT", "pack10"), choices=["raw", "pack12", "pack11", "pack10"],
                     help="wire format of the streamed layers: raw bf16, or the lossless 12-bit / 11.1-bit encodings")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--cpu-layers", type=int, default=0,
+                    help="build-defined: with decoding policy 2, this many streamed layers run their decode step on the host cores "
+                         "(policy 1 per layer, weights never cross the link); 0 = the reference's uniform policy")
     a = ap.parse_args()
 
     import torch
@@ -163,6 +166,8 @@ def main():
     n_gpu = shape.layers if (is_llama and a.gpu_percentage >= 100) else int(shape.layers * a.gpu_percentage / 100)
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
                  gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=a.enable_cxl, no_overlap=False)
+    if a.cpu_layers:
+        flags["cpu_layers"] = a.cpu_layers
     if a.cxl_nodes:
         from lia_amd.cxl.numa_alloc import set_cxl_nodes
         set_cxl_nodes([int(v) for v in a.cxl_nodes.split(",")])
@@ -178,7 +183,9 @@ def main():
     else:
         pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[a.stream_format]
         model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
-                                        host_owner=(group is None or group.is_root), pack12=pack12)
+                                        host_owner=(group is None or group.is_root), pack12=pack12,
+                                        raw_layers=(OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, a.cpu_layers)
+                                                    if (a.cpu_layers and a.decoding_policy == 2 and group is None) else ()))
         sched = OffloadScheduler(model, device=dev_index, dp_group=group, pack12=pack12)
     from lia_amd import hostinfo
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
@@ -199,6 +206,7 @@ def main():
     sched.forward(ids, kv, max_new_tokens=new, **flags)
     if not is_llama:
         sched.ctx.set_host_threads(host_threads)
+        sched.host_threads = host_threads
     cur = ids[:, -1:].clone()
     sched.forward(cur, kv, max_new_tokens=new, **flags)
 
@@ -223,6 +231,7 @@ def main():
     sched.stream_stats(reset=True)
     sched.ctx.prof_start(16384)
     sync()
+    thr0 = hostinfo.cgroup_cpu_throttle()
     t0 = time.time()
     step_lat = []
     for _ in range(a.steps):
@@ -232,6 +241,7 @@ def main():
         step_lat.append(time.time() - ts)
     sync()
     elapsed = time.time() - t0
+    thr1 = hostinfo.cgroup_cpu_throttle()
     prof = sched.ctx.prof_stop()
     h2d_bytes, h2d_ms = sched.stream_stats()
 
@@ -246,7 +256,7 @@ def main():
         achieved = prof["skinny_bytes"] / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
         traffic, traffic_src = (pmc_traffic("lia_gemm_skinny2_kernel<4") if (a.model == "opt-30b" and B == 64) else (None, None))
         out = {
-            "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if (a.model == "opt-30b" and B == 64 and T == 256 and a.gpu_percentage == 10)
+            "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if (a.model == "opt-30b" and B == 64 and T == 256 and a.gpu_percentage == 10 and not a.cpu_layers)
                       else f"decode tokens/s (+ prefill ms), {a.model} bs={B} in{T} gpu%={a.gpu_percentage}",
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -254,7 +264,7 @@ def main():
             "config": {"workload": f"{shape.name} shape (random-init N(0,0.02)), batch {B}/GPU identical rows, prompt {T}, "
                                    f"gpu%={a.gpu_percentage} ({n_gpu} resident + {shape.layers - n_gpu} streamed layers), "
                                    f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
-                                   f"num-minibatch {a.num_minibatch}",
+                                   f"num-minibatch {a.num_minibatch}{', ' + str(a.cpu_layers) + ' decode layers on the host cores' if a.cpu_layers else ''}",
                        "global_batch": B * world, "prompt_len": T, "new_tokens": new,
                        "parallelism": f"dp{world} batch-shard" if world > 1 else "single GPU",
                        "host_attention_threads": host_threads},
@@ -274,6 +284,8 @@ def main():
                                "gemm_tflops": prof_prefill["tiled_flops"] / max(prof_prefill["tiled_ms"], 1e-9) / 1e9,
                                "mfma_frac": prof_prefill["tiled_flops"] / max(prof_prefill["tiled_ms"], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS,
                                "h2d_busy_ms": pre_h2d_ms, "h2d_gbs_while_busy": pre_h2d_bytes / max(pre_h2d_ms, 1e-9) / 1e6},
+            "host_cpu_throttle": {"periods": thr1[0] - thr0[0], "throttled_ms": (thr1[1] - thr0[1]) / 1e3,
+                                  "note": "cgroup CFS quota stalls during the timed decode steps (cpu.stat)"},
             "build_s": build_s,
             "host_memory_gib": {k: (None if v is None else round(v / 2**30, 2)) for k, v in hostinfo.cgroup_memory().items()},
         }

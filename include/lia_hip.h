@@ -106,6 +106,9 @@ typedef struct {
  * the host attends. */
 int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
                       const lia_bf16* x, lia_bf16* y, lia_kv* kv, int B, int T, int pos0, int b0, void* stream);
+/* dst / src: device memory or pinned (mapped) host memory; bytes % 16 == 0; asynchronous on `stream`.  Kernel copy used for
+ * the small activation hops of the cooperative policies (modeling_opt.py:320-355 load_activation / store_hidden). */
+int lia_blit(void* dst, const void* src, size_t bytes, void* stream);
 int lia_ctx_kv_store_wait(lia_ctx* ctx); /* host-blocks until every policy-0 K/V delivery has landed */
 
 /* ---- individual sub-layer ops (same kernels the layer call uses; exposed for parity tests) ------ */

@@ -972,6 +972,16 @@ extern "C" int lia_memcpy_h2d(void* dst_device, const void* src_host, size_t byt
   HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
   return LIA_OK;
 }
+// Small transfer between device memory and MAPPED pinned host memory by a kernel on `stream` (16-byte multiples):
+// the copy engines belong to the weight stream, a hipMemcpy would queue behind a 0.8-1.2 GB layer copy.
+extern "C" int lia_blit(void* dst, const void* src, size_t bytes, void* stream) {
+  if (!dst || !src) return LIA_ERR_MISSING;
+  if (bytes % 16) { lia_set_error("lia_blit: %zu bytes is not a multiple of 16", bytes); return LIA_ERR_INVALID; }
+  lia_blit_launch(dst, src, bytes, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
 extern "C" int lia_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes) {
   if (!dst_host || !src_device) return LIA_ERR_MISSING;
   HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));

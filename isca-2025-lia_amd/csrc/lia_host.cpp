@@ -315,9 +315,66 @@ static inline __m512 dp32(__m512 acc, const lia_bf16* a, const lia_bf16* b) {
 }
 #endif
 
+// Decode-sized M (<= 256): the weights are streamed once and x (M x K, ~0.9 MB at M = 64, K = 7168) must stay close
+// to the core.  Tiles of 64 weight rows x K-chunks of <= 2048: per chunk the x slice (M x 4 KB) and the tile's weight
+// slice (256 KB) both sit in L2, a 4 x 4 zmm block runs over the chunk, and the chunk sums land in a thread-local
+// fp32 tile C[M][64] (L1).  With the whole K in one pass x overflows L2 and every 4 weight rows re-read it from L3.
+static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
+                               int M, int N, int K, int relu) {
+  constexpr int RB = 4, NT = 64, KC = 2048;
+  const int ntiles = (N + NT - 1) / NT;
+#pragma omp parallel
+  {
+    float* C = (float*)aligned_alloc(64, (size_t)((M + 3) & ~3) * NT * sizeof(float));
+#pragma omp for schedule(dynamic, 1)
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int nt0 = tile * NT, ntn = N - nt0 < NT ? N - nt0 : NT;
+      memset(C, 0, (size_t)((M + 3) & ~3) * NT * sizeof(float));
+      for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kl = K - k0 < KC ? K - k0 : KC;
+        for (int nb = 0; nb < ntn; nb += RB) {
+          const int nr = ntn - nb < RB ? ntn - nb : RB;
+          const lia_bf16* wr = w + (long)(nt0 + nb) * K + k0;
+          for (int m0 = 0; m0 < M; m0 += RB) {
+            const int mr = M - m0 < RB ? M - m0 : RB;
+            const lia_bf16* xr = x + (long)m0 * K + k0;
+            __m512 acc[RB][RB];
+            for (int i = 0; i < RB; ++i)
+              for (int j = 0; j < RB; ++j) acc[i][j] = _mm512_setzero_ps();
+            if (mr == RB && nr == RB) {
+              for (int k = 0; k < kl; k += 32) {
+#pragma GCC unroll 4
+                for (int i = 0; i < RB; ++i)
+#pragma GCC unroll 4
+                  for (int j = 0; j < RB; ++j) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
+              }
+            } else {
+              for (int k = 0; k < kl; k += 32)
+                for (int i = 0; i < mr; ++i)
+                  for (int j = 0; j < nr; ++j) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
+            }
+            for (int i = 0; i < mr; ++i)
+              for (int j = 0; j < nr; ++j) C[(m0 + i) * NT + nb + j] += _mm512_reduce_add_ps(acc[i][j]);
+          }
+        }
+      }
+      for (int m = 0; m < M; ++m)
+        for (int j = 0; j < ntn; ++j) {
+          float t = C[m * NT + j] + (bias ? bf16_to_f32(bias[nt0 + j]) : 0.f);
+          t = round_bf16(t);
+          if (relu && t < 0.f) t = 0.f;
+          if (residual) t = round_bf16(bf16_to_f32(residual[(long)m * N + nt0 + j]) + t);
+          y[(long)m * N + nt0 + j] = f32_to_bf16(t);
+        }
+    }
+    free(C);
+  }
+}
+
 // y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.
 static void host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                         long M, int N, int K, int relu) {
+  if (M <= 256 && !getenv("LIA_HOST_LINEAR_V1")) { host_linear_skinny(x, w, bias, residual, y, (int)M, N, K, relu); return; }
   constexpr int RB = 4;
   const long mblocks = (M + RB - 1) / RB;
   const int nblocks = (N + RB - 1) / RB;

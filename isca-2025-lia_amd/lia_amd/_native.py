@@ -87,6 +87,7 @@ SIGNATURES = {
     "lia_stream_mark_ready": (c_int, [c_void_p, c_int]),
     "lia_pack12_bound": (c_size_t, [c_size_t]),
     "lia_pack12_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
+    "lia_blit": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "lia_pack10_bound": (c_size_t, [c_size_t]),
     "lia_pack10_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
     "lia_pack11_bound": (c_size_t, [c_size_t]),

@@ -48,6 +48,8 @@ def generate(model, input_ids, max_new_tokens=None, min_new_tokens=None, do_samp
            "no_overlap": bool(lia["no_overlap"]), "pin_weight": bool(lia["pin_weight"]),
            "gpu_percentage": lia["gpu_percentage"] or 0, "num_minibatch": lia["num_minibatch"] or 1,
            "enable_cxl": bool(lia["enable_cxl"])}
+    if model_kwargs.get("cpu_layers"):           # build-defined extension (scheduler.forward): host-computed decode layers
+        lia["cpu_layers"] = int(model_kwargs.pop("cpu_layers"))
     min_new = min_new_tokens or 0
     return _greedy_search(model, input_ids, max_new_tokens, min_new, eos_token_id, pad_token_id, token_latency,
                           return_logits, lia)

@@ -90,6 +90,20 @@ def host_memory_budget():
     return min(vals) if vals else None
 
 
+def cgroup_cpu_throttle():
+    """(nr_throttled, throttled_usec) of the cgroup so far: CFS quota stalls hit every thread of the container at once, so a
+    host-compute team that (with the runtime's helper threads) overshoots cpu.max pays for it in whole scheduler periods."""
+    out = {"nr_throttled": 0, "throttled_usec": 0}
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, _, v = line.partition(" ")
+            if k in out:
+                out[k] = int(v)
+    except (OSError, ValueError):
+        pass
+    return out["nr_throttled"], out["throttled_usec"]
+
+
 def cgroup_memory():
     """{"current", "peak", "max"} bytes of the cgroup (None where unreadable): what a run really pinned / may pin."""
     out = {}

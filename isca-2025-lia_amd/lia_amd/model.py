@@ -259,13 +259,14 @@ class LiaOPTModel:
 
     @classmethod
     def random_init(cls, shape, seed=0, init="normal", n_gpu_layers=0, pin_weight=True, enable_cxl=False,
-                    host_owner=True, pack12=False):
+                    host_owner=True, pack12=False, raw_layers=()):
         """Random-init weights of the exact architecture, generated ON THE GPU one layer at a time and
         moved straight to their tier (an OPT-30B would take minutes to draw on the CPU).
         init="normal": HF _init_weights (lia/modeling_opt.py:895-904): Linear/Embedding ~ N(0, 0.02), zero
         bias, LN = (1, 0).  init="uniform01": the reference's dummy recipe (opt-weight-gen.py:61-62), seeded.
         Every tensor group has its own seed, so data-parallel ranks draw identical resident layers;
-        host_owner=False (non-root DP ranks) skips the streamed layers, which arrive by broadcast."""
+        host_owner=False (non-root DP ranks) skips the streamed layers, which arrive by broadcast.
+        raw_layers: layers whose host copy stays raw bf16 whatever the wire format (the host cores compute them)."""
         self = cls(shape)
         if host_owner:
             from . import hostinfo
@@ -303,10 +304,11 @@ class LiaOPTModel:
                     flat[o:o + k] = draw(k)
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu_layers:
+                fmt = 0 if li in raw_layers else pack12
                 if enable_cxl:
-                    st.to_cxl(pack12 if pack12 not in (False, None) else 0)
+                    st.to_cxl(fmt if fmt not in (False, None) else 0)
                 elif pin_weight:
-                    st.to_pinned(pack12)
+                    st.to_pinned(fmt)
                 else:
                     st.to_pinned()  # leave the device; demoted to pageable below
                     host = np.array(st._host_view(), copy=True)
@@ -317,7 +319,7 @@ class LiaOPTModel:
         return self
 
     # -- placement (first forward) ------------------------------------------------------------------
-    def place(self, n_gpu_layers, pin_weight, enable_cxl, pack12=False):
+    def place(self, n_gpu_layers, pin_weight, enable_cxl, pack12=False, raw_layers=()):
         """Idempotent tier assignment done on the first forward, as move_gpu_layer / pin_memory are
         (lia/modeling_opt.py:1182-1184, 1214-1217)."""
         key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
@@ -335,10 +337,10 @@ class LiaOPTModel:
             elif st.tier == "device":
                 raise ValueError("gpu_percentage shrank between calls: resident layers cannot be demoted")
             elif enable_cxl and pin_weight:
-                st.to_cxl({False: 0, True: 12, None: 0}.get(pack12, pack12))
+                st.to_cxl(0 if i in raw_layers else {False: 0, True: 12, None: 0}.get(pack12, pack12))
             elif pin_weight:
                 if st.tier != "pinned":
-                    st.to_pinned(pack12)
+                    st.to_pinned(0 if i in raw_layers else pack12)
         torch.cuda.synchronize()
         self.placed_for = key
 

@@ -22,6 +22,9 @@ class Box:
     attn_gbs: float = 6000.0          # decode attention on HBM-resident KV
     mfma_tflops: float = 1150.0       # prefill GEMM on random data
     host_gbs_per_thread: float = 13.0
+    host_linear_gbs_per_thread: float = 3.6   # policy-1 linears at M = 64 beside the running weight stream (4.9 alone)
+    host_attn_beside_stream: float = 0.55     # host attention keeps this share of its rate while the copy engine reads DRAM
+    wire_ratio: float = 0.675         # bytes shipped per weight byte: pack10 0.675, pack11 0.696, pack12 0.751, raw 1.0
     host_threads: int = 0
     host_mem_gb: float = 0.0
 
@@ -84,6 +87,33 @@ def estimate(shape, B, T, new, gpu_percentage, decoding_policy, box=None, kv_in_
     hbm = n_gpu * lb / 1e9 + emb_gb + 2 * lb / 1e9 + (L if kv_in_hbm else n_gpu) * kv_layer / 1e9 + 3.5
     host = n_str * lb / 1e9 + (0 if kv_in_hbm else n_str * kv_layer / 1e9)
     return prefill_ms, decode_ms, hbm, host, n_gpu
+
+
+def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None):
+    """How many streamed layers should take their decode step on the host cores (scheduler.forward cpu_layers) beside
+    decoding policy 2: a host layer costs its linears at the host's weight-read rate + the host attention, but frees one
+    layer's worth of link time.  The step is max(link time of the remaining layers, sum of every layer's latency);
+    returns (count, predicted ms per step).  Calibrated on the r01 scan: OPT-30B, B = 64, 16 host
+    threads -> 11 layers, 488 ms predicted and measured."""
+    box = box or Box()
+    L, H = shape.layers, shape.hidden
+    n_gpu = int(L * gpu_percentage / 100)
+    n_str = L - n_gpu
+    lb = layer_bytes(shape)
+    copy_ms = 1e3 * lb * box.wire_ratio / (box.link_gbs * 1e9)
+    gemm_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
+    kv_read = 2 * (T + new // 2) * B * H * 2
+    attn_gpu_ms = 1e3 * kv_read / (box.attn_gbs * 1e9)
+    attn_host_ms = 1e3 * kv_read / (box.host_threads * box.host_gbs_per_thread * box.host_attn_beside_stream * 1e9)
+    t_g = gemm_ms + attn_host_ms + 0.3
+    t_c = 1e3 * lb / (box.host_threads * box.host_linear_gbs_per_thread * 1e9) + attn_host_ms + 0.3
+    lm_ms = 1e3 * shape.vocab * H * 2 / (box.hbm_gbs * 1e9)
+    best = (0, None)
+    for c in range(0, max(1, n_str)):
+        step = max((n_str - c) * copy_ms, n_gpu * (gemm_ms + attn_gpu_ms) + (n_str - c) * t_g + c * t_c) + lm_ms + 0.5
+        if best[1] is None or step < best[1] - 1e-9:
+            best = (c, step)
+    return best
 
 
 def plan(shape, B, T, new, box=None, objective="decode"):

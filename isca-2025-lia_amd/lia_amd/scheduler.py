@@ -267,7 +267,10 @@ class OffloadScheduler:
 
     # -- one forward -----------------------------------------------------------------------------------
     def forward(self, input_ids, kv_state, prefill_policy=1, decoding_policy=1, no_overlap=False, pin_weight=False,
-                gpu_percentage=0, num_minibatch=1, enable_cxl=False, max_new_tokens=None, suppress_token=-1):
+                gpu_percentage=0, num_minibatch=1, enable_cxl=False, max_new_tokens=None, suppress_token=-1, cpu_layers=0):
+        """cpu_layers (build-defined): with decoding policy 2, that many of the streamed layers run
+        their decode step entirely on the host cores (policy 1, weights read in place) instead of crossing the link --
+        the cooperative split of the reference taken per layer.  Prefill is unaffected (policy 0 for every layer)."""
         m, sh = self.model, self.model.shape
         B, T = input_ids.shape
         L = sh.layers
@@ -288,7 +291,9 @@ class OffloadScheduler:
 
         # move_gpu_layer / pin_memory, idempotent.  The policy-1 host path reads the host copy directly, so the pack12
         # wire format is only used when neither phase runs on the CPU.
-        m.place(n_gpu, pin_weight, enable_cxl, self.pack12 and prefill_policy != 1 and decoding_policy != 1)
+        cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and decoding_policy == 2 and self.dp is None) else frozenset()
+        m.place(n_gpu, pin_weight, enable_cxl, self.pack12 and prefill_policy != 1 and decoding_policy != 1, raw_layers=cpu_set)
+        host_now = cpu_set if not is_prefill else frozenset()     # layers this forward computes on the host
         rows = B * T if n_gpu > 0 else mini * T                    # resident layers take the whole batch
         if policy == 0 and n_gpu < L:
             rows = max(rows, mini * kv_state.smax)                 # policy-0 decode parks the cached prefix in a slab
@@ -308,6 +313,15 @@ class OffloadScheduler:
             ctx.synchronize()
             kv_state.len = pos0 + T
             return logits, nxt
+        def next_streamed(i, wrapped):
+            """the streamed layer after i that needs a slot: decode forwards skip the host-computed layers"""
+            while True:
+                i += 1
+                if i >= L:
+                    i, wrapped = first_streamed, True
+                if not ((wrapped or not is_prefill) and i in cpu_set):
+                    return i, wrapped
+
         if n_gpu < L and overlap:
             pipe.prefetch(first_streamed)                          # no-op if the previous step already wrapped to it
         for idx in range(L):
@@ -316,6 +330,9 @@ class OffloadScheduler:
                 ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
                 x, y = y, x
                 continue
+            if idx in host_now:
+                x, y = self._host_decode_layer(idx, x, y, kv_state, B, T, pos0)
+                continue
             if not overlap:
                 pipe.prefetch(idx)
             wptrs = pipe.acquire(idx)
@@ -323,9 +340,9 @@ class OffloadScheduler:
                 # weight prefetch of the next streamed layer(s) overlaps this layer's compute (:1305-1312, :1508-1515):
                 # every free slot is filled; after the last layer the order wraps to the first streamed layer of the
                 # NEXT forward, so the copy engine keeps running across token steps
-                nxt = idx
+                nxt, wrapped = idx, False
                 for _ in range(pipe.n_slots - 1):
-                    nxt = nxt + 1 if nxt + 1 < L else first_streamed
+                    nxt, wrapped = next_streamed(nxt, wrapped)
                     if nxt == idx or not pipe.can_prefetch():
                         break
                     pipe.prefetch(nxt)
@@ -348,6 +365,39 @@ class OffloadScheduler:
             ctx.kv_store_wait()                                    # host cache complete before the next step reads it
         kv_state.len = pos0 + T
         return logits, nxt
+
+    @staticmethod
+    def cpu_layer_set(n_gpu, L, count):
+        """`count` host-computed layers spread evenly over the streamed ones (never the first streamed layer, which the
+        wrap-around prefetch targets): while the host works on one of them the copy engine fills the free slots."""
+        n_str = L - n_gpu
+        count = max(0, min(int(count), n_str - 1))
+        if count == 0:
+            return frozenset()
+        return frozenset(n_gpu + 1 + int((j + 0.5) * (n_str - 1) / count) for j in range(count))
+
+    def _host_decode_layer(self, idx, x, y, kv_state, B, T, pos0):
+        """One decode step of layer idx on the host cores (policy 1 for this layer): hidden state GPU -> pinned host by a
+        kernel blit, lia_host_layer_forward on the raw host copy of the weights and the host KV cache, result back."""
+        m, sh, ctx, lib = self.model, self.model.shape, self.ctx, self.ctx.lib
+        st = m.layers[idx]
+        if st.packed or not st.is_dma_able():
+            raise ValueError(f"layer {idx} is to run on the host but its host copy is not raw pinned bf16")
+        nbytes = B * T * sh.hidden * 2
+        if getattr(self, "_host_hidden", None) is None or self._host_hidden[2] < nbytes:
+            self._host_hidden = (PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes), nbytes)
+        hx, hy, _ = self._host_hidden
+        N.check(lib.lia_blit(ctypes.c_void_p(hx), ctypes.c_void_p(x.data_ptr()), nbytes, ctypes.c_void_p(ctx.stream)), "lia_blit")
+        ctx.synchronize()
+        from . import hostinfo
+        threads = getattr(self, "host_threads", None) or hostinfo.default_host_threads(1)
+        w = ops.weight_ptr_array(st.host_ptr(), m.offsets)
+        kv = kv_state.kv[idx]
+        N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx), ctypes.c_void_p(hy),
+                                           ctypes.c_void_p(kv.k), ctypes.c_void_p(kv.v), kv.smax, kv.batch, B, T, pos0, 0, threads),
+                "lia_host_layer_forward")
+        N.check(lib.lia_blit(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(hy), nbytes, ctypes.c_void_p(ctx.stream)), "lia_blit")
+        return y, x
 
     def _host_layers(self, x, kv_state, n_gpu, B, T, pos0):
         """Policy 1 ("compute everything on CPU", lia/modeling_opt.py:1168, branches :1367-1377 / :1545-1555): layers

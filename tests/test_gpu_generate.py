@@ -88,6 +88,29 @@ def test_generate_logits_match_oracle(oracle, name):
     model.close()
 
 
+@pytest.mark.parametrize("name", GEN_CASES)
+@pytest.mark.parametrize("fmt", ["raw", "pack10"])
+def test_generate_with_host_computed_decode_layers(name, fmt, monkeypatch):
+    """cpu_layers (build-defined): some streamed layers take their decode step on the host cores (policy 1 per layer)
+    while the others stay on policy 2; prefill is policy 0 for all.  Same greedy ids as the HF golden run."""
+    import torch
+    from lia_amd.generation import generate
+    monkeypatch.setenv("LIA_STREAM_FORMAT", fmt)
+    z, m, ids, c = _load(name)
+    model = _model(m, c)
+    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], prefill_policy=0,
+                   decoding_policy=2, gpu_percentage=25, pin_weight=True, cpu_layers=2)
+    assert (out.numpy() == z["ids_bf16"]).all(), (out[0, c["T"]:].tolist(), z["ids_bf16"][0, c["T"]:].tolist())
+    sched = model._lia_scheduler
+    n_gpu = int(c["L"] * 25 / 100)
+    host = sched.cpu_layer_set(n_gpu, c["L"], 2)
+    assert host and all(not model.layers[i].packed for i in host)
+    if fmt != "raw":
+        assert any(model.layers[i].packed for i in range(n_gpu, c["L"]) if i not in host)
+    sched.close()
+    model.close()
+
+
 def test_generate_argument_errors():
     import torch
     from lia_amd.generation import generate

@@ -27,3 +27,17 @@ def test_monotonic_in_gpu_percentage_and_plan_picks_resident_when_it_fits():
     big = resolve_shape("opt-175b")
     p2 = planner.plan(big, 32, 256, 32, BOX)
     assert 0 < p2.n_gpu_layers < big.layers and p2.host_gb <= 0.85 * BOX.host_mem_gb and p2.hbm_gb <= 0.92 * 288
+
+
+def test_plan_cpu_layers_matches_the_measured_optimum():
+    """OPT-30B, B = 64, gpu% = 10, 16 host threads, pack10 on the wire: the r01 scan found the link-bound/host-bound
+    crossover at 11 host-computed layers, 488 ms per step."""
+    from lia_amd import planner
+    from lia_amd.model import resolve_shape
+    box = planner.Box(host_threads=16, host_mem_gb=300.0)
+    c, ms = planner.plan_cpu_layers(resolve_shape("opt-30b"), 64, 256, 32, 10, box)
+    assert 9 <= c <= 13 and 460 <= ms <= 520, (c, ms)
+    # a raw wire format makes every shipped layer dearer, so more layers move to the host; few host threads -> fewer
+    c_raw, _ = planner.plan_cpu_layers(resolve_shape("opt-30b"), 64, 256, 32, 10, planner.Box(host_threads=16, host_mem_gb=300.0, wire_ratio=1.0))
+    c_weak, _ = planner.plan_cpu_layers(resolve_shape("opt-30b"), 64, 256, 32, 10, planner.Box(host_threads=4, host_mem_gb=300.0))
+    assert c_raw > c and c_weak < c
