@@ -311,7 +311,11 @@ __global__ __launch_bounds__(256) void lia_gemm_tiled_kernel(const bf16_t* __res
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
   const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+#ifdef LIA_GM
+  constexpr int GM = LIA_GM;
+#else
   constexpr int GM = 8;
+#endif
   const int group = lin / (GM * tiles_n);
   const int first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
@@ -397,7 +401,11 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
   const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  constexpr int GM = 8;
+#ifdef LIA_GM
+  constexpr int GM = LIA_GM;
+#else
+  constexpr int GM = 4;   // m-tiles per XCD group: 2 / 4 / 8 / 16 / 32 measured, 4 is 1-4 % ahead of 8 on three of the four OPT-30B shapes
+#endif
   const int group = lin / (GM * tiles_n);
   const int first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
@@ -467,7 +475,11 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __
 // LDS: 2 buffers x 2 halves x (W 256 rows x 64 B + x 256 rows x 64 B) = 128 KB.
 // ---------------------------------------------------------------------------------------------
 constexpr int T3_HALF_BYTES = 2 * 256 * 64;   // one k-half of a tile: W part 16 KB + x part 16 KB
+#ifdef LIA_GEMM_STAMPS
+__device__ unsigned long long g_t3_stamps[2 * 4096];
+#endif
 
+template <int DBG, int NSLOT>
 __global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
@@ -482,7 +494,11 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* _
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
   const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  constexpr int GM = 8;
+#ifdef LIA_GM
+  constexpr int GM = LIA_GM;
+#else
+  constexpr int GM = 4;
+#endif
   const int group = lin / (GM * tiles_n);
   const int first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
@@ -510,20 +526,20 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* _
   const bf16_t* const xsrc1 = x + (long)min(m0 + 64 + srow, M - 1) * ldx + khalf;
   const bf16_t* const xsrc2 = x + (long)min(m0 + 128 + srow, M - 1) * ldx + khalf;
   const bf16_t* const xsrc3 = x + (long)min(m0 + 192 + srow, M - 1) * ldx + khalf;
-  char* const my_half = smem + grp * T3_HALF_BYTES + wg * 1024;
+  char* const my_lane_base = smem + wg * 1024;      // + slot * T3_HALF_BYTES: unit u = 2 t + half lives in slot u % NSLOT
   // (macros, not lambdas: a lambda that captures the fragment / accumulator arrays sends them to scratch)
-#define T3_STAGE_W(t)                                                                                                    \
+#define T3_STAGE_W(t, slot)                                                                                              \
   do {                                                                                                                    \
-    char* dst_ = my_half + ((t) & 1) * 2 * T3_HALF_BYTES;                                                                 \
+    char* dst_ = my_lane_base + (slot) * T3_HALF_BYTES;                                                                   \
     const long k0_ = (long)(t) * T2_BK;                                                                                   \
     __builtin_amdgcn_global_load_lds(GL_AS1(wsrc0 + k0_), LDS_AS3(dst_), 16, 0, 0);                                       \
     __builtin_amdgcn_global_load_lds(GL_AS1(wsrc1 + k0_), LDS_AS3(dst_ + 4096), 16, 0, 0);                                \
     __builtin_amdgcn_global_load_lds(GL_AS1(wsrc2 + k0_), LDS_AS3(dst_ + 8192), 16, 0, 0);                                \
     __builtin_amdgcn_global_load_lds(GL_AS1(wsrc3 + k0_), LDS_AS3(dst_ + 12288), 16, 0, 0);                               \
   } while (0)
-#define T3_STAGE_X(t)                                                                                                    \
+#define T3_STAGE_X(t, slot)                                                                                              \
   do {                                                                                                                    \
-    char* dst_ = my_half + ((t) & 1) * 2 * T3_HALF_BYTES + 16384;                                                         \
+    char* dst_ = my_lane_base + (slot) * T3_HALF_BYTES + 16384;                                                           \
     const long k0_ = (long)(t) * T2_BK;                                                                                   \
     __builtin_amdgcn_global_load_lds(GL_AS1(xsrc0 + k0_), LDS_AS3(dst_), 16, 0, 0);                                       \
     __builtin_amdgcn_global_load_lds(GL_AS1(xsrc1 + k0_), LDS_AS3(dst_ + 4096), 16, 0, 0);                                \
@@ -539,9 +555,9 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* _
   const char* const xfrag = smem + 16384 + wm * 8192 + frag_off;
   bf16x8 a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7;
 #define T3_LD(p) __builtin_bit_cast(bf16x8, *(const uint4*)(p))
-#define T3_READ(t, half)                                                                                                 \
+#define T3_READ(slot)                                                                                                    \
   do {                                                                                                                    \
-    const int off_ = (((t) & 1) * 2 + (half)) * T3_HALF_BYTES;                                                            \
+    const int off_ = (slot) * T3_HALF_BYTES;                                                                              \
     a0 = T3_LD(wfrag + off_); a1 = T3_LD(wfrag + off_ + 1024); a2 = T3_LD(wfrag + off_ + 2048); a3 = T3_LD(wfrag + off_ + 3072); \
     b0 = T3_LD(xfrag + off_); b1 = T3_LD(xfrag + off_ + 1024); b2 = T3_LD(xfrag + off_ + 2048); b3 = T3_LD(xfrag + off_ + 3072); \
     b4 = T3_LD(xfrag + off_ + 4096); b5 = T3_LD(xfrag + off_ + 5120); b6 = T3_LD(xfrag + off_ + 6144); b7 = T3_LD(xfrag + off_ + 7168); \
@@ -561,34 +577,62 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* _
     T3_ROW(0, a0) T3_ROW(1, a1) T3_ROW(2, a2) T3_ROW(3, a3)                                                               \
     __builtin_amdgcn_s_setprio(0);                                                                                        \
   } while (0)
-#define T3_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifdef LIA_GEMM_STAMPS
+  // tools/gemm_bench.hip -DLIA_GEMM_STAMPS: cycle stamps before / after every barrier from waves 0 and 4 of workgroup 0
+  unsigned long long* stamp_p = (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) ? g_t3_stamps + (wave >> 2) * 4096 : nullptr;
+  int stamp_n = 0;
+#define T3_STAMP() do { if (stamp_p && stamp_n < 4096) stamp_p[stamp_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define T3_STAMP() do { } while (0)
+#endif
+#define T3_BARRIER() do { __builtin_amdgcn_sched_barrier(0); T3_STAMP(); __builtin_amdgcn_s_barrier(); T3_STAMP(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define T3_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
   const int nk = K / T2_BK;
-  T3_STAGE_W(0); T3_STAGE_X(0);
-  if (nk > 1) { T3_STAGE_W(1); wait_vmcnt<4>(); } else wait_vmcnt<0>();
+  // unit u = 2 t + half lives in ring slot u % NSLOT.  NSLOT = 4: the two-buffer scheme described above.
+  // NSLOT = 5 (160 KB): the LDS-DMA window is what bounds this kernel -- ablation (tools/gemm_bench -DLIA_GEMM_ABLATE): the
+  // loop without MFMAs takes as long as with them, without LDS-DMA 1.6 PFLOP/s; every sharer of an operand chunk asks for
+  // it at the same moment, so all of them see the L2-miss latency (~1.7 us) and a CU's fill rate is (LDS bytes that may be
+  // in flight) / latency = 64 KB / 1.7 us = 37 GB/s, i.e. 1.2 PFLOP/s at 128 flop/B.  The fifth slot lets my half of tile
+  // t+2 leave one k-step after the slot's previous unit was last read: pieces 0-3 in M(t,0), 4-7 in R(t,1), retired by
+  // vmcnt(8) at the end of M(t+1,1) -- 96-128 KB in flight instead of 64.
+  int u0 = 0;                                        // slot of unit 2 t
+#define T3_SLOT(d) ((u0 + (d)) % NSLOT)
+  if (NSLOT == 4) {
+    T3_STAGE_W(0, grp); T3_STAGE_X(0, grp);
+    if (nk > 1) { T3_STAGE_W(1, 2 + grp); wait_vmcnt<4>(); } else wait_vmcnt<0>();
+  } else {
+    T3_STAGE_W(0, grp); T3_STAGE_X(0, grp);
+    if (nk > 1) { T3_STAGE_W(1, 2 + grp); T3_STAGE_X(1, 2 + grp); wait_vmcnt<8>(); } else wait_vmcnt<0>();
+  }
   T3_BARRIER();
   if (grp == 1) T3_BARRIER();      // the stagger
   for (int t = 0; t < nk; ++t) {
     // R(t,0)
-    T3_READ(t, 0);
-    if (t + 1 < nk) T3_STAGE_X(t + 1);
+    if (!(DBG & 2) || t == 0) T3_READ(T3_SLOT(0));
+    if (NSLOT == 4 && !(DBG & 1) && t + 1 < nk) T3_STAGE_X(t + 1, T3_SLOT(2 + grp));
     T3_LGKM0();
     T3_BARRIER();
     // M(t,0)
-    T3_MMA();
+    if (NSLOT == 5 && !(DBG & 1) && t + 2 < nk) T3_STAGE_W(t + 2, T3_SLOT(4 + grp));
+    if (!(DBG & 4)) T3_MMA();
     T3_BARRIER();
     // R(t,1)
-    T3_READ(t, 1);
+    if (!(DBG & 2)) T3_READ(T3_SLOT(1));
+    if (NSLOT == 5 && !(DBG & 1) && t + 2 < nk) T3_STAGE_X(t + 2, T3_SLOT(4 + grp));
     T3_LGKM0();
     T3_BARRIER();
     // M(t,1)
-    if (t + 2 < nk) T3_STAGE_W(t + 2);
-    T3_MMA();                        // (never inside a branch: hipcc then copies the accumulators and spills)
-    if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    if (NSLOT == 4 && !(DBG & 1) && t + 2 < nk) T3_STAGE_W(t + 2, T3_SLOT(4 + grp));
+    if (!(DBG & 4)) T3_MMA();        // (never inside a branch on a runtime value: hipcc then copies the accumulators and spills)
+    if (NSLOT == 4) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+    else { if (t + 2 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
     if (t + 1 < nk || grp == 0) T3_BARRIER();
+    u0 = (u0 + 2) % NSLOT;
   }
+#undef T3_SLOT
 #undef T3_BARRIER
+#undef T3_STAMP
 #undef T3_LGKM0
 #undef T3_MMA
 #undef T3_ROW
@@ -715,16 +759,37 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   }
   if ((K % TL_BK) != 0) return -1;
   if (regime) *regime = 2;
-  if (M >= 1024 && N >= 512 && g_tiled_variant == 257) {
+  if (M >= 1024 && N >= 512 && (g_tiled_variant == 257 || g_tiled_variant == 258)) {
     int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T3_HALF_BYTES);
+      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T3_HALF_BYTES);
+      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * T3_HALF_BYTES);
       attr_set = true;
     }
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(lia_gemm_tiled256s_kernel, dim3(tiles_m * tiles_n), dim3(512), 4 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N,
-                       K, tiles_m, tiles_n, *ep, *om);
+#ifdef LIA_GEMM_ABLATE
+    // tools/gemm_bench.hip -DLIA_GEMM_ABLATE: timing-only variants (wrong results): 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA
+    static int abl = [] { const char* e = getenv("ABLATE"); return e ? atoi(e) : 0; }();
+#define T3_ABL(n) if (abl == n) { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<n, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T3_HALF_BYTES); \
+      hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<n, 4>), dim3(tiles_m * tiles_n), dim3(512), 4 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); \
+      if (ev1) (void)hipEventRecord(ev1, st); return 0; }
+    T3_ABL(1) T3_ABL(2) T3_ABL(3) T3_ABL(4) T3_ABL(5) T3_ABL(6) T3_ABL(7)
+    if (abl == 16 || abl == 14) {   // 5-slot ring: 16 = DMA only (no reads, no MFMA), 14 = reads + DMA, no MFMA
+      if (abl == 16) { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<6, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * T3_HALF_BYTES);
+        hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<6, 5>), dim3(tiles_m * tiles_n), dim3(512), 5 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); }
+      else { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * T3_HALF_BYTES);
+        hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<4, 5>), dim3(tiles_m * tiles_n), dim3(512), 5 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); }
+      if (ev1) (void)hipEventRecord(ev1, st);
+      return 0;
+    }
+#endif
+    if (g_tiled_variant == 258)
+      hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<0, 5>), dim3(tiles_m * tiles_n), dim3(512), 5 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N,
+                         K, tiles_m, tiles_n, *ep, *om);
+    else
+      hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<0, 4>), dim3(tiles_m * tiles_n), dim3(512), 4 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N,
+                         K, tiles_m, tiles_n, *ep, *om);
     if (ev1) (void)hipEventRecord(ev1, st);
     return 0;
   }

@@ -42,6 +42,27 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
+#ifdef LIA_GEMM_STAMPS
+  {
+    // one launch of the staggered kernel, then the barrier-to-barrier intervals of waves 0 (group 0) and 4 (group 1)
+    auto& sh = shapes[0];
+    LiaEpilogue ep{bias, res, sh.N, 0};
+    LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
+    lia_gemm_set_tiled_variant(257);
+    for (int rep = 0; rep < 2; ++rep) lia_gemm_launch(x, sh.K, w[0], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, 0, st, nullptr, nullptr, nullptr);
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(2 * 4096);
+    CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_t3_stamps), h.size() * 8));
+    for (int g = 0; g < 2; ++g) {
+      printf("group %d (stamps: before/after each barrier; intervals in cycles of the 100 MHz-or-shader counter):\n", g);
+      const unsigned long long* p = h.data() + g * 4096;
+      // stamp 2i = arrival at barrier i, 2i+1 = release.  work(i) = arrival(i) - release(i-1); wait(i) = release(i) - arrival(i)
+      for (int i = 4; i < 4 + 24; ++i) printf("  barrier %2d: work %6llu  wait %6llu\n", i, p[2 * i] - p[2 * i - 1], p[2 * i + 1] - p[2 * i]);
+      printf("  total over 400 barriers: %llu\n", p[2 * 404] - p[2 * 4]);
+    }
+    return 0;
+  }
+#endif
   if (getenv("CHECK")) {
     // variant 257 against variant 256 on the same operands: the two kernels add the same products in the same order
     // (k ascending inside one accumulator), so the outputs must be bit-identical
@@ -53,7 +74,7 @@ int main(int argc, char** argv) {
       for (int rep = 0; rep < 3; ++rep) {
         om.base[0] = y; lia_gemm_set_tiled_variant(256);
         lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, 0, st, nullptr, nullptr, nullptr);
-        om.base[0] = y2; lia_gemm_set_tiled_variant(257);
+        om.base[0] = y2; lia_gemm_set_tiled_variant(getenv("VARIANT") ? atoi(getenv("VARIANT")) : 257);
         lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, 0, st, nullptr, nullptr, nullptr);
         CK(hipStreamSynchronize(st));
         size_t n = (size_t)M * s.N; h1.resize(n); h2.resize(n);
