@@ -24,7 +24,7 @@ __global__ __launch_bounds__(512) void k(const char* __restrict__ src, long row_
   const int col = chunk * 16;
   // this wave's 512-row window starts somewhere inside the span (power of two); no division in the loop
   const char* base = src + ((((long)((blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / share)) * 8 + wave) * 512 * row_stride) & (span - 1) & ~15L) + (long)row * row_stride + col;
-  char* lds = smem + wave * (INFL * 1024);
+  char* lds = smem + wave * (INFL * 1024) + (swz_mode == 3 ? 65536 : 0);   // SWZ=3: destinations above 64 KB
   uint4 regs[INFL];
   long off = 0;
   for (int it = 0; it < iters; ++it) {

@@ -92,10 +92,11 @@ int main(int argc, char** argv) {
     LiaEpilogue ep{getenv("NOBIAS") ? nullptr : bias, getenv("NORES") ? nullptr : res, s.N, 0};
     LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
     const int iters = M > 256 ? 4 : 12;
-    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K, w[it % NBUF], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, force_split, st, nullptr, nullptr, nullptr);
+    const long ldp = getenv("LDPAD") ? atol(getenv("LDPAD")) : 0;   // row stride = K + LDPAD elements (aliasing experiment)
+    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, force_split, st, nullptr, nullptr, nullptr);
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
-    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K, w[it % NBUF], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, force_split, st, nullptr, nullptr, nullptr);
+    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, force_split, st, nullptr, nullptr, nullptr);
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     double bytes = 2.0 * ((double)s.N * s.K + (double)M * s.K + (double)M * s.N);
