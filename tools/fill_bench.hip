@@ -30,7 +30,13 @@ __global__ __launch_bounds__(512) void k(const char* __restrict__ src, long row_
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < INFL; ++u) {
-      const char* p = base + (long)(((it * INFL + u) & 63) * (64 / LPR)) * row_stride;
+      const char* p;
+      if (swz_mode == 4) {   // SWZ=4 (INFL = 8): GEMM-like streaming -- this wave owns 64 rows, one 128-B line of each per iteration,
+                             // k advances one line per iteration, a new 512-row window every 112 iterations
+        const long win = (it / 112) * 256L * 4096 * row_stride;
+        p = src + ((((long)((blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / share)) * 8 + wave) * 512 * row_stride + win) & (span - 1) & ~127L)
+            + (long)((u & 7) * 8 + row) * row_stride + (long)(((it * (INFL / 8 > 0 ? INFL / 8 : 1)) + (u >> 3)) % 112) * 128 + col;
+      } else p = base + (long)(((it * INFL + u) & 63) * (64 / LPR)) * row_stride;
       if (MODE == 0 || MODE == 2) __builtin_amdgcn_global_load_lds(GL_AS1(p), LDS_AS3(lds + u * 1024), 16, 0, 0);
       else regs[u] = *(const uint4*)p;
     }
@@ -75,6 +81,8 @@ int main() {
   run<0, 128, 8>(src, stride, span, 4, "LDS-DMA, 128-B segments");
   run<0, 64, 8>(src, stride, span, 8, "LDS-DMA, 64-B segments");
   run<2, 128, 8>(src, stride, span, 8, "LDS-DMA + vmcnt(4) + 4 barriers per 8 KB");
+  run<0, 128, 16>(src, stride, span, 8, "LDS-DMA, 128-B segments");
+  run<0, 128, 12>(src, stride, span, 8, "LDS-DMA, 128-B segments");
   run<1, 128, 4>(src, stride, span, 8, "global_load + ds_write, 128-B segments");
   run<1, 128, 8>(src, stride, span, 8, "global_load + ds_write, 128-B segments");
   run<1, 128, 8>(src, stride, span, 4, "global_load + ds_write, 128-B segments");
