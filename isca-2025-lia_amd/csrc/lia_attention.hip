@@ -546,8 +546,6 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
 // 1: first-generation kernel, 2: lia_attn_prefill128_kernel (d = 128).  LIA_ATTN_PREFILL_VARIANT overrides.
 static int g_prefill_variant = [] { const char* e = getenv("LIA_ATTN_PREFILL_VARIANT"); return e ? atoi(e) : 2; }();
 extern "C" void lia_attn_set_prefill_variant(int v) { g_prefill_variant = v; }
-static int g_kv_token_major = 0;   // experiment (tools/attn_ab.py): K/V given as [B][T][h][d]
-extern "C" void lia_attn_set_kv_token_major(int v) { g_kv_token_major = v; }
 
 extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
                                        int B, int T, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
@@ -560,8 +558,8 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
     case 128:
       if (g_prefill_variant == 2) {
         const long hd = (long)kv_heads * 128;
-        if (g_kv_token_major) hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, hd, (long)T * hd, b0, scaling, post_scale);
-        else hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, post_scale);
+        // (a token-major [B][T][h][d] K/V -- strides (hd, T hd) -- was measured: same time, so the cache layout stays)
+        hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, post_scale);
       }
       else hipLaunchKernelGGL(lia_attn_prefill_kernel<128>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale);
       break;

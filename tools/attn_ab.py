@@ -11,7 +11,6 @@ from lia_amd import _native as N, ops  # noqa: E402
 
 L = N.lib()
 L.lia_attn_set_prefill_variant.argtypes = [__import__("ctypes").c_int]
-L.lia_attn_set_kv_token_major.argtypes = [__import__("ctypes").c_int]
 cases = [(2, 8, 4), (1, 17, 4), (3, 40, 2), (2, 256, 2), (1, 300, 3), (64, 256, 56), (4, 1000, 8), (128, 1024, 32)]
 if len(sys.argv) == 4:
     cases = [tuple(int(v) for v in sys.argv[1:4])]
@@ -34,20 +33,6 @@ for B, T, heads in cases:
         ctx.synchronize()
         times.append((time.time() - t0) / 3)
         outs.append(o.view(torch.int16).clone())
-    # same K/V handed over token-major ([B][T][h][d]): what the projection GEMM writes before any cache scatter
-    kt, vt = k.permute(1, 0, 2, 3).contiguous(), v.permute(1, 0, 2, 3).contiguous()
-    torch.cuda.synchronize()
-    L.lia_attn_set_kv_token_major(1)
-    o = ctx.attention(q, kt, vt, T, heads)
-    ctx.synchronize()
-    t0 = time.time()
-    for _ in range(3):
-        o = ctx.attention(q, kt, vt, T, heads)
-    ctx.synchronize()
-    t_tm = (time.time() - t0) / 3
-    bad_tm = int((o.view(torch.int16) != outs[0]).sum())
-    L.lia_attn_set_kv_token_major(0)
-    print(f"   token-major K/V: mismatches {bad_tm}, v2 {t_tm * 1e3:.3f} ms")
     bad = int((outs[0] != outs[1]).sum())
     flops = 4 * B * heads * T * T * 128 / 2
     print(f"B={B} T={T} heads={heads}: mismatches {bad} / {outs[0].numel()}   v1 {times[0] * 1e3:.3f} ms  v2 {times[1] * 1e3:.3f} ms "
