@@ -183,7 +183,8 @@ def main():
     else:
         pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[a.stream_format]
         model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
-                                        host_owner=(group is None or group.is_root), pack12=pack12,
+                                        host_owner=(group is None or group.is_root or group.mode == "allgather"), pack12=pack12,
+                                        shard=((rank, world) if (group is not None and world > 1 and group.mode == "allgather") else None),
                                         raw_layers=(OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, a.cpu_layers)
                                                     if (a.cpu_layers and a.decoding_policy == 2 and group is None) else ()))
         sched = OffloadScheduler(model, device=dev_index, dp_group=group, pack12=pack12)
@@ -266,7 +267,7 @@ def main():
                                    f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
                                    f"num-minibatch {a.num_minibatch}{', ' + str(a.cpu_layers) + ' decode layers on the host cores' if a.cpu_layers else ''}",
                        "global_batch": B * world, "prompt_len": T, "new_tokens": new,
-                       "parallelism": f"dp{world} batch-shard" if world > 1 else "single GPU",
+                       "parallelism": (f"dp{world} batch-shard, {group.mode} weight stream" if world > 1 else "single GPU"),
                        "host_attention_threads": host_threads},
             "prefill_ms": prefill_ms,
             "decode_latency_ms": {"mean": 1e3 * sum(step_lat) / len(step_lat), "p90": 1e3 * sorted(step_lat)[int(0.9 * (len(step_lat) - 1))],

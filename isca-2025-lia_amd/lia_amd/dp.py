@@ -42,6 +42,12 @@ class DataParallelGroup:
         self.dist, self.rank, self.world, self.local_rank = dist, rank, world, local_rank
         self.chunk_bytes = chunk_bytes or int(os.environ.get("LIA_DP_CHUNK_BYTES", DEFAULT_CHUNK))
         self.root = 0
+        # how a streamed layer reaches the G ranks: "broadcast" (BASELINE.json: rank 0 reads it over its link, one RCCL
+        # broadcast) or "allgather" (SURVEY.md section 8e alternative: every rank keeps and reads 1/G of the wire bytes over
+        # ITS OWN host link, one all-gather over xGMI puts the layer together -- G times the host-link rate)
+        self.mode = os.environ.get("LIA_DP_STREAM", "broadcast").lower()
+        if self.mode not in ("broadcast", "allgather"):
+            raise ValueError(f"LIA_DP_STREAM={self.mode!r}: expected broadcast or allgather")
 
     @property
     def is_root(self):

@@ -67,7 +67,8 @@ class LayerStore:
     def __init__(self, desc, offsets, total_bytes):
         self.desc, self.offsets, self.nbytes = desc, offsets, total_bytes
         self.tier = None          # "device" | "pinned" | "cxl" | "pageable" | "remote"
-        self.packed = 0           # 0: host copy is raw bf16; 11 / 12: it holds that lossless encoding (lia_pack12.hip)
+        self.packed = 0           # 0: host copy is raw bf16; 10 / 11 / 12: it holds that lossless encoding (lia_pack12.hip)
+        self.shard = None         # (rank, world, slice bytes) when the host copy is one slice of the wire bytes
         self.stream_bytes = total_bytes   # bytes that cross the host link per use
         self._dev = None          # torch uint8 CUDA tensor
         self._np = None           # numpy uint8 (pageable)
@@ -149,10 +150,13 @@ class LayerStore:
             return None            # the encoding is no smaller than the raw layer (very wide distribution): ship raw
         return enc, out.value
 
-    def to_pinned(self, pack12=False):
+    def to_pinned(self, pack12=False, shard=None):
         """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227); with pack12 the pinned copy is
-        the lossless 12-bit encoding (75 % of the bytes)."""
+        the lossless 12-bit encoding (75 % of the bytes).  shard = (r, G): keep only the r-th of G equal slices of the wire
+        bytes (data-parallel "allgather" streaming: every rank pulls its slice over its own link)."""
         fmt = {False: 0, True: 12, None: 0}.get(pack12, pack12)          # accepts False / True (= 12) / 11 / 12
+        if shard is not None and shard[1] > 1:
+            return self._to_pinned_shard(fmt, shard)
         if self.tier == "pinned":
             if self.packed and not fmt:
                 raise ValueError("layer is pinned in a packed wire format but the raw bf16 copy was requested")
@@ -175,6 +179,41 @@ class LayerStore:
         self._free()
         self._ptr, self.tier = ptr, "pinned"
         self.packed, self.stream_bytes = (fmt if enc else 0), nbytes
+
+    @staticmethod
+    def shard_bytes(total, world):
+        """slice size of a `total`-byte wire buffer over `world` ranks: equal, 256-byte aligned slices (the last one padded)"""
+        return ((total + world - 1) // world + 255) // 256 * 256
+
+    def _to_pinned_shard(self, fmt, shard):
+        r, G = shard
+        enc = None
+        if fmt in (10, 11) and self.nbytes % 2048 == 0:
+            enc = self._encode_packed(fmt)
+        elif fmt == 12 and self.nbytes % 32 == 0:
+            enc = self._encode_packed(12)
+        if enc:
+            src, total = enc
+        else:
+            if self.tier != "device":
+                src = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
+                N.check(self._lib.lia_memcpy_h2d(src.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
+            else:
+                src = self._dev
+            total = self.nbytes
+        sh = self.shard_bytes(total, G)
+        lo, hi = min(r * sh, total), min((r + 1) * sh, total)
+        from . import hostinfo
+        hostinfo.guard_host_allocation(sh, "pinning a slice of a streamed layer")
+        ptr = self._lib.lia_host_alloc_pinned(sh)
+        if not ptr:
+            raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
+        ctypes.memset(ptr, 0, sh)
+        if hi > lo:
+            N.check(self._lib.lia_memcpy_d2h(ptr, src.data_ptr() + lo, hi - lo), "lia_memcpy_d2h")
+        self._free()
+        self._ptr, self.tier = ptr, "pinned"
+        self.packed, self.stream_bytes, self.shard = (fmt if enc else 0), total, (r, G, sh)
 
     def to_cxl(self, pack=0):
         """realloc_to_numa (lia/modeling_opt.py:168-175) + hipHostRegister so the copy engine can DMA from it
@@ -216,7 +255,7 @@ class LayerStore:
             self._lib.numa_free_node(self._ptr, self.stream_bytes)      # the size it was allocated with
         self._ptr = self._dev = self._np = None
         self.tier = None
-        self.packed, self.stream_bytes = 0, self.nbytes
+        self.packed, self.stream_bytes, self.shard = 0, self.nbytes, None
 
     def close(self):
         self._free()
@@ -259,7 +298,7 @@ class LiaOPTModel:
 
     @classmethod
     def random_init(cls, shape, seed=0, init="normal", n_gpu_layers=0, pin_weight=True, enable_cxl=False,
-                    host_owner=True, pack12=False, raw_layers=()):
+                    host_owner=True, pack12=False, raw_layers=(), shard=None):
         """Random-init weights of the exact architecture, generated ON THE GPU one layer at a time and
         moved straight to their tier (an OPT-30B would take minutes to draw on the CPU).
         init="normal": HF _init_weights (lia/modeling_opt.py:895-904): Linear/Embedding ~ N(0, 0.02), zero
@@ -270,7 +309,7 @@ class LiaOPTModel:
         self = cls(shape)
         if host_owner:
             from . import hostinfo
-            hostinfo.check_host_allocation(int(self.streamed_bytes(n_gpu_layers) * (0.76 if pack12 else 1.0)),
+            hostinfo.check_host_allocation(int(self.streamed_bytes(n_gpu_layers) * (0.76 if pack12 else 1.0) / (shard[1] if shard else 1)),
                                            f"{shape.name}: {shape.layers - n_gpu_layers} streamed layers")
         g = torch.Generator(device="cuda")
         g.manual_seed(seed * 100003)
@@ -308,7 +347,7 @@ class LiaOPTModel:
                 if enable_cxl:
                     st.to_cxl(fmt if fmt not in (False, None) else 0)
                 elif pin_weight:
-                    st.to_pinned(fmt)
+                    st.to_pinned(fmt, shard=shard)
                 else:
                     st.to_pinned()  # leave the device; demoted to pageable below
                     host = np.array(st._host_view(), copy=True)
@@ -319,7 +358,7 @@ class LiaOPTModel:
         return self
 
     # -- placement (first forward) ------------------------------------------------------------------
-    def place(self, n_gpu_layers, pin_weight, enable_cxl, pack12=False, raw_layers=()):
+    def place(self, n_gpu_layers, pin_weight, enable_cxl, pack12=False, raw_layers=(), shard=None):
         """Idempotent tier assignment done on the first forward, as move_gpu_layer / pin_memory are
         (lia/modeling_opt.py:1182-1184, 1214-1217)."""
         key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
@@ -340,7 +379,7 @@ class LiaOPTModel:
                 st.to_cxl(0 if i in raw_layers else {False: 0, True: 12, None: 0}.get(pack12, pack12))
             elif pin_weight:
                 if st.tier != "pinned":
-                    st.to_pinned(0 if i in raw_layers else pack12)
+                    st.to_pinned(0 if i in raw_layers else pack12, shard=shard)
         torch.cuda.synchronize()
         self.placed_for = key
 

@@ -57,6 +57,11 @@ class WeightPipeline:
                         meta[i, 0], meta[i, 1] = int(st.packed), int(st.stream_bytes)
             dp_group.dist.broadcast(meta, src=dp_group.root)
             self.layer_meta = meta.cpu().tolist()
+            if dp_group.mode == "allgather":
+                for i, st in enumerate(model.layers):
+                    if st.tier not in ("device", None, "remote") and [int(st.packed), int(st.stream_bytes)] != self.layer_meta[i]:
+                        raise RuntimeError(f"layer {i}: this rank's wire encoding differs from the root's (allgather streaming needs "
+                                           "identical weights and format on every rank)")
 
     def can_prefetch(self):
         return len(self.inflight) + len(self.held) < self.n_slots
@@ -75,6 +80,8 @@ class WeightPipeline:
         elif self.dp is None:
             N.check(self.lib.lia_stream_prefetch(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.nbytes, int(st.is_dma_able())),
                     "lia_stream_prefetch")
+        elif self.dp.mode == "allgather":
+            self._prefetch_allgather(st, slot, layer_idx)
         else:
             self._prefetch_broadcast(st, slot, layer_idx)
         self.inflight.append((layer_idx, slot))
@@ -88,12 +95,7 @@ class WeightPipeline:
         packed, nbytes = self.layer_meta[layer_idx]
         N.check(self.lib.lia_stream_begin(self.handle, slot), "lia_stream_begin")
         if packed:
-            if self.staging_tensors is None:
-                cap = max(self.lib.lia_pack12_bound(self.model.layer_bytes // 2), self.lib.lia_pack11_bound(self.model.layer_bytes // 2),
-                          self.lib.lia_pack10_bound(self.model.layer_bytes // 2))
-                self.staging_tensors = [RawDeviceBuffer(self.lib.lia_stream_staging_ptr(self.handle, s), cap).tensor()
-                                        for s in range(self.n_slots)]
-            target, copy_fn = self.staging_tensors[slot][:nbytes], self.lib.lia_stream_copy_chunk_packed
+            target, copy_fn = self._staging()[slot][:nbytes], self.lib.lia_stream_copy_chunk_packed
         else:
             target, copy_fn = self.slot_tensors[slot][:self.model.layer_bytes], self.lib.lia_stream_copy_chunk
         before = None
@@ -106,6 +108,49 @@ class WeightPipeline:
             works = broadcast_chunked(dp.dist, target, dp.root, dp.chunk_bytes, before_chunk=before)
             for w in works:
                 w.wait()              # the copy stream waits for RCCL's stream; the host does not block
+        if packed:
+            N.check(self.lib.lia_stream_decode_packed(self.handle, slot, self.model.layer_bytes // 2, int(packed)), "lia_stream_decode_packed")
+        N.check(self.lib.lia_stream_mark_ready(self.handle, slot), "lia_stream_mark_ready")
+
+    def _staging(self):
+        if self.staging_tensors is None:
+            from .dp import RawDeviceBuffer
+            cap = max(self.lib.lia_pack12_bound(self.model.layer_bytes // 2), self.lib.lia_pack11_bound(self.model.layer_bytes // 2),
+                      self.lib.lia_pack10_bound(self.model.layer_bytes // 2))
+            self.staging_tensors = [RawDeviceBuffer(self.lib.lia_stream_staging_ptr(self.handle, s), cap).tensor()
+                                    for s in range(self.n_slots)]
+        return self.staging_tensors
+
+    def _prefetch_allgather(self, st, slot, layer_idx):
+        """Every rank copies ITS slice of the layer's wire bytes host -> device over its own link, then one all-gather on
+        the copy stream assembles the layer in every rank's slot (or staging area, then the decode kernel)."""
+        from .model import LayerStore
+        dp = self.dp
+        packed, nbytes = self.layer_meta[layer_idx]
+        G, r = dp.world, dp.rank
+        sh = LayerStore.shard_bytes(nbytes, G)
+        if st.shard is None or st.shard != (r, G, sh):
+            raise ValueError(f"layer {layer_idx}: allgather streaming needs the host copy pinned as slice {r} of {G} "
+                             "(LiaOPTModel.random_init(..., shard=(rank, world)))")
+        N.check(self.lib.lia_stream_begin(self.handle, slot), "lia_stream_begin")
+        if packed:
+            full, copy_fn = self._staging()[slot], self.lib.lia_stream_copy_chunk_packed
+        else:
+            full, copy_fn = self.slot_tensors[slot], self.lib.lia_stream_copy_chunk
+        if G * sh > full.numel():
+            raise ValueError(f"layer {layer_idx}: {G} slices of {sh} bytes do not fit the {full.numel()}-byte slot")
+        full = full[:G * sh]
+        N.check(copy_fn(self.handle, slot, r * sh, ctypes.c_void_p(st.host_ptr()), sh, int(st.is_dma_able())), "lia_stream_copy_chunk")
+        mine = full[r * sh:(r + 1) * sh]
+        with torch.cuda.stream(self.copy_stream):
+            if dp.dist.get_backend() == "nccl":
+                dp.dist.all_gather_into_tensor(full, mine, async_op=True).wait()      # in place: `mine` is slice r of `full`
+            else:
+                parts = [torch.empty_like(mine) for _ in range(G)]                    # gloo (validation runs): out of place
+                dp.dist.all_gather(parts, mine.clone())
+                for g, p in enumerate(parts):
+                    if g != r:
+                        full[g * sh:(g + 1) * sh].copy_(p)
         if packed:
             N.check(self.lib.lia_stream_decode_packed(self.handle, slot, self.model.layer_bytes // 2, int(packed)), "lia_stream_decode_packed")
         N.check(self.lib.lia_stream_mark_ready(self.handle, slot), "lia_stream_mark_ready")
@@ -292,7 +337,9 @@ class OffloadScheduler:
         # move_gpu_layer / pin_memory, idempotent.  The policy-1 host path reads the host copy directly, so the pack12
         # wire format is only used when neither phase runs on the CPU.
         cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and decoding_policy == 2 and self.dp is None) else frozenset()
-        m.place(n_gpu, pin_weight, enable_cxl, self.pack12 and prefill_policy != 1 and decoding_policy != 1, raw_layers=cpu_set)
+        shard = (self.dp.rank, self.dp.world) if (self.dp is not None and self.dp.world > 1 and self.dp.mode == "allgather") else None
+        m.place(n_gpu, pin_weight, enable_cxl, self.pack12 and prefill_policy != 1 and decoding_policy != 1, raw_layers=cpu_set,
+                shard=shard)
         host_now = cpu_set if not is_prefill else frozenset()     # layers this forward computes on the host
         rows = B * T if n_gpu > 0 else mini * T                    # resident layers take the whole batch
         if policy == 0 and n_gpu < L:

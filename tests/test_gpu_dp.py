@@ -23,10 +23,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage):
+def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode):
     for p in (ROOT, os.path.join(ROOT, "isca-2025-lia_amd"), GOLD):
         sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIA_DP_CHUNK_BYTES=str(96 * 1024))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIA_DP_CHUNK_BYTES=str(96 * 1024), LIA_DP_STREAM=mode)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage):
         model = LiaOPTModel.from_numpy(shape, m)
         n_gpu = int(L * gpu_percentage / 100)
         g = dp.DataParallelGroup(dist, rank, world, rank)
-        if not g.is_root:
+        if not g.is_root and mode == "broadcast":
             for li, st in enumerate(model.layers):
                 if li >= n_gpu:
                     st._free()
@@ -59,7 +59,9 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage):
         assert (out.numpy() == z["ids_bf16"][lo:hi]).all(), (rank, out[:, T:].tolist())
         full = g.gather_ids(out, B)
         assert (full.numpy() == z["ids_bf16"]).all()
-        if not g.is_root:
+        if mode == "allgather":       # every rank pinned exactly its slice of every streamed layer's wire bytes
+            assert all(st.shard is not None and st.shard[:2] == (rank, world) for st in model.layers[n_gpu:])
+        elif not g.is_root:
             assert all(st.tier == "remote" for st in model.layers[n_gpu:])
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
         model._lia_scheduler.close()
@@ -67,10 +69,12 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["broadcast", "allgather"])
 @pytest.mark.parametrize("fmt", ["raw", "pack10"])
 @pytest.mark.parametrize("gpu_percentage", [0, 50])
-def test_two_ranks_one_gpu_match_golden(tmp_path, fmt, gpu_percentage):
+def test_two_ranks_one_gpu_match_golden(tmp_path, fmt, gpu_percentage, mode):
+    """mode = how a streamed layer reaches both ranks: the root's copy + one broadcast, or each rank's half + one all-gather."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), fmt, "generate_h256", gpu_percentage), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), fmt, "generate_h256", gpu_percentage, mode), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
