@@ -137,6 +137,11 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count()) if os.environ.get("LIA_DP_SAME_GPU") == "1" else local_rank
     backend = os.environ.get("LIA_DP_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
+    # the reference pins its CPU work with `numactl -m 0 -C 0-39` (README.md:78); here: the cores of the GPU's NUMA node, where
+    # the pinned weights and KV caches live (LIA_PIN_NODE=<n> overrides, -1 = no pinning).  Must precede the first OpenMP team.
+    from lia_amd import hostinfo as _hi
+    pin_node = int(os.environ["LIA_PIN_NODE"]) if os.environ.get("LIA_PIN_NODE") is not None else _hi.gpu_numa_node(dev_index)
+    pinned_cpus = _hi.pin_to_node(pin_node) if pin_node >= 0 else 0
     dist = None
     force_dp = os.environ.get("LIA_FORCE_DP") == "1"      # exercise the broadcast path on a single GPU (world 1)
     if world > 1 or force_dp:
@@ -268,7 +273,7 @@ def main():
                                    f"num-minibatch {a.num_minibatch}{', ' + str(a.cpu_layers) + ' decode layers on the host cores' if a.cpu_layers else ''}",
                        "global_batch": B * world, "prompt_len": T, "new_tokens": new,
                        "parallelism": (f"dp{world} batch-shard, {group.mode} weight stream" if world > 1 else "single GPU"),
-                       "host_attention_threads": host_threads},
+                       "host_attention_threads": host_threads, "host_numa_node": pin_node if pinned_cpus else None},
             "prefill_ms": prefill_ms,
             "decode_latency_ms": {"mean": 1e3 * sum(step_lat) / len(step_lat), "p90": 1e3 * sorted(step_lat)[int(0.9 * (len(step_lat) - 1))],
                                   "max": 1e3 * max(step_lat)},

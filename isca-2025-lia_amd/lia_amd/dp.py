@@ -70,18 +70,24 @@ class DataParallelGroup:
         return torch.cat([o[:hi - lo].cpu() for o, (lo, hi) in zip(outs, sizes)], dim=0)
 
     def pin_host_threads(self, ncpu=None):
-        """Give each rank its own slice of the physical cores for the policy-2 host attention, so G ranks do not
-        oversubscribe one another (OpenMP threads inherit the process affinity mask)."""
+        """Give each rank its own slice of the physical cores it may use (the current affinity mask -- bench.py has already
+        narrowed it to the NUMA node of this rank's GPU) for the policy-2 host attention, so G ranks do not oversubscribe one
+        another (OpenMP threads inherit the process affinity mask).  Slices are indexed by local rank over `world` equal
+        parts, so ranks that share a node never overlap."""
         ncpu = ncpu or (os.cpu_count() or 1)
-        phys = max(1, ncpu // 2)
-        per = max(1, phys // self.world)
-        lo = self.local_rank * per
-        cores = set(range(lo, min(phys, lo + per)))
+        try:
+            avail = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            return 0
+        phys = [c for c in avail if c < max(1, ncpu // 2)] or avail
+        per = max(1, len(phys) // self.world)
+        lo = (self.local_rank % self.world) * per
+        cores = set(phys[lo:lo + per]) or set(phys)
         try:
             os.sched_setaffinity(0, cores)
         except (AttributeError, OSError):
             pass
-        return per
+        return len(cores)
 
 
 class RawDeviceBuffer:

@@ -46,6 +46,47 @@ def default_host_threads(world=1):
     return max(1, n // max(1, world))
 
 
+def node_cpus(node):
+    """CPU ids of a NUMA node (sysfs cpulist), or None"""
+    try:
+        txt = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+    except OSError:
+        return None
+    cpus = set()
+    for part in txt.split(","):
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(dev_index=0):
+    """NUMA node of a GPU from sysfs (PCI ids via torch's device properties), or -1 when unknown: pinned host memory is
+    allocated next to the GPU, so the host-compute threads belong on that node's cores."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(dev_index)
+        path = f"/sys/bus/pci/devices/{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0/numa_node"
+        return int(open(path).read().strip())
+    except Exception:
+        return -1
+
+
+def pin_to_node(node):
+    """Restrict this process (and the OpenMP teams it will create) to the CPUs of one NUMA node -- the reference's
+    `numactl -m 0 -C 0-39` (README.md:78) for a box where numactl is not ours to run.  Returns the CPU count or 0."""
+    cpus = node_cpus(node)
+    if not cpus:
+        return 0
+    try:
+        allowed = os.sched_getaffinity(0) & cpus
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            return len(allowed)
+    except (AttributeError, OSError):
+        pass
+    return 0
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
