@@ -90,6 +90,15 @@ def main(argv=None):
     print(args)
     if not args.benchmark:
         print("note: only --benchmark mode exists here (no tokenizer offline); running the benchmark protocol")
+    # the reference's launch line is `OMP_NUM_THREADS=40 numactl -m 0 -C 0-39 python run.py ...` (README.md:78): host compute
+    # on the node that holds the pinned weights / KV caches.  Here: the NUMA node of GPU 0 (LIA_PIN_NODE overrides, -1 = off).
+    import os
+    from . import hostinfo
+    import torch
+    if torch.cuda.is_available():
+        node = int(os.environ["LIA_PIN_NODE"]) if os.environ.get("LIA_PIN_NODE") is not None else hostinfo.gpu_numa_node(0)
+        if node >= 0 and hostinfo.pin_to_node(node):
+            print(f"host threads pinned to NUMA node {node}")
     model = load_model(args)
     generate_kwargs = dict(do_sample=False, num_beams=1, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
                            token_latency=args.token_latency, prefill_policy=args.prefill_policy,
