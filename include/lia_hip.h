@@ -56,6 +56,7 @@ int lia_ctx_set_host_threads(lia_ctx* ctx, int n); /* OpenMP threads of the poli
 typedef struct {
   long skinny_launches; double skinny_ms, skinny_bytes, skinny_flops; /* decode regime (M <= 256)  */
   long tiled_launches;  double tiled_ms, tiled_bytes, tiled_flops;    /* prefill regime            */
+  double empty_bracket_ms; /* what an event pair around NOTHING reads on this stream: the bracket's own cost, measured at stop */
 } lia_prof_result;
 int lia_prof_start(lia_ctx* ctx, int max_launches);
 int lia_prof_stop(lia_ctx* ctx, lia_prof_result* out); /* synchronises the compute stream */

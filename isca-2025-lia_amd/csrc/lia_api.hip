@@ -171,6 +171,20 @@ extern "C" int lia_prof_stop(lia_ctx* c, lia_prof_result* out) {
     if (r.regime == 1) { out->skinny_launches++; out->skinny_ms += ms; out->skinny_bytes += r.bytes; out->skinny_flops += r.flops; }
     else { out->tiled_launches++; out->tiled_ms += ms; out->tiled_bytes += r.bytes; out->tiled_flops += r.flops; }
   }
+  // calibrate the bracket: 32 empty event pairs on the same stream (rocprofv3's kernel durations carry no such term)
+  if (c->prof_events->size() >= 2) {
+    double sum = 0.0;
+    const int reps = 32;
+    for (int i = 0; i < reps; ++i) {
+      HIP_TRY(hipEventRecord((*c->prof_events)[0], c->compute));
+      HIP_TRY(hipEventRecord((*c->prof_events)[1], c->compute));
+      HIP_TRY(hipEventSynchronize((*c->prof_events)[1]));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, (*c->prof_events)[0], (*c->prof_events)[1]));
+      sum += ms;
+    }
+    out->empty_bracket_ms = sum / reps;
+  }
   return LIA_OK;
 }
 

@@ -26,7 +26,8 @@ class LayerDesc(ctypes.Structure):
 
 class ProfResult(ctypes.Structure):
     _fields_ = [("skinny_launches", c_long), ("skinny_ms", c_double), ("skinny_bytes", c_double), ("skinny_flops", c_double),
-                ("tiled_launches", c_long), ("tiled_ms", c_double), ("tiled_bytes", c_double), ("tiled_flops", c_double)]
+                ("tiled_launches", c_long), ("tiled_ms", c_double), ("tiled_bytes", c_double), ("tiled_flops", c_double),
+                ("empty_bracket_ms", c_double)]
 
 
 class LlamaDesc(ctypes.Structure):
