@@ -77,6 +77,18 @@ __device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char
                                                  const LiaEpilogue& ep, const LiaOutMap& om, int lane) {
   const int l15 = lane & 15, lq = lane >> 4;
   const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+  const int c = lane & 7;
+  // the residual rows of the whole wave tile, all requested up front (clamped addresses, no branch around a load: a load
+  // inside the per-row `if` below is waited for on the spot -- 16 dependent round trips, ~13 us per tile): their latency
+  // then hides behind the accumulator -> LDS pass
+  uint4 rres[2 * MB];
+  if (hr) {
+#pragma unroll
+    for (int r = 0; r < 2 * MB; ++r) {
+      const int gm = min(m_base + r * 8 + (lane >> 3), M - 1), gn = min(n_base + c * 8, N - 8);
+      rres[r] = *(const uint4*)(ep.residual + (long)gm * ep.ldr + gn);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -103,24 +115,21 @@ __device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char
     }
   }
   // same-wave LDS write -> read: program order + the compiler's lgkmcnt wait suffice (the region is private)
-  const int c = lane & 7;
 #pragma unroll
   for (int r = 0; r < 2 * MB; ++r) {
     const int m = r * 8 + (lane >> 3);
     const int gm = m_base + m, gn = n_base + c * 8;
     uint4 v = *(const uint4*)(region + m * 128 + ((c ^ (m & 7)) << 4));
-    if (gm < M && gn < N) {
-      if (hr) {
-        uint4 rr = *(const uint4*)(ep.residual + (long)gm * ep.ldr + gn);
-        const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
-        uint32_t ow[4];
+    if (hr) {
+      const uint4 rr = rres[r];
+      const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+      uint32_t ow[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          ow[e] = pack_bf16x2(bf2f(rw[e] & 0xffff) + bf2f(vw[e] & 0xffff), bf2f(rw[e] >> 16) + bf2f(vw[e] >> 16));
-        v = uint4{ow[0], ow[1], ow[2], ow[3]};
-      }
-      *(uint4*)lia_out_ptr(om, gm, gn) = v;
+      for (int e = 0; e < 4; ++e)
+        ow[e] = pack_bf16x2(bf2f(rw[e] & 0xffff) + bf2f(vw[e] & 0xffff), bf2f(rw[e] >> 16) + bf2f(vw[e] >> 16));
+      v = uint4{ow[0], ow[1], ow[2], ow[3]};
     }
+    if (gm < M && gn < N) *(uint4*)lia_out_ptr(om, gm, gn) = v;
   }
 }
 
