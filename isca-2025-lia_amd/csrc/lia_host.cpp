@@ -374,7 +374,8 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
 // y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.
 static void host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                         long M, int N, int K, int relu) {
-  if (M <= 256 && !getenv("LIA_HOST_LINEAR_V1")) { host_linear_skinny(x, w, bias, residual, y, (int)M, N, K, relu); return; }
+  static const bool use_v1 = getenv("LIA_HOST_LINEAR_V1") != nullptr;   // A/B knob of tools/host_linear_bench.py, read once
+  if (M <= 256 && !use_v1) { host_linear_skinny(x, w, bias, residual, y, (int)M, N, K, relu); return; }
   constexpr int RB = 4;
   const long mblocks = (M + RB - 1) / RB;
   const int nblocks = (N + RB - 1) / RB;
