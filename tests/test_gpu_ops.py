@@ -356,3 +356,31 @@ def test_pack12_roundtrip_is_bit_exact(gpu, kind, fmt):
     N.check(L.lia_memcpy_d2h(res.ctypes.data, ctypes.c_void_p(slot), 2 * n))
     assert (res == bits).all(), int((res != bits).sum())
     L.lia_stream_destroy(h)
+
+
+def test_blit_and_pinned_pool_round_trip(gpu):
+    """lia_blit (kernel copy over mapped pinned memory: the activation hops of the cooperative policies) and the exact-size
+    pinned pool behind the host KV caches: device -> pinned -> device round trip, block recycling, argument errors."""
+    import ctypes
+    ctx, ops, torch = gpu
+    from lia_amd import _native as N
+    from lia_amd.scheduler import PinnedPool
+    L = N.lib()
+    n = 64 * 7168
+    src = torch.arange(n, dtype=torch.int32, device="cuda").to(torch.int16)
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    p = PinnedPool.acquire(2 * n)
+    N.check(L.lia_blit(ctypes.c_void_p(p), ctypes.c_void_p(src.data_ptr()), 2 * n, ctypes.c_void_p(ctx.stream)))
+    ctx.synchronize()
+    host = PinnedPool.as_tensor(p, (n,)).view(torch.int16)
+    assert torch.equal(host, src.cpu())
+    N.check(L.lia_blit(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(p), 2 * n, ctypes.c_void_p(ctx.stream)))
+    ctx.synchronize()
+    assert torch.equal(dst, src)
+    with pytest.raises(ValueError):
+        N.check(L.lia_blit(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(p), 2 * n - 2, ctypes.c_void_p(ctx.stream)))   # not 16-byte
+    PinnedPool.release(p, 2 * n)
+    assert PinnedPool.acquire(2 * n) == p                     # same size -> the block comes back from the free list
+    PinnedPool.release(p, 2 * n)
+    PinnedPool.trim()
