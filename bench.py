@@ -74,7 +74,33 @@ def cpu_baseline(shape, B, T, threads=None):
     t0 = time.time()
     orc.layer_forward(1, W, xp, kp, vp, 0, heads)
     pre_layer_s = (time.time() - t0) * (B / Bp)
+    # beside it: the product's own policy-1 layer (lia_host_layer_forward, the code `--decoding-policy 1` and --cpu-layers
+    # run) on the same sample -- the faster CPU implementation of the two, so the GPU/CPU ratio is not flattered
+    product_tps = None
+    try:
+        import ctypes
+        from lia_amd import _native as N, ops
+        desc = ops.make_desc(H, heads, F)
+        offs, total = ops.pack_offsets(desc)
+        flat = np.zeros(total // 2, np.uint16)
+        order = ["ln1_w", "ln1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
+                 "fc2_w", "fc2_b"]
+        for i, name in enumerate(order):
+            a = W[name].reshape(-1)
+            flat[offs[i] // 2: offs[i] // 2 + a.size] = a
+        wp = ops.weight_ptr_array(flat.ctypes.data, offs)
+        yd = np.empty_like(xd)
+        args = (ctypes.byref(desc), ctypes.byref(wp), xd.ctypes.data, yd.ctypes.data, kc.ctypes.data, vc.ctypes.data, T + 2, B, B, 1, T, 0,
+                threads)
+        N.check(N.lib().lia_host_layer_forward(*args))
+        t0 = time.time()
+        for _ in range(reps):
+            N.check(N.lib().lia_host_layer_forward(*args))
+        product_tps = B / ((time.time() - t0) / reps * L)
+    except Exception as e:          # the baseline of record is the oracle's; this one is informative
+        product_tps = f"not measured: {e}"
     return {"value": B / (dec_layer_s * L), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "product_host_path_tokens_s": product_tps,
             "cpu": hostinfo.cpu_model(), "isa": hostinfo.isa_flags(), "cpus_usable": hostinfo.usable_cpus(),
             "prefill_ms": 1e3 * pre_layer_s * L,
             "inner_loop": "avx512_bf16 vdpbf16ps" if fast else "fp32 fma",
