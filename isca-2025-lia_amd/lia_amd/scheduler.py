@@ -57,7 +57,7 @@ class WeightPipeline:
                         meta[i, 0], meta[i, 1] = int(st.packed), int(st.stream_bytes)
             dp_group.dist.broadcast(meta, src=dp_group.root)
             self.layer_meta = meta.cpu().tolist()
-            if dp_group.mode == "allgather":
+            if dp_group.mode == "allgather" and dp_group.world > 1:
                 for i, st in enumerate(model.layers):
                     if st.tier not in ("device", None, "remote") and [int(st.packed), int(st.stream_bytes)] != self.layer_meta[i]:
                         raise RuntimeError(f"layer {i}: this rank's wire encoding differs from the root's (allgather streaming needs "
@@ -80,7 +80,7 @@ class WeightPipeline:
         elif self.dp is None:
             N.check(self.lib.lia_stream_prefetch(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.nbytes, int(st.is_dma_able())),
                     "lia_stream_prefetch")
-        elif self.dp.mode == "allgather":
+        elif self.dp.mode == "allgather" and self.dp.world > 1:        # (one rank: nothing to gather, the broadcast path serves)
             self._prefetch_allgather(st, slot, layer_idx)
         else:
             self._prefetch_broadcast(st, slot, layer_idx)
