@@ -1,0 +1,18 @@
+"""-m gpu: randomised shape sweep of lia_linear over every GEMM regime (tools/gemm_fuzz.py) against a plain PyTorch fp32
+matmul of the same bf16 operands with the reference's rounding points."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_linear_fuzz(seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_fuzz.py"), "120", str(seed)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "120 cases ok" in r.stdout
