@@ -40,6 +40,10 @@ def build_parser():
     p.add_argument("--num-minibatch", default=1, type=int)
     p.add_argument("--enable-cxl", action="store_true")
     # build-specific
+    p.add_argument("--stream-format", default=os.environ.get("LIA_STREAM_FORMAT", "raw"), choices=["raw", "pack12", "pack11", "pack10"],
+                   help="wire format of the pinned streamed layers: raw bf16 (what the reference ships) or a lossless packed format")
+    p.add_argument("--cpu-layers", default=0, type=int,
+                   help="with --decoding-policy 2: this many streamed layers take their decode step on the host cores (policy 1 per layer)")
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--init", default="normal", choices=["normal", "uniform01"],
                    help="uniform01 = the reference's dummy-weight recipe (utils/opt-weight-gen.py:61-62)")
@@ -59,8 +63,13 @@ def load_model(args):
         return load_hf_opt(args.model_id)
     shape = resolve_shape(args.model_id)
     n_gpu = int(shape.layers * args.gpu_percentage / 100)
+    fmt = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[args.stream_format]
+    if args.prefill_policy == 1 or args.decoding_policy == 1:
+        fmt = 0                      # the host path reads the raw copy in place
+    from .scheduler import OffloadScheduler
+    raw = OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, args.cpu_layers) if (args.cpu_layers and args.decoding_policy == 2) else ()
     return LiaOPTModel.random_init(shape, seed=args.seed, init=args.init, n_gpu_layers=n_gpu,
-                                   pin_weight=args.pin_weight or args.enable_cxl, enable_cxl=args.enable_cxl)
+                                   pin_weight=args.pin_weight or args.enable_cxl, enable_cxl=args.enable_cxl, pack12=fmt, raw_layers=raw)
 
 
 def summarize(total_time, num_iter, num_warmup, total_list, batch_size, out=print):
@@ -99,11 +108,14 @@ def main(argv=None):
         node = int(os.environ["LIA_PIN_NODE"]) if os.environ.get("LIA_PIN_NODE") is not None else hostinfo.gpu_numa_node(0)
         if node >= 0 and hostinfo.pin_to_node(node):
             print(f"host threads pinned to NUMA node {node}")
+    os.environ["LIA_STREAM_FORMAT"] = args.stream_format          # the scheduler generate() creates reads it
     model = load_model(args)
     generate_kwargs = dict(do_sample=False, num_beams=1, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
                            token_latency=args.token_latency, prefill_policy=args.prefill_policy,
                            decoding_policy=args.decoding_policy, no_overlap=args.no_overlap, pin_weight=args.pin_weight,
                            gpu_percentage=args.gpu_percentage, num_minibatch=args.num_minibatch, enable_cxl=args.enable_cxl)
+    if args.cpu_layers:
+        generate_kwargs["cpu_layers"] = args.cpu_layers
     input_ids = synthetic_prompt(model.shape.vocab, int(args.input_tokens), args.batch_size)
     total_time, total_list = 0.0, []
     for i in range(args.num_iter):
