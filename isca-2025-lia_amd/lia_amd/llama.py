@@ -91,7 +91,8 @@ class LiaLlamaModel:
         return self
 
     @classmethod
-    def random_init(cls, shape, seed=0, n_gpu_layers=None, pin_weight=True):
+    def random_init(cls, shape, seed=0, n_gpu_layers=None, pin_weight=True, pack=0):
+        """pack = 0 / 10 / 11 / 12: wire format of the pinned streamed layers (lia_pack12.hip), as for the OPT model"""
         self = cls(shape)
         n_gpu = shape.layers if n_gpu_layers is None else n_gpu_layers
         from . import hostinfo
@@ -115,12 +116,12 @@ class LiaLlamaModel:
                     flat[o:o + H] = 1.0
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu:
-                st.to_pinned()
+                st.to_pinned(pack)
         torch.cuda.synchronize()
         self.placed_for = (n_gpu, True, False)
         return self
 
-    def place(self, n_gpu_layers, pin_weight, enable_cxl):
+    def place(self, n_gpu_layers, pin_weight, enable_cxl, pack=0):
         key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
         if self.placed_for == key:
             return
@@ -130,9 +131,9 @@ class LiaLlamaModel:
             elif st.tier == "device":
                 raise ValueError("gpu_percentage shrank between calls: resident layers cannot be demoted")
             elif enable_cxl and pin_weight:
-                st.to_cxl()
+                st.to_cxl(pack)
             elif pin_weight:
-                st.to_pinned()
+                st.to_pinned(pack)
         torch.cuda.synchronize()
         self.placed_for = key
 
@@ -156,8 +157,11 @@ class LlamaKVState:
 class LlamaScheduler:
     """forward(ids, kv, gpu_percentage=..., num_minibatch=...) -> (logits, next ids) on the device."""
 
-    def __init__(self, model, device=0, n_slots=4):
+    def __init__(self, model, device=0, n_slots=4, pack=None):
+        import os
         self.model, self.device, self.n_slots = model, device, n_slots
+        fmt = os.environ.get("LIA_STREAM_FORMAT", "raw").lower() if pack is None else pack
+        self.pack = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, 0: 0, 10: 10, 11: 11, 12: 12, False: 0, True: 12}[fmt]
         self.ctx = self.pipe = None
         self.hidden, self.resident, self.tables = {}, {}, None
 
@@ -196,7 +200,7 @@ class LlamaScheduler:
         if B % num_minibatch:
             raise ValueError(f"batch {B} not divisible by num_minibatch {num_minibatch}")
         mini = B // num_minibatch if T > 1 else B
-        m.place(n_gpu, pin_weight, enable_cxl)
+        m.place(n_gpu, pin_weight, enable_cxl, self.pack)
         x, y = self._ensure(mini * T, B, T, n_gpu, kv_state.smax)
         ctx, pipe = self.ctx, self.pipe
         st = ctypes.c_void_p(ctx.stream)

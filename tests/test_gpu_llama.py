@@ -61,9 +61,13 @@ def test_llama_layer_forward(oracle, name):
     model.close()
 
 
+@pytest.mark.parametrize("fmt", ["raw", "pack10"])
 @pytest.mark.parametrize("gpu_pct,mb", [(100, 1), (34, 1), (0, 2)])
-def test_llama_generate_ids_match_hf(gpu_pct, mb):
+def test_llama_generate_ids_match_hf(gpu_pct, mb, fmt, monkeypatch):
     import torch
+    monkeypatch.setenv("LIA_STREAM_FORMAT", fmt)
+    if fmt != "raw" and gpu_pct >= 100:
+        pytest.skip("nothing is streamed")
     from lia_amd.generation import generate
     from lia_amd.llama import LiaLlamaModel, LlamaShape
     z = np.load(os.path.join(GOLD, "llama_generate_h256.npz"))
@@ -75,5 +79,8 @@ def test_llama_generate_ids_match_hf(gpu_pct, mb):
     out, lat = generate(model, torch.from_numpy(ids), max_new_tokens=new, min_new_tokens=new, token_latency=True,
                         gpu_percentage=gpu_pct, num_minibatch=mb, pin_weight=True)
     assert (out.numpy() == z["ids_bf16"]).all(), (out[0, T:].tolist(), z["ids_bf16"][0, T:].tolist())
+    if fmt != "raw":
+        n_gpu = int(L * gpu_pct / 100)
+        assert all(st.packed == 10 for st in model.layers[n_gpu:])      # the streamed layers really travel encoded
     model._lia_scheduler.close()
     model.close()
