@@ -217,7 +217,7 @@ def main():
                                         host_owner=(group is None or group.is_root or group.mode == "allgather"), pack12=pack12,
                                         shard=((rank, world) if (group is not None and world > 1 and group.mode == "allgather") else None),
                                         raw_layers=(OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, a.cpu_layers)
-                                                    if (a.cpu_layers and a.decoding_policy == 2 and group is None) else ()))
+                                                    if (a.cpu_layers and a.decoding_policy in (2, 3) and group is None) else ()))
         sched = OffloadScheduler(model, device=dev_index, dp_group=group, pack12=pack12)
     from lia_amd import hostinfo
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
@@ -234,7 +234,9 @@ def main():
 
     # untimed shake-out: allocations (pinned KV, workspace), page-in, clocks
     kv = (KVState(model, n_gpu, B, T + new) if is_llama else
-          KVState(model, n_gpu, B, T + new, all_on_device=(a.prefill_policy == 3 and a.decoding_policy == 3)))
+          KVState(model, n_gpu, B, T + new, all_on_device=(a.prefill_policy == 3 and a.decoding_policy == 3),
+                  host_layers=(OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, a.cpu_layers)
+                               if (a.cpu_layers and a.prefill_policy == 3 and a.decoding_policy == 3) else ())))
     sched.forward(ids, kv, max_new_tokens=new, **flags)
     if not is_llama:
         sched.ctx.set_host_threads(host_threads)

@@ -71,8 +71,9 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         kv = LlamaKVState(model, B, T + max_new_tokens)
     else:
         # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278; in HBM for every layer when both policies are 3
-        kv = KVState(model, n_gpu, B, T + max_new_tokens,
-                     all_on_device=(lia["prefill_policy"] == 3 and lia["decoding_policy"] == 3))
+        on_dev = lia["prefill_policy"] == 3 and lia["decoding_policy"] == 3
+        host_layers = OffloadScheduler.cpu_layer_set(n_gpu, L, lia["cpu_layers"]) if (on_dev and lia.get("cpu_layers")) else ()
+        kv = KVState(model, n_gpu, B, T + max_new_tokens, all_on_device=on_dev, host_layers=host_layers)
     unfinished = torch.ones(B, dtype=torch.int64)
     latency_list, logits_list = [], []
     cur = ids

@@ -225,19 +225,22 @@ class KVState:
     """Per-layer KV caches of one generation: seq-major [Smax,B,h,d] (attentions.py:462-476), in HBM for
     resident layers and in pinned host memory for streamed ones (lia/modeling_opt.py:1270-1281)."""
 
-    def __init__(self, model, n_gpu, B, smax, all_on_device=False):
+    def __init__(self, model, n_gpu, B, smax, all_on_device=False, host_layers=()):
+        """host_layers (with all_on_device): layers whose cache stays in pinned host memory all the same -- the layers the
+        cooperative split computes on the host cores (scheduler.forward cpu_layers)."""
         sh = model.shape
         self.B, self.smax, self.len = B, smax, 0
         self.all_on_device = all_on_device
+        host_layers = frozenset(host_layers) if all_on_device else frozenset()
         if all_on_device:
             n_gpu = sh.layers          # policy 3 for streamed layers too: every cache lives in HBM
         from . import hostinfo
-        hostinfo.check_host_allocation(2 * (sh.layers - n_gpu) * smax * B * sh.hidden * 2, "host KV cache")
+        hostinfo.check_host_allocation(2 * (sh.layers - n_gpu + len(host_layers)) * smax * B * sh.hidden * 2, "host KV cache")
         self.tensors, self.kv, self._pinned = [], [], []
         shape = (smax, B, sh.heads, sh.head_dim)
         nbytes = 2 * smax * B * sh.heads * sh.head_dim
         for i in range(sh.layers):
-            if i < n_gpu:
+            if i < n_gpu and i not in host_layers:
                 k = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
                 v = torch.empty_like(k)
                 on_dev = 1
@@ -336,7 +339,10 @@ class OffloadScheduler:
 
         # move_gpu_layer / pin_memory, idempotent.  The policy-1 host path reads the host copy directly, so the pack12
         # wire format is only used when neither phase runs on the CPU.
-        cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and decoding_policy == 2 and self.dp is None) else frozenset()
+        cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and decoding_policy in (2, 3) and self.dp is None) else frozenset()
+        if cpu_set and decoding_policy == 3 and any(kv_state.kv[i].on_device for i in cpu_set):
+            raise ValueError("cpu_layers with the KV cache in HBM: the host-computed layers need a host cache "
+                             "(KVState(..., all_on_device=True, host_layers=OffloadScheduler.cpu_layer_set(...)))")
         shard = (self.dp.rank, self.dp.world) if (self.dp is not None and self.dp.world > 1 and self.dp.mode == "allgather") else None
         m.place(n_gpu, pin_weight, enable_cxl, self.pack12 and prefill_policy != 1 and decoding_policy != 1, raw_layers=cpu_set,
                 shard=shard)
@@ -396,9 +402,12 @@ class OffloadScheduler:
             if policy in (0, 3):
                 # FlexGen-style minibatches (:1283-1365).  Policy 3 here = streamed weights with the cache kept in HBM
                 # (build-defined; the reference reserves 3 for resident layers, :1175-1176)
+                # a host-computed layer keeps its cache on the host: its prefill delivers K/V there (policy 0) even when the
+                # other streamed layers keep theirs in HBM (policy 3)
+                pol = 0 if (policy == 3 and idx in cpu_set) else policy
                 for i in range(B // mini):
                     sl = slice(i * mini, (i + 1) * mini)
-                    ctx.layer_forward(m.desc, policy, wptrs, x[sl], y[sl], kv_state.kv[idx], mini, T, pos0, i * mini)
+                    ctx.layer_forward(m.desc, pol, wptrs, x[sl], y[sl], kv_state.kv[idx], mini, T, pos0, i * mini)
             else:
                 ctx.layer_forward(m.desc, 2, wptrs, x, y, kv_state.kv[idx], B, T, pos0, 0)   # :1493-1543
             pipe.release(idx)
@@ -408,7 +417,7 @@ class OffloadScheduler:
 
         logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
         ctx.synchronize()
-        if policy == 0:
+        if policy == 0 or (is_prefill and cpu_set):
             ctx.kv_store_wait()                                    # host cache complete before the next step reads it
         kv_state.len = pos0 + T
         return logits, nxt

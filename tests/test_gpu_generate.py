@@ -90,7 +90,8 @@ def test_generate_logits_match_oracle(oracle, name):
 
 @pytest.mark.parametrize("name", GEN_CASES)
 @pytest.mark.parametrize("fmt", ["raw", "pack10"])
-def test_generate_with_host_computed_decode_layers(name, fmt, monkeypatch):
+@pytest.mark.parametrize("pol", [(0, 2), (3, 3)], ids=["kv-on-host", "kv-in-hbm"])
+def test_generate_with_host_computed_decode_layers(name, fmt, pol, monkeypatch):
     """cpu_layers (build-defined): some streamed layers take their decode step on the host cores (policy 1 per layer)
     while the others stay on policy 2; prefill is policy 0 for all.  Same greedy ids as the HF golden run."""
     import torch
@@ -98,8 +99,9 @@ def test_generate_with_host_computed_decode_layers(name, fmt, monkeypatch):
     monkeypatch.setenv("LIA_STREAM_FORMAT", fmt)
     z, m, ids, c = _load(name)
     model = _model(m, c)
-    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], prefill_policy=0,
-                   decoding_policy=2, gpu_percentage=25, pin_weight=True, cpu_layers=2)
+    # (3, 3): the GPU-computed streamed layers keep their cache in HBM, the host-computed ones on the host
+    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], prefill_policy=pol[0],
+                   decoding_policy=pol[1], gpu_percentage=25, pin_weight=True, cpu_layers=2)
     assert (out.numpy() == z["ids_bf16"]).all(), (out[0, c["T"]:].tolist(), z["ids_bf16"][0, c["T"]:].tolist())
     sched = model._lia_scheduler
     n_gpu = int(c["L"] * 25 / 100)
