@@ -105,6 +105,13 @@ class LayerStore:
             return self._ptr
         raise RuntimeError("layer is on the device")
 
+    def raw_host_ptr(self):
+        """raw bf16 host copy for the host cores (policy 1 / a host-computed layer): the second, raw pinned copy when the
+        streamed copy is packed, else the host copy itself; None when there is none"""
+        if getattr(self, "_raw_ptr", None):
+            return self._raw_ptr
+        return None if (self.packed or self.shard or self.tier not in ("pinned", "cxl", "pageable")) else self.host_ptr()
+
     def device_ptr(self):
         assert self.tier == "device"
         return self._dev.data_ptr()
@@ -150,10 +157,12 @@ class LayerStore:
             return None            # the encoding is no smaller than the raw layer (very wide distribution): ship raw
         return enc, out.value
 
-    def to_pinned(self, pack12=False, shard=None):
+    def to_pinned(self, pack12=False, shard=None, keep_raw=False):
         """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227); with pack12 the pinned copy is
         the lossless 12-bit encoding (75 % of the bytes).  shard = (r, G): keep only the r-th of G equal slices of the wire
-        bytes (data-parallel "allgather" streaming: every rank pulls its slice over its own link)."""
+        bytes (data-parallel "allgather" streaming: every rank pulls its slice over its own link).  keep_raw (with a packed
+        format): also keep a raw pinned copy for the host cores (a host-computed layer streams packed in the prefill and is
+        read raw in decode); dropped silently when the container has no room for it -- the layer then stays raw only."""
         fmt = {False: 0, True: 12, None: 0}.get(pack12, pack12)          # accepts False / True (= 12) / 11 / 12
         if shard is not None and shard[1] > 1:
             return self._to_pinned_shard(fmt, shard)
@@ -166,8 +175,19 @@ class LayerStore:
             enc = self._encode_packed(fmt)
         elif fmt == 12 and self.nbytes % 32 == 0:
             enc = self._encode_packed(12)
-        nbytes = enc[1] if enc else self.nbytes
         from . import hostinfo
+        raw_ptr = None
+        if enc and keep_raw:
+            try:
+                hostinfo.guard_host_allocation(self.nbytes + enc[1], "raw + packed pinned copies of a host-computed layer", ceiling=0.85)
+                raw_ptr = self._lib.lia_host_alloc_pinned(self.nbytes)
+            except MemoryError:
+                raw_ptr = None
+            if raw_ptr:
+                self._fill_host(raw_ptr)
+            else:
+                enc = None               # no room for two copies: keep the raw one only (it also streams, just more bytes)
+        nbytes = enc[1] if enc else self.nbytes
         hostinfo.guard_host_allocation(nbytes, "pinning a streamed layer")
         ptr = self._lib.lia_host_alloc_pinned(nbytes)
         if not ptr:
@@ -177,7 +197,7 @@ class LayerStore:
         else:
             self._fill_host(ptr)
         self._free()
-        self._ptr, self.tier = ptr, "pinned"
+        self._ptr, self.tier, self._raw_ptr = ptr, "pinned", raw_ptr
         self.packed, self.stream_bytes = (fmt if enc else 0), nbytes
 
     @staticmethod
@@ -248,6 +268,9 @@ class LayerStore:
         return self.tier in ("pinned", "cxl")
 
     def _free(self):
+        if getattr(self, "_raw_ptr", None):
+            self._lib.lia_host_free_pinned(self._raw_ptr)
+        self._raw_ptr = None
         if self.tier == "pinned" and self._ptr:
             self._lib.lia_host_free_pinned(self._ptr)
         elif self.tier == "cxl" and self._ptr:
@@ -343,11 +366,11 @@ class LiaOPTModel:
                     flat[o:o + k] = draw(k)
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu_layers:
-                fmt = 0 if li in raw_layers else pack12
                 if enable_cxl:
+                    fmt = 0 if li in raw_layers else pack12
                     st.to_cxl(fmt if fmt not in (False, None) else 0)
                 elif pin_weight:
-                    st.to_pinned(fmt, shard=shard)
+                    st.to_pinned(pack12, shard=shard, keep_raw=(li in raw_layers))
                 else:
                     st.to_pinned()  # leave the device; demoted to pageable below
                     host = np.array(st._host_view(), copy=True)
@@ -379,7 +402,7 @@ class LiaOPTModel:
                 st.to_cxl(0 if i in raw_layers else {False: 0, True: 12, None: 0}.get(pack12, pack12))
             elif pin_weight:
                 if st.tier != "pinned":
-                    st.to_pinned(0 if i in raw_layers else pack12, shard=shard)
+                    st.to_pinned(pack12, shard=shard, keep_raw=(i in raw_layers))
         torch.cuda.synchronize()
         self.placed_for = key
 

@@ -437,8 +437,9 @@ class OffloadScheduler:
         kernel blit, lia_host_layer_forward on the raw host copy of the weights and the host KV cache, result back."""
         m, sh, ctx, lib = self.model, self.model.shape, self.ctx, self.ctx.lib
         st = m.layers[idx]
-        if st.packed or not st.is_dma_able():
-            raise ValueError(f"layer {idx} is to run on the host but its host copy is not raw pinned bf16")
+        raw = st.raw_host_ptr()
+        if raw is None:
+            raise ValueError(f"layer {idx} is to run on the host but has no raw bf16 host copy")
         nbytes = B * T * sh.hidden * 2
         if getattr(self, "_host_hidden", None) is None or self._host_hidden[2] < nbytes:
             self._host_hidden = (PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes), nbytes)
@@ -447,7 +448,7 @@ class OffloadScheduler:
         ctx.synchronize()
         from . import hostinfo
         threads = getattr(self, "host_threads", None) or hostinfo.default_host_threads(1)
-        w = ops.weight_ptr_array(st.host_ptr(), m.offsets)
+        w = ops.weight_ptr_array(raw, m.offsets)
         kv = kv_state.kv[idx]
         N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx), ctypes.c_void_p(hy),
                                            ctypes.c_void_p(kv.k), ctypes.c_void_p(kv.v), kv.smax, kv.batch, B, T, pos0, 0, threads),
