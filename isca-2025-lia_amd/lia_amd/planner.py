@@ -22,8 +22,9 @@ class Box:
     attn_gbs: float = 6000.0          # decode attention on HBM-resident KV
     mfma_tflops: float = 1150.0       # prefill GEMM on random data
     host_gbs_per_thread: float = 13.0
-    host_linear_gbs_per_thread: float = 3.6   # policy-1 linears at M = 64 beside the running weight stream (4.9 alone)
-    host_attn_beside_stream: float = 0.55     # host attention keeps this share of its rate while the copy engine reads DRAM
+    # host-computed layers, threads pinned to the NUMA node that holds the weights (bench.py / run_generation.py do that):
+    host_linear_gbs_per_thread: float = 4.4   # policy-1 linears at M = 64 beside the running weight stream (4.9 alone; 3.6 unpinned)
+    host_attn_beside_stream: float = 0.8      # share of its rate the host attention keeps beside the stream (0.55 unpinned)
     wire_ratio: float = 0.675         # bytes shipped per weight byte: pack10 0.675, pack11 0.696, pack12 0.751, raw 1.0
     host_threads: int = 0
     host_mem_gb: float = 0.0
@@ -89,12 +90,13 @@ def estimate(shape, B, T, new, gpu_percentage, decoding_policy, box=None, kv_in_
     return prefill_ms, decode_ms, hbm, host, n_gpu
 
 
-def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None):
+def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None, kv_in_hbm=False):
     """How many streamed layers should take their decode step on the host cores (scheduler.forward cpu_layers) beside
     decoding policy 2: a host layer costs its linears at the host's weight-read rate + the host attention, but frees one
     layer's worth of link time.  The step is max(link time of the remaining layers, sum of every layer's latency);
-    returns (count, predicted ms per step).  Calibrated on the r01 scan: OPT-30B, B = 64, 16 host
-    threads -> 11 layers, 488 ms predicted and measured."""
+    returns (count, predicted ms per step).  kv_in_hbm: the GPU-computed streamed layers keep their cache in HBM (policy 3 /
+    3), so only the host-computed layers use the host cores.  Calibrated on the r01 scans, OPT-30B,
+    B = 64, 16 pinned host threads: 16 layers / 412 ms measured with the cache on the host, 19 layers / 367 ms with it in HBM."""
     box = box or Box()
     L, H = shape.layers, shape.hidden
     n_gpu = int(L * gpu_percentage / 100)
@@ -105,7 +107,7 @@ def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None):
     kv_read = 2 * (T + new // 2) * B * H * 2
     attn_gpu_ms = 1e3 * kv_read / (box.attn_gbs * 1e9)
     attn_host_ms = 1e3 * kv_read / (box.host_threads * box.host_gbs_per_thread * box.host_attn_beside_stream * 1e9)
-    t_g = gemm_ms + attn_host_ms + 0.3
+    t_g = gemm_ms + (attn_gpu_ms if kv_in_hbm else attn_host_ms) + 0.3
     t_c = 1e3 * lb / (box.host_threads * box.host_linear_gbs_per_thread * 1e9) + attn_host_ms + 0.3
     lm_ms = 1e3 * shape.vocab * H * 2 / (box.hbm_gbs * 1e9)
     best = (0, None)
