@@ -149,7 +149,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--cpu-layers", type=int, default=0,
                     help="build-defined: with decoding policy 2, this many streamed layers run their decode step on the host cores "
-                         "(policy 1 per layer, weights never cross the link); 0 = the reference's uniform policy")
+                         "(policy 1 per layer, weights never cross the link); 0 = the reference's uniform policy; -1 = let "
+                         "lia_amd.planner.plan_cpu_layers choose from the box's host rates")
     a = ap.parse_args()
 
     import torch
@@ -195,6 +196,12 @@ def main():
     if T + new > shape.max_pos:
         raise SystemExit("prompt + steps exceeds max positions")
     n_gpu = shape.layers if (is_llama and a.gpu_percentage >= 100) else int(shape.layers * a.gpu_percentage / 100)
+    if a.cpu_layers < 0 and not is_llama:
+        from lia_amd import planner, hostinfo as _hi2
+        a.cpu_layers, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
+                                                  planner.Box(host_threads=a.host_threads or _hi2.default_host_threads(world),
+                                                              wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
+                                                  kv_in_hbm=(a.prefill_policy == 3 and a.decoding_policy == 3))
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
                  gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=a.enable_cxl, no_overlap=False)
     if a.cpu_layers:
