@@ -5,7 +5,7 @@ the tree; this is a small roofline model of THIS implementation, calibrated on t
 
   per streamed layer    copy      = layer_bytes / link_gbs                       (57 GB/s pinned H2D on the box)
   decode, resident      gpu       = layer_bytes / hbm_gbs + kv_bytes / hbm_gbs   (skinny GEMM ~4.8 TB/s, attention ~6 TB/s)
-  decode, policy 2      host attn = kv_bytes / (threads * host_gbs_per_thread)   (13 GB/s per core measured)
+  decode, policy 2      host attn = kv_bytes / min(threads * 23 GB/s, 220 GB/s)  (row-run prefetch; 13 GB/s per core before)
   prefill               gemm      = flops / mfma_tflops                          (1.15 PFLOP/s measured)
   a streamed layer costs max(copy, its compute); a forward is the sum over layers (+ a fill bubble in prefill).
 """
@@ -20,8 +20,9 @@ class Box:
     hbm_gb: float = 288.0
     hbm_gbs: float = 4800.0           # what the decode GEMM sustains at M = 64
     attn_gbs: float = 6000.0          # decode attention on HBM-resident KV
-    mfma_tflops: float = 1150.0       # prefill GEMM on random data
-    host_gbs_per_thread: float = 13.0
+    mfma_tflops: float = 1200.0       # prefill GEMM on random data, in the pipeline (GM = 4 tile order)
+    host_gbs_per_thread: float = 23.0  # host attention with the row-run prefetch: 46 GB/s at 2 threads ...
+    host_gbs_cap: float = 220.0        # ... and 223 GB/s at 16 (the socket's DRAM)
     # host-computed layers, threads pinned to the NUMA node that holds the weights (bench.py / run_generation.py do that):
     host_linear_gbs_per_thread: float = 4.4   # policy-1 linears at M = 64 beside the running weight stream (4.9 alone; 3.6 unpinned)
     host_attn_beside_stream: float = 0.8      # share of its rate the host attention keeps beside the stream (0.55 unpinned)
@@ -66,11 +67,11 @@ def estimate(shape, B, T, new, gpu_percentage, decoding_policy, box=None, kv_in_
     S = T + new
     kv_layer = 2 * S * B * H * 2                       # K and V of one layer, bytes
     kv_in_hbm = (decoding_policy == 3) if kv_in_hbm is None else kv_in_hbm
-    copy_ms = 1e3 * lb / (box.link_gbs * 1e9)
+    copy_ms = 1e3 * lb * box.wire_ratio / (box.link_gbs * 1e9)   # bytes shipped per layer in the box's wire format
     # decode
     gemm_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
     attn_gpu_ms = 1e3 * (2 * (T + new // 2) * B * H * 2) / (box.attn_gbs * 1e9)
-    attn_host_ms = 1e3 * (2 * (T + new // 2) * B * H * 2) / (box.host_threads * box.host_gbs_per_thread * 1e9)
+    attn_host_ms = 1e3 * (2 * (T + new // 2) * B * H * 2) / (min(box.host_threads * box.host_gbs_per_thread, box.host_gbs_cap) * 1e9)
     resident_ms = gemm_ms + attn_gpu_ms
     if decoding_policy == 2:
         streamed_ms = max(copy_ms, gemm_ms + attn_host_ms + 0.3)
@@ -106,7 +107,7 @@ def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None, kv_in_hbm=False)
     gemm_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
     kv_read = 2 * (T + new // 2) * B * H * 2
     attn_gpu_ms = 1e3 * kv_read / (box.attn_gbs * 1e9)
-    attn_host_ms = 1e3 * kv_read / (box.host_threads * box.host_gbs_per_thread * box.host_attn_beside_stream * 1e9)
+    attn_host_ms = 1e3 * kv_read / (min(box.host_threads * box.host_gbs_per_thread, box.host_gbs_cap) * box.host_attn_beside_stream * 1e9)
     t_g = gemm_ms + (attn_gpu_ms if kv_in_hbm else attn_host_ms) + 0.3
     t_c = 1e3 * lb / (box.host_threads * box.host_linear_gbs_per_thread * 1e9) + attn_host_ms + 0.3
     lm_ms = 1e3 * shape.vocab * H * 2 / (box.hbm_gbs * 1e9)

@@ -8,11 +8,15 @@ BOX = planner.Box(host_threads=16, host_mem_gb=280.0)
 
 def test_headline_prediction_close_to_measurement():
     sh = resolve_shape("opt-30b")
-    pre, dec, hbm, host, n_gpu = planner.estimate(sh, 64, 256, 32, 10, 2, BOX)
+    raw = planner.Box(host_threads=16, host_mem_gb=280.0, wire_ratio=1.0)
+    pre, dec, hbm, host, n_gpu = planner.estimate(sh, 64, 256, 32, 10, 2, raw)
     assert n_gpu == 4
-    assert abs(dec - 955.0) / 955.0 < 0.05          # measured 955 ms/step
-    assert abs(pre - 1050.0) / 1050.0 < 0.10        # measured 1050 ms
+    assert abs(dec - 955.0) / 955.0 < 0.05          # raw bf16 on the wire: measured 955 ms/step
+    assert abs(pre - 1050.0) / 1050.0 < 0.10        # measured 1013-1050 ms
     assert 50 < host < 90 and hbm < 30
+    pre10, dec10, *_ = planner.estimate(sh, 64, 256, 32, 10, 2, BOX)           # pack10 (the default wire ratio)
+    assert abs(dec10 - 649.0) / 649.0 < 0.05        # measured 649 ms/step
+    assert abs(pre10 - 840.0) / 840.0 < 0.12        # measured 831-861 ms: compute-bound once the wire is packed
     pre_r, dec_r, *_ = planner.estimate(sh, 64, 256, 32, 100, 3, BOX)
     assert abs(dec_r - 18.7) / 18.7 < 0.35          # measured 18.7 ms/step fully resident
     assert abs(pre_r - 858.0) / 858.0 < 0.15
