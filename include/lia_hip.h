@@ -207,6 +207,10 @@ int lia_pack11_encode(const lia_bf16* src_device, size_t n_values, char* dst_dev
  * for N(0,sigma) weights, against an exponent-entropy bound of 10.55.  n_values must be a multiple of 1024. */
 size_t lia_pack10_bound(size_t n_values);
 int lia_pack10_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
+/* Rebuild the raw bf16 values of an encoded buffer (device -> device), asynchronous on `stream` (NULL = the default
+ * stream): the kernels the streamer runs, exposed for re-tiering a layer that the host holds in a packed format
+ * (model placement, lia/modeling_opt.py:229-268) and for the round-trip tests.  format: 10, 11 or 12. */
+int lia_pack_decode(const char* src_device, lia_bf16* dst_device, size_t n_values, int format, void* stream);
 /* format: 10, 11 or 12 */
 int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int format,
                                int pinned);

@@ -760,7 +760,7 @@ struct lia_streamer {
   std::vector<char> decoded_on_side;
   hipStream_t copy;
   std::vector<hipEvent_t> copied, released, t0, t1;
-  std::vector<char> has_release, timing_pending;
+  std::vector<char> has_release, timing_pending, was_marked;
   std::vector<size_t> pending_bytes;
   char* bounce;
   double bytes, busy_ms;
@@ -788,6 +788,7 @@ extern "C" int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, l
   HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
   s->copied.resize(n_slots); s->released.resize(n_slots); s->t0.resize(n_slots); s->t1.resize(n_slots);
   s->has_release.assign(n_slots, 0); s->timing_pending.assign(n_slots, 0); s->pending_bytes.assign(n_slots, 0);
+  s->was_marked.assign(n_slots, 0);
   for (int i = 0; i < n_slots; ++i) {
     HIP_TRY(hipEventCreateWithFlags(&s->copied[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->released[i], hipEventDisableTiming));
@@ -831,6 +832,9 @@ extern "C" int lia_stream_begin(lia_streamer* s, int slot) {
   if (!s || slot < 0 || slot >= s->n_slots) { lia_set_error("lia_stream_begin: slot=%d", slot); return LIA_ERR_INVALID; }
   streamer_collect(s, slot);
   if (s->has_release[slot]) HIP_TRY(hipStreamWaitEvent(s->copy, s->released[slot], 0));
+  // A prefetch the caller dropped (never waited for, never released) may still have its decode kernel running on the side
+  // stream, reading this slot's staging area and writing the slot: the new copy must land behind it as well.
+  if (s->was_marked[slot]) HIP_TRY(hipStreamWaitEvent(s->copy, s->copied[slot], 0));
   HIP_TRY(hipEventRecord(s->t0[slot], s->copy));
   s->pending_bytes[slot] = 0;
   return LIA_OK;
@@ -908,6 +912,17 @@ extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_valu
   return LIA_OK;
 }
 
+extern "C" int lia_pack_decode(const char* src_device, lia_bf16* dst_device, size_t n_values, int format, void* stream) {
+  if (!src_device || !dst_device) { lia_set_error("lia_pack_decode: NULL buffer"); return LIA_ERR_MISSING; }
+  if ((format != 10 && format != 11 && format != 12) || (n_values % 16) || (format != 12 && (n_values % 1024))) {
+    lia_set_error("lia_pack_decode: n_values=%zu format=%d", n_values, format);
+    return LIA_ERR_INVALID;
+  }
+  lia_packed_decode_launch(src_device, dst_device, n_values, format, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
 extern "C" int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int format,
                                           int pinned) {
   int rc = lia_stream_begin(s, slot);
@@ -925,11 +940,13 @@ extern "C" int lia_stream_mark_ready(lia_streamer* s, int slot) {
     HIP_TRY(hipEventRecord(s->copied[slot], s->decode));              // ready = decoded
     s->decoded_on_side[slot] = 0;
     s->timing_pending[slot] = 1;
+    s->was_marked[slot] = 1;
     return LIA_OK;
   }
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));
   HIP_TRY(hipEventRecord(s->copied[slot], s->copy));
   s->timing_pending[slot] = 1;
+  s->was_marked[slot] = 1;
   return LIA_OK;
 }
 

@@ -56,6 +56,10 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
                   heads, head_dim, cache_batch, b0);
     return LIA_ERR_INVALID;
   }
+  if (head_dim > 128) {   // the per-head accumulators are a fixed 8 x 8 zmm block (OPT / Llama heads are 64 or 128 wide)
+    lia_set_error("lia_host_attention: head_dim %d > 128 is not supported", head_dim);
+    return LIA_ERR_INVALID;
+  }
   const int d = head_dim;
   const long hd = (long)heads * d;
   const long row = (long)cache_batch * hd;
@@ -429,6 +433,21 @@ static void host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bi
   (void)mblocks;
 }
 
+// The linears are compiled for AVX-512-BF16 (vdpbf16ps); on a host without it the first such instruction would be a
+// SIGILL, so the exported entry points check CPUID once and fail with a message instead.
+static int host_isa_ok(const char* who) {
+#if LIA_HAVE_DPBF16
+  static const int ok = __builtin_cpu_supports("avx512bf16") ? 1 : 0;
+  if (!ok) {
+    lia_set_error("%s: this library was built for AVX-512-BF16 hosts (vdpbf16ps); the CPU does not support it", who);
+    return LIA_ERR_INVALID;
+  }
+#else
+  (void)who;
+#endif
+  return LIA_OK;
+}
+
 extern "C" int lia_host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H,
                                   float eps, int n_threads) {
   if (!x || !g || !b || !y) return LIA_ERR_MISSING;
@@ -442,6 +461,7 @@ extern "C" int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_b
                                lia_bf16* y, long M, int N, int K, int relu, int n_threads) {
   if (!x || !w || !y) return LIA_ERR_MISSING;
   if (M < 0 || N <= 0 || K <= 0 || K % 32) { lia_set_error("lia_host_linear: K=%d must be a multiple of 32", K); return LIA_ERR_INVALID; }
+  if (int rc = host_isa_ok("lia_host_linear")) return rc;
   if (n_threads > 0) omp_set_num_threads(n_threads);
   host_linear(x, w, bias, residual, y, M, N, K, relu);
   return LIA_OK;
@@ -457,11 +477,12 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   for (int i = 0; i < 16; ++i)
     if (!weights[i]) { lia_set_error("lia_host_layer_forward: weights[%d] is NULL", i); return LIA_ERR_MISSING; }
   const int H = d->hidden, F = d->ffn, heads = d->heads;
-  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || H % 32 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
+  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || (H / heads) > 128 || H % 32 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
       pos0 + T > smax || b0 < 0 || b0 + B > cache_batch) {
     lia_set_error("lia_host_layer_forward: bad shape H=%d heads=%d F=%d B=%d T=%d pos0=%d smax=%d", H, heads, F, B, T, pos0, smax);
     return LIA_ERR_INVALID;
   }
+  if (int rc = host_isa_ok("lia_host_layer_forward")) return rc;
   if (n_threads > 0) omp_set_num_threads(n_threads);
   const lia_bf16* const* W = (const lia_bf16* const*)weights;
   const long M = (long)B * T;
@@ -481,4 +502,11 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   return LIA_OK;
 }
 
-extern "C" int lia_host_has_avx512_bf16(void) { return LIA_HAVE_DPBF16; }
+// 1 when the vdpbf16ps inner loops are compiled in AND this CPU executes them
+extern "C" int lia_host_has_avx512_bf16(void) {
+#if LIA_HAVE_DPBF16
+  return __builtin_cpu_supports("avx512bf16") ? 1 : 0;
+#else
+  return 0;
+#endif
+}

@@ -93,6 +93,7 @@ SIGNATURES = {
     "lia_pack10_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
     "lia_pack11_bound": (c_size_t, [c_size_t]),
     "lia_pack11_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
+    "lia_pack_decode": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "lia_stream_prefetch_packed": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_size_t, c_int, c_int]),
     "lia_stream_copy_chunk_packed": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, c_int]),
     "lia_stream_decode_packed": (c_int, [c_void_p, c_int, c_size_t, c_int]),

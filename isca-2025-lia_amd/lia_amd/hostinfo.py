@@ -59,6 +59,25 @@ def node_cpus(node):
     return cpus
 
 
+def numa_nodes():
+    """ids of the NUMA nodes that hold memory (sysfs), sorted; [] when unknown"""
+    import glob
+    import re
+    out = []
+    for p in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        m = re.search(r"node(\d+)$", p)
+        if not m:
+            continue
+        try:
+            txt = open(os.path.join(p, "meminfo")).read()
+            mt = re.search(r"MemTotal:\s+(\d+)", txt)
+            if mt and int(mt.group(1)) > 0:
+                out.append(int(m.group(1)))
+        except OSError:
+            pass
+    return sorted(out)
+
+
 def gpu_numa_node(dev_index=0):
     """NUMA node of a GPU from sysfs (PCI ids via torch's device properties), or -1 when unknown: pinned host memory is
     allocated next to the GPU, so the host-compute threads belong on that node's cores."""

@@ -118,22 +118,26 @@ class LiaLlamaModel:
             if li >= n_gpu:
                 st.to_pinned(pack)
         torch.cuda.synchronize()
-        self.placed_for = (n_gpu, True, False)
+        self.placed_for = (n_gpu, True, False, LayerStore._fmt_of(pack))
         return self
 
     def place(self, n_gpu_layers, pin_weight, enable_cxl, pack=0):
-        key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
+        """as LiaOPTModel.place: idempotent per flag set, re-places the layers when the flags change"""
+        key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl), LayerStore._fmt_of(pack))
         if self.placed_for == key:
             return
         for i, st in enumerate(self.layers):
             if i < n_gpu_layers:
                 st.to_device()
-            elif st.tier == "device":
-                raise ValueError("gpu_percentage shrank between calls: resident layers cannot be demoted")
-            elif enable_cxl and pin_weight:
+        for i, st in enumerate(self.layers):
+            if i < n_gpu_layers:
+                continue
+            if enable_cxl and pin_weight:
                 st.to_cxl(pack)
             elif pin_weight:
                 st.to_pinned(pack)
+            elif st.tier == "device" or st.packed:
+                st.to_pageable()
         torch.cuda.synchronize()
         self.placed_for = key
 
@@ -200,6 +204,10 @@ class LlamaScheduler:
         if B % num_minibatch:
             raise ValueError(f"batch {B} not divisible by num_minibatch {num_minibatch}")
         mini = B // num_minibatch if T > 1 else B
+        if m.placed_for != (n_gpu, bool(pin_weight), bool(enable_cxl), LayerStore._fmt_of(self.pack)):
+            if self.pipe is not None:
+                self.pipe.drain()          # copies in flight read the host buffers a re-placement frees
+            self.resident.clear()
         m.place(n_gpu, pin_weight, enable_cxl, self.pack)
         x, y = self._ensure(mini * T, B, T, n_gpu, kv_state.smax)
         ctx, pipe = self.ctx, self.pipe

@@ -70,6 +70,7 @@ class LayerStore:
         self.packed = 0           # 0: host copy is raw bf16; 10 / 11 / 12: it holds that lossless encoding (lia_pack12.hip)
         self.shard = None         # (rank, world, slice bytes) when the host copy is one slice of the wire bytes
         self.stream_bytes = total_bytes   # bytes that cross the host link per use
+        self.want_fmt = 0         # wire format asked for by the last to_pinned / to_cxl (a layer that does not fit stays raw)
         self._dev = None          # torch uint8 CUDA tensor
         self._np = None           # numpy uint8 (pageable)
         self._ptr = None          # raw host pointer (pinned / cxl)
@@ -91,12 +92,16 @@ class LayerStore:
         self._np, self.tier = flat, "pageable"
 
     # -- tier moves -------------------------------------------------------------------------------
+    # Every move goes through ONE intermediate, the raw bf16 layer in device memory (_raw_on_device): whatever tier and wire
+    # format the layer is in, it can be re-placed in any other, so one model object serves calls with different policies,
+    # gpu% and wire formats (the reference re-tiers with move_gpu_layer / pin_memory on every first forward of a process,
+    # lia/modeling_opt.py:1182-1184,1214-1217; its scripts start one process per flag set).
     def _host_view(self):
         if self.tier == "pageable":
             return self._np
-        if self.tier in ("pinned", "cxl"):
+        if self.tier in ("pinned", "cxl") and not self.packed and not self.shard:
             return np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self._ptr))
-        raise RuntimeError("layer is on the device")
+        raise RuntimeError(f"no raw host view of a layer in tier {self.tier!r} (packed={self.packed}, shard={self.shard})")
 
     def host_ptr(self):
         if self.tier == "pageable":
@@ -116,32 +121,59 @@ class LayerStore:
         assert self.tier == "device"
         return self._dev.data_ptr()
 
-    def _fill_host(self, ptr):
+    def _raw_on_device(self):
+        """The raw bf16 layer as a CUDA uint8 tensor, from whatever tier / wire format holds it now (a packed host copy is
+        shipped encoded and rebuilt by the same decode kernels the streamer uses)."""
         if self.tier == "device":
-            N.check(self._lib.lia_memcpy_d2h(ptr, self._dev.data_ptr(), self.nbytes), "lia_memcpy_d2h")
-        else:
-            dst = np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(ptr))
-            dst[:] = self._host_view()
+            return self._dev
+        if self.tier in (None, "remote"):
+            raise RuntimeError(f"layer holds no data (tier {self.tier!r})")
+        dev = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
+        raw = getattr(self, "_raw_ptr", None)
+        if raw or not (self.packed or self.shard):
+            N.check(self._lib.lia_memcpy_h2d(dev.data_ptr(), raw or self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
+            return dev
+        if self.shard:
+            raise ValueError("this rank holds one slice of the layer's wire bytes (allgather streaming); it cannot be re-tiered here")
+        enc = torch.empty(self.stream_bytes, dtype=torch.uint8, device="cuda")
+        N.check(self._lib.lia_memcpy_h2d(enc.data_ptr(), self._ptr, self.stream_bytes), "lia_memcpy_h2d")
+        N.check(self._lib.lia_pack_decode(ctypes.c_void_p(enc.data_ptr()), ctypes.c_void_p(dev.data_ptr()), self.nbytes // 2,
+                                          int(self.packed), None), "lia_pack_decode")
+        torch.cuda.synchronize()
+        return dev
+
+    def _fill_host(self, ptr, src):
+        N.check(self._lib.lia_memcpy_d2h(ptr, src.data_ptr(), self.nbytes), "lia_memcpy_d2h")
 
     def to_device(self):
         """move_gpu_layer (lia/modeling_opt.py:229-268), minus the un-blocking (weights are already row-major)."""
         if self.tier == "device":
             return
-        if self.packed:
-            raise ValueError("a pack12-encoded host layer cannot be promoted to the device tier (re-load the model)")
-        dev = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
-        N.check(self._lib.lia_memcpy_h2d(dev.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
+        dev = self._raw_on_device()
         self._free()
         self._dev, self.tier = dev, "device"
 
-    def _encode_packed(self, fmt):
-        """-> (device uint8 tensor with the encoded bytes, n bytes) or None when the layer does not fit the format."""
-        if self.tier != "device":
-            tmp = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
-            N.check(self._lib.lia_memcpy_h2d(tmp.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
-            src = tmp
+    def to_pageable(self):
+        """plain (unpinned) host memory: what the reference streams from without --pin-weight (lia/modeling_opt.py:1219-1220)"""
+        if self.tier == "pageable":
+            return
+        src = self._raw_on_device()
+        host = np.empty(self.nbytes, np.uint8)
+        N.check(self._lib.lia_memcpy_d2h(host.ctypes.data, src.data_ptr(), self.nbytes), "lia_memcpy_d2h")
+        self._free()
+        self._np, self.tier = host, "pageable"
+
+    def _encode_packed(self, fmt, src):
+        """src: the raw layer on the device -> (device uint8 tensor with the encoded bytes, n bytes), or None when the layer
+        does not fit the format."""
+        if fmt in (10, 11):
+            if self.nbytes % 2048:
+                return None
+        elif fmt == 12:
+            if self.nbytes % 32:
+                return None
         else:
-            src = self._dev
+            return None
         bound, encode = {10: (self._lib.lia_pack10_bound, self._lib.lia_pack10_encode),
                          11: (self._lib.lia_pack11_bound, self._lib.lia_pack11_encode),
                          12: (self._lib.lia_pack12_bound, self._lib.lia_pack12_encode)}[fmt]
@@ -157,24 +189,28 @@ class LayerStore:
             return None            # the encoding is no smaller than the raw layer (very wide distribution): ship raw
         return enc, out.value
 
+    @staticmethod
+    def _fmt_of(pack):
+        return {False: 0, True: 12, None: 0}.get(pack, pack)          # accepts False / True (= 12) / 0 / 10 / 11 / 12
+
     def to_pinned(self, pack12=False, shard=None, keep_raw=False):
-        """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227); with pack12 the pinned copy is
-        the lossless 12-bit encoding (75 % of the bytes).  shard = (r, G): keep only the r-th of G equal slices of the wire
+        """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227); with a packed format the pinned copy
+        is that lossless encoding (67-75 % of the bytes).  shard = (r, G): keep only the r-th of G equal slices of the wire
         bytes (data-parallel "allgather" streaming: every rank pulls its slice over its own link).  keep_raw (with a packed
         format): also keep a raw pinned copy for the host cores (a host-computed layer streams packed in the prefill and is
-        read raw in decode); dropped silently when the container has no room for it -- the layer then stays raw only."""
-        fmt = {False: 0, True: 12, None: 0}.get(pack12, pack12)          # accepts False / True (= 12) / 11 / 12
+        read raw in decode); dropped silently when the container has no room for it -- the layer then stays raw only.
+        A layer already pinned in ANOTHER format (or tier) is re-encoded: nothing is sticky."""
+        fmt = self._fmt_of(pack12)
         if shard is not None and shard[1] > 1:
+            if self.tier == "pinned" and self.shard and self.shard[:2] == tuple(shard) and self.want_fmt == fmt:
+                return
             return self._to_pinned_shard(fmt, shard)
-        if self.tier == "pinned":
-            if self.packed and not fmt:
-                raise ValueError("layer is pinned in a packed wire format but the raw bf16 copy was requested")
-            return            # already pinned (a raw copy also serves a packed request: it simply ships more bytes)
-        enc = None
-        if fmt in (10, 11) and self.nbytes % 2048 == 0:
-            enc = self._encode_packed(fmt)
-        elif fmt == 12 and self.nbytes % 32 == 0:
-            enc = self._encode_packed(12)
+        if (self.tier == "pinned" and not self.shard and self.want_fmt == fmt and
+                (not keep_raw or not self.packed or getattr(self, "_raw_ptr", None))):
+            return
+        src = self._raw_on_device()
+        self._free()                                   # the host copy goes first: never two generations of a layer in host memory
+        enc = self._encode_packed(fmt, src)
         from . import hostinfo
         raw_ptr = None
         if enc and keep_raw:
@@ -184,21 +220,23 @@ class LayerStore:
             except MemoryError:
                 raw_ptr = None
             if raw_ptr:
-                self._fill_host(raw_ptr)
+                self._fill_host(raw_ptr, src)
             else:
                 enc = None               # no room for two copies: keep the raw one only (it also streams, just more bytes)
         nbytes = enc[1] if enc else self.nbytes
         hostinfo.guard_host_allocation(nbytes, "pinning a streamed layer")
         ptr = self._lib.lia_host_alloc_pinned(nbytes)
         if not ptr:
+            if raw_ptr:
+                self._lib.lia_host_free_pinned(raw_ptr)
+            self._dev, self.tier = src, "device"       # nothing is lost: the layer stays where it could be rebuilt
             raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
         if enc:
             N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
         else:
-            self._fill_host(ptr)
-        self._free()
+            self._fill_host(ptr, src)
         self._ptr, self.tier, self._raw_ptr = ptr, "pinned", raw_ptr
-        self.packed, self.stream_bytes = (fmt if enc else 0), nbytes
+        self.packed, self.stream_bytes, self.want_fmt = (fmt if enc else 0), nbytes, fmt
 
     @staticmethod
     def shard_bytes(total, world):
@@ -207,19 +245,12 @@ class LayerStore:
 
     def _to_pinned_shard(self, fmt, shard):
         r, G = shard
-        enc = None
-        if fmt in (10, 11) and self.nbytes % 2048 == 0:
-            enc = self._encode_packed(fmt)
-        elif fmt == 12 and self.nbytes % 32 == 0:
-            enc = self._encode_packed(12)
+        src = self._raw_on_device()
+        self._free()
+        enc = self._encode_packed(fmt, src)
         if enc:
             src, total = enc
         else:
-            if self.tier != "device":
-                src = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
-                N.check(self._lib.lia_memcpy_h2d(src.data_ptr(), self.host_ptr(), self.nbytes), "lia_memcpy_h2d")
-            else:
-                src = self._dev
             total = self.nbytes
         sh = self.shard_bytes(total, G)
         lo, hi = min(r * sh, total), min((r + 1) * sh, total)
@@ -231,38 +262,37 @@ class LayerStore:
         ctypes.memset(ptr, 0, sh)
         if hi > lo:
             N.check(self._lib.lia_memcpy_d2h(ptr, src.data_ptr() + lo, hi - lo), "lia_memcpy_d2h")
-        self._free()
         self._ptr, self.tier = ptr, "pinned"
-        self.packed, self.stream_bytes, self.shard = (fmt if enc else 0), total, (r, G, sh)
+        self.packed, self.stream_bytes, self.shard, self.want_fmt = (fmt if enc else 0), total, (r, G, sh), fmt
 
     def to_cxl(self, pack=0):
         """realloc_to_numa (lia/modeling_opt.py:168-175) + hipHostRegister so the copy engine can DMA from it
         (the reference leaves the CXL copy pageable, lia/cxl/numa_alloc.py:49).  pack = 10 / 11 / 12: the tier holds
         that lossless wire format instead of raw bf16 (fewer bytes in the tier AND on the link)."""
-        if self.tier == "cxl":
+        fmt = self._fmt_of(pack)
+        if self.tier == "cxl" and self.want_fmt == fmt:
             return
-        enc = None
-        if pack in (10, 11) and self.nbytes % 2048 == 0:
-            enc = self._encode_packed(pack)
-        elif pack == 12 and self.nbytes % 32 == 0:
-            enc = self._encode_packed(12)
+        src = self._raw_on_device()
+        self._free()
+        enc = self._encode_packed(fmt, src)
         nbytes = enc[1] if enc else self.nbytes
         from . import hostinfo
         hostinfo.guard_host_allocation(nbytes, "CXL-tier copy of a streamed layer")
         ptr = self._lib.numa_alloc_interleave(nbytes)
         if not ptr:
+            self._dev, self.tier = src, "device"
             raise MemoryError("Fail to allocate CXL memory!")  # same text as lia/modeling_opt.py:175
         rc = self._lib.lia_numa_register(ptr, nbytes)           # register first: the fill below then runs at DMA speed
         if rc != 0:
             self._lib.numa_free_node(ptr, nbytes)
+            self._dev, self.tier = src, "device"
             N.check(rc, "lia_numa_register")
         if enc:
             N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
         else:
-            self._fill_host(ptr)
-        self._free()
+            self._fill_host(ptr, src)
         self._ptr, self.tier = ptr, "cxl"
-        self.packed, self.stream_bytes = (pack if enc else 0), nbytes
+        self.packed, self.stream_bytes, self.want_fmt = (fmt if enc else 0), nbytes, fmt
 
     def is_dma_able(self):
         return self.tier in ("pinned", "cxl")
@@ -278,7 +308,7 @@ class LayerStore:
             self._lib.numa_free_node(self._ptr, self.stream_bytes)      # the size it was allocated with
         self._ptr = self._dev = self._np = None
         self.tier = None
-        self.packed, self.stream_bytes, self.shard = 0, self.nbytes, None
+        self.packed, self.stream_bytes, self.shard, self.want_fmt = 0, self.nbytes, None, 0
 
     def close(self):
         self._free()
@@ -302,7 +332,7 @@ class LiaOPTModel:
         self.offsets, self.layer_bytes = ops.pack_offsets(self.desc)
         self.layers = [LayerStore(self.desc, self.offsets, self.layer_bytes) for _ in range(shape.layers)]
         self.embed_tokens = self.embed_positions = self.final_ln_w = self.final_ln_b = None
-        self.placed_for = None  # (n_gpu_layers, pin_weight, enable_cxl) of the last placement
+        self.placed_for = None  # _place_key(...) of the last placement
 
     # -- builders ---------------------------------------------------------------------------------
     @classmethod
@@ -366,43 +396,51 @@ class LiaOPTModel:
                     flat[o:o + k] = draw(k)
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu_layers:
-                if enable_cxl:
-                    fmt = 0 if li in raw_layers else pack12
-                    st.to_cxl(fmt if fmt not in (False, None) else 0)
+                fmt = LayerStore._fmt_of(pack12)
+                if enable_cxl and pin_weight:        # the reference consults enable_cxl only inside pin_memory (:1214-1217)
+                    st.to_cxl(0 if li in raw_layers else fmt)
                 elif pin_weight:
-                    st.to_pinned(pack12, shard=shard, keep_raw=(li in raw_layers))
+                    st.to_pinned(fmt, shard=shard, keep_raw=(li in raw_layers))
                 else:
-                    st.to_pinned()  # leave the device; demoted to pageable below
-                    host = np.array(st._host_view(), copy=True)
-                    st._free()
-                    st._np, st.tier = host, "pageable"
+                    st.to_pageable()
         torch.cuda.synchronize()
-        self.placed_for = (n_gpu_layers, pin_weight, enable_cxl)
+        self.placed_for = self._place_key(n_gpu_layers, pin_weight, enable_cxl, pack12, raw_layers, shard)
         return self
 
-    # -- placement (first forward) ------------------------------------------------------------------
+    # -- placement (first forward, and again whenever the flags change) -------------------------------
+    @staticmethod
+    def _place_key(n_gpu_layers, pin_weight, enable_cxl, pack12, raw_layers, shard):
+        return (int(n_gpu_layers), bool(pin_weight), bool(enable_cxl), LayerStore._fmt_of(pack12), frozenset(raw_layers or ()),
+                tuple(shard) if shard else None)
+
     def place(self, n_gpu_layers, pin_weight, enable_cxl, pack12=False, raw_layers=(), shard=None):
-        """Idempotent tier assignment done on the first forward, as move_gpu_layer / pin_memory are
-        (lia/modeling_opt.py:1182-1184, 1214-1217)."""
-        key = (n_gpu_layers, bool(pin_weight), bool(enable_cxl))
+        """Tier assignment, idempotent per flag set: move_gpu_layer / pin_memory of the reference (lia/modeling_opt.py:1182-1184,
+        1214-1217) run on the first forward of a process; here a later call with other flags (policy 1 needs raw host copies,
+        another gpu%, another wire format, the CXL tier) RE-PLACES the layers instead of failing -- every LayerStore can be
+        rebuilt on the device from whatever it holds."""
+        key = self._place_key(n_gpu_layers, pin_weight, enable_cxl, pack12, raw_layers, shard)
         if self.placed_for == key:
             return
+        fmt = LayerStore._fmt_of(pack12)
+        from . import hostinfo
         if pin_weight:
-            from . import hostinfo
-            moving = sum(st.nbytes for i, st in enumerate(self.layers) if i >= n_gpu_layers and st.tier == "pageable")
-            hostinfo.check_host_allocation(moving, "pinning the streamed layers")
+            moving = sum(st.nbytes for i, st in enumerate(self.layers) if i >= n_gpu_layers and st.tier in ("pageable", "device"))
+            leaving = sum(st.nbytes for i, st in enumerate(self.layers) if i < n_gpu_layers and st.tier == "pageable")
+            hostinfo.check_host_allocation(max(0, moving - leaving), "pinning the streamed layers")
+        # promotions first (they free host memory), then the host-side moves
         for i, st in enumerate(self.layers):
-            if st.tier == "remote":
-                continue
-            if i < n_gpu_layers:
+            if st.tier != "remote" and i < n_gpu_layers:
                 st.to_device()
-            elif st.tier == "device":
-                raise ValueError("gpu_percentage shrank between calls: resident layers cannot be demoted")
-            elif enable_cxl and pin_weight:
-                st.to_cxl(0 if i in raw_layers else {False: 0, True: 12, None: 0}.get(pack12, pack12))
+        for i, st in enumerate(self.layers):
+            if st.tier == "remote" or i < n_gpu_layers:
+                continue
+            if enable_cxl and pin_weight:
+                st.to_cxl(0 if i in raw_layers else fmt)
             elif pin_weight:
-                if st.tier != "pinned":
-                    st.to_pinned(pack12, shard=shard, keep_raw=(i in raw_layers))
+                st.to_pinned(fmt, shard=shard, keep_raw=(i in raw_layers))
+            elif st.tier == "device" or st.packed or st.shard:
+                st.to_pageable()              # no --pin-weight: plain host memory, staged through the bounce buffer
+            # (a raw pinned / CXL copy left by an earlier --pin-weight call also serves an unpinned request)
         torch.cuda.synchronize()
         self.placed_for = key
 

@@ -69,7 +69,7 @@ def load_model(args):
     from .scheduler import OffloadScheduler
     raw = OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, args.cpu_layers) if (args.cpu_layers and args.decoding_policy == 2) else ()
     return LiaOPTModel.random_init(shape, seed=args.seed, init=args.init, n_gpu_layers=n_gpu,
-                                   pin_weight=args.pin_weight or args.enable_cxl, enable_cxl=args.enable_cxl, pack12=fmt, raw_layers=raw)
+                                   pin_weight=args.pin_weight, enable_cxl=args.enable_cxl, pack12=fmt, raw_layers=raw)
 
 
 def summarize(total_time, num_iter, num_warmup, total_list, batch_size, out=print):

@@ -39,7 +39,7 @@ class WeightPipeline:
         h = ctypes.c_void_p()
         N.check(self.lib.lia_stream_create(ctx.handle, n_slots, model.layer_bytes, ctypes.byref(h)), "lia_stream_create")
         self.handle, self.n_slots = h, n_slots
-        self.next_slot = 0
+        self.free_slots = list(range(n_slots))
         self.inflight = []          # [(layer_idx, slot)] in issue order, not yet acquired
         self.held = {}              # layer_idx -> slot (acquired, not yet released)
         self.slot_ptrs = [self.lib.lia_stream_slot_ptr(h, s) for s in range(n_slots)]
@@ -64,7 +64,7 @@ class WeightPipeline:
                                            "identical weights and format on every rank)")
 
     def can_prefetch(self):
-        return len(self.inflight) + len(self.held) < self.n_slots
+        return bool(self.free_slots)
 
     def prefetch(self, layer_idx):
         if any(li == layer_idx for li, _ in self.inflight) or layer_idx in self.held:
@@ -72,8 +72,7 @@ class WeightPipeline:
         if not self.can_prefetch():
             return
         st = self.model.layers[layer_idx]
-        slot = self.next_slot
-        self.next_slot = (slot + 1) % self.n_slots
+        slot = self.free_slots.pop(0)
         if self.dp is None and st.packed:
             N.check(self.lib.lia_stream_prefetch_packed(self.handle, slot, ctypes.c_void_p(st.host_ptr()), st.stream_bytes, st.nbytes // 2,
                                                         int(st.packed), int(st.is_dma_able())), "lia_stream_prefetch_packed")
@@ -157,13 +156,20 @@ class WeightPipeline:
 
     def acquire(self, layer_idx):
         """Make the compute stream wait for the layer's copy; returns the 16 device pointers."""
-        if not self.inflight or self.inflight[0][0] != layer_idx:
-            # nothing (or something else) was prefetched: drop stale prefetches, load on demand
-            self.inflight = [(li, s) for li, s in self.inflight if li == layer_idx]
-            if not self.inflight:
-                self.prefetch(layer_idx)
-        li, slot = self.inflight.pop(0)
-        assert li == layer_idx
+        pos = next((j for j, (li, _) in enumerate(self.inflight) if li == layer_idx), None)
+        if pos is None:
+            # the layer was not prefetched (a prefill after a decode step with host-computed layers, a different gpu%):
+            # load it on demand.  Queued copies of OTHER layers are kept -- the copy stream runs them in order and they
+            # are acquired later in this forward; only when every slot is taken is the NEWEST of them given up
+            # (lia_stream_begin orders the slot's next copy behind the dropped one's decode kernel).
+            while not self.free_slots and self.inflight:
+                _, s_drop = self.inflight.pop()
+                self.free_slots.append(s_drop)
+            if not self.free_slots:
+                raise RuntimeError(f"no streamer slot free for layer {layer_idx}: {len(self.held)} layers are held")
+            self.prefetch(layer_idx)
+            pos = len(self.inflight) - 1
+        li, slot = self.inflight.pop(pos)
         N.check(self.lib.lia_stream_wait(self.handle, slot, ctypes.c_void_p(self.ctx.stream)), "lia_stream_wait")
         self.held[layer_idx] = slot
         return self.ptr_arrays[slot]
@@ -171,6 +177,14 @@ class WeightPipeline:
     def release(self, layer_idx):
         slot = self.held.pop(layer_idx)
         N.check(self.lib.lia_stream_release(self.handle, slot, ctypes.c_void_p(self.ctx.stream)), "lia_stream_release")
+        self.free_slots.append(slot)
+
+    def drain(self):
+        """Forget every queued copy and wait for the copy engine: called before the model re-tiers its layers."""
+        for _, slot in self.inflight:
+            self.free_slots.append(slot)
+        self.inflight = []
+        torch.cuda.synchronize()
 
     def stats(self, reset=False):
         b, ms = ctypes.c_double(), ctypes.c_double()
@@ -284,6 +298,7 @@ class OffloadScheduler:
         self.hidden = {}
         self.resident_ptrs = {}
         self.last_step_ms = {}
+        self.host_threads = None    # OpenMP team of the host attention / host layers; default = hostinfo.default_host_threads
 
     # -- resources -----------------------------------------------------------------------------------
     def _ensure(self, rows, B, T, n_gpu):
@@ -298,6 +313,12 @@ class OffloadScheduler:
             if self.ctx is not None:
                 self.ctx.close()
             self.ctx = ops.Context(self.device, need)
+            # the policy-2 host attention team: usable CPUs (affinity mask AND cgroup quota) split over the ranks, never
+            # omp_get_max_threads() -- a team larger than the quota stalls every layer's round trip (hostinfo.py)
+            from . import hostinfo
+            if not getattr(self, "host_threads", None):
+                self.host_threads = hostinfo.default_host_threads(self.dp.world if self.dp else 1)
+            self.ctx.set_host_threads(self.host_threads)
         if self.pipe is None and n_gpu < sh.layers:
             self.pipe = WeightPipeline(self.ctx, self.model, self.n_slots, self.dp)
         key = (B, T)
@@ -344,8 +365,15 @@ class OffloadScheduler:
             raise ValueError("cpu_layers with the KV cache in HBM: the host-computed layers need a host cache "
                              "(KVState(..., all_on_device=True, host_layers=OffloadScheduler.cpu_layer_set(...)))")
         shard = (self.dp.rank, self.dp.world) if (self.dp is not None and self.dp.world > 1 and self.dp.mode == "allgather") else None
-        m.place(n_gpu, pin_weight, enable_cxl, self.pack12 and prefill_policy != 1 and decoding_policy != 1, raw_layers=cpu_set,
-                shard=shard)
+        wire = self.pack12 if (prefill_policy != 1 and decoding_policy != 1) else 0
+        if m.placed_for != m._place_key(n_gpu, pin_weight, enable_cxl, wire, cpu_set, shard):
+            # the flags changed since the last placement: the model re-tiers its layers (policy 1 wants raw host copies,
+            # another gpu%, wire format or host tier).  Copies in flight read host buffers that are about to be freed and
+            # the cached device pointers of the resident layers go stale.
+            if self.pipe is not None:
+                self.pipe.drain()
+            self.resident_ptrs.clear()
+        m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=cpu_set, shard=shard)
         host_now = cpu_set if not is_prefill else frozenset()     # layers this forward computes on the host
         rows = B * T if n_gpu > 0 else mini * T                    # resident layers take the whole batch
         if policy == 0 and n_gpu < L:
@@ -472,7 +500,7 @@ class OffloadScheduler:
         hy = torch.empty_like(hx).pin_memory()
         N.check(lib.lia_memcpy_d2h(ctypes.c_void_p(hx.data_ptr()), ctypes.c_void_p(x.data_ptr()), hx.numel() * 2), "lia_memcpy_d2h")
         from . import hostinfo
-        threads = hostinfo.default_host_threads(self.dp.world if self.dp else 1)
+        threads = self.host_threads or hostinfo.default_host_threads(self.dp.world if self.dp else 1)
         for idx in range(n_gpu, sh.layers):
             st = m.layers[idx]
             if st.packed:

@@ -59,6 +59,8 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode):
         assert (out.numpy() == z["ids_bf16"][lo:hi]).all(), (rank, out[:, T:].tolist())
         full = g.gather_ids(out, B)
         assert (full.numpy() == z["ids_bf16"]).all()
+        if g.is_root or mode == "allgather":       # the host copies really are in the wire format that was asked for
+            assert all(st.packed == {"raw": 0, "pack10": 10}[fmt] for st in model.layers[n_gpu:]), [st.packed for st in model.layers]
         if mode == "allgather":       # every rank pinned exactly its slice of every streamed layer's wire bytes
             assert all(st.shard is not None and st.shard[:2] == (rank, world) for st in model.layers[n_gpu:])
         elif not g.is_root:

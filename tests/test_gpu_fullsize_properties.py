@@ -1,4 +1,5 @@
-"""-m gpu: BASELINE.json's full layer size (OPT-30B: H 7168, 56 heads, F 28672; B 64, T 256) through size-independent
+"""-m gpu: BASELINE.json's full layer sizes (configs[1] OPT-30B: H 7168, 56 heads, F 28672, B 64, T 256; configs[2]
+OPT-175B: H 12288, 96 heads, F 49152, B 32, T 256 -- llm/utils/opt-weight-gen.py:84-96) through size-independent
 properties -- the oracle would need minutes per case at this size, so correctness is pinned by invariants that must
 hold for ANY correct implementation of the path:
 
@@ -18,13 +19,14 @@ import pytest
 import synth
 
 pytestmark = pytest.mark.gpu
-H, HEADS, F = 7168, 56, 28672
+SHAPES = {"opt-30b": (7168, 56, 28672, 64), "opt-175b": (12288, 96, 49152, 32)}      # H, heads, F, batch of the config
 
 
-@pytest.fixture(scope="module")
-def big():
+@pytest.fixture(scope="module", params=sorted(SHAPES))
+def big(request):
     import torch
     from lia_amd import _native as N, ops
+    H, HEADS, F, BATCH = SHAPES[request.param]
     desc = ops.make_desc(H, HEADS, F)
     offs, total = ops.pack_offsets(desc)
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -34,14 +36,17 @@ def big():
         flat[offs[i] // 2: offs[i] // 2 + n] = (0.02 * torch.randn(n, generator=g, device="cuda")).to(torch.bfloat16)
     for i in (0, 10):
         flat[offs[i] // 2: offs[i] // 2 + H] = 1.0
-    ctx = ops.Context(0, ops.workspace_bytes(desc, 64 * 257))
+    ctx = ops.Context(0, ops.workspace_bytes(desc, BATCH * 257))
     wptrs = ops.weight_ptr_array(flat.data_ptr(), offs)
-    yield dict(torch=torch, N=N, ops=ops, desc=desc, ctx=ctx, w=wptrs, flat=flat, gen=g)
+    yield dict(torch=torch, N=N, ops=ops, desc=desc, ctx=ctx, w=wptrs, flat=flat, gen=g, H=H, HEADS=HEADS, F=F, BATCH=BATCH)
     ctx.close()
+    del flat
+    torch.cuda.empty_cache()
 
 
 def _kv(big, smax, B, device=True):
     torch, N = big["torch"], big["N"]
+    H, HEADS = big["H"], big["HEADS"]
     d = H // HEADS
     if device:
         k = torch.zeros((smax, B, HEADS, d), dtype=torch.bfloat16, device="cuda")
@@ -53,7 +58,7 @@ def _kv(big, smax, B, device=True):
 
 
 def _x(big, B, T, identical=False, seed=1):
-    torch = big["torch"]
+    torch, H = big["torch"], big["H"]
     g = torch.Generator(device="cuda").manual_seed(seed)
     x = torch.randn((1 if identical else B, T, H), generator=g, device="cuda").to(torch.bfloat16)
     x = x.repeat(B, 1, 1).contiguous() if identical else x.contiguous()
@@ -74,7 +79,8 @@ def _run(big, policy, x, kv, T, pos0, b0=0, rows=None):
 
 def test_identical_rows_policy_equivalence_and_minibatching(big):
     torch = big["torch"]
-    B, T = 64, 256
+    B, T = big["BATCH"], 256
+    mb = B // 2
     x = _x(big, B, T, identical=True)
     k3, v3, kv3 = _kv(big, T + 2, B, True)
     y3 = _run(big, 3, x, kv3, T, 0)
@@ -84,11 +90,11 @@ def test_identical_rows_policy_equivalence_and_minibatching(big):
     y0 = _run(big, 0, x, kvh, T, 0)
     assert torch.equal(y0, y3)                                                                     # property 2
     assert torch.equal(kh[:T].cuda(), k3[:T]) and torch.equal(vh[:T].cuda(), v3[:T])
-    # property 3: two minibatches of 32 rows into the same host cache
+    # property 3: two minibatches of B/2 rows into the same host cache
     kh2, vh2, kvh2 = _kv(big, T + 2, B, False)
     y2 = torch.empty_like(x)
     for i in range(2):
-        big["ctx"].layer_forward(big["desc"], 0, big["w"], x[i * 32:(i + 1) * 32], y2[i * 32:(i + 1) * 32], kvh2, 32, T, 0, i * 32)
+        big["ctx"].layer_forward(big["desc"], 0, big["w"], x[i * mb:(i + 1) * mb], y2[i * mb:(i + 1) * mb], kvh2, mb, T, 0, i * mb)
     big["ctx"].synchronize()
     big["ctx"].kv_store_wait()
     assert torch.equal(y2, y3) and torch.equal(kh2[:T], kh[:T]) and torch.equal(vh2[:T], vh[:T])
@@ -130,7 +136,7 @@ def test_batch_independence_and_kv_cache_equivalence(big):
 def test_gemm_regimes_agree(big):
     """property 5: rows computed by the skinny kernel (M = 256) == the same rows computed by the tiled kernels
     (M = 1280 -> 256^2 tiles, M = 300 -> 128^2 tiles), to one bf16 ulp of the result."""
-    torch, ctx = big["torch"], big["ctx"]
+    torch, ctx, H = big["torch"], big["ctx"], big["H"]
     g = torch.Generator(device="cuda").manual_seed(9)
     x = torch.randn((1280, H), generator=g, device="cuda").to(torch.bfloat16)
     w = (0.02 * torch.randn((2048, H), generator=g, device="cuda")).to(torch.bfloat16)
@@ -142,8 +148,9 @@ def test_gemm_regimes_agree(big):
     ctx.synchronize()
     for other in (y_big[:256], y_mid[:256]):
         diff = (other.float() - y_small.float()).abs()
-        # at most one bf16 ulp of the result (|y| < 8 -> 0.031), on a handful of elements
-        assert diff.max() <= 0.04 and (other == y_small).float().mean() > 0.99, (float(diff.max()), float((other == y_small).float().mean()))
+        # at most one bf16 ulp of the result (2^-7 of the largest |y|: 0.031 at |y| < 8), on a handful of elements
+        assert diff.max() <= 0.0079 * float(y_small.float().abs().max()) + 1e-3 and (other == y_small).float().mean() > 0.99, \
+            (float(diff.max()), float((other == y_small).float().mean()))
 
 
 def test_edge_cases_tiny_prompt_batch1_and_max_positions(oracle):

@@ -43,12 +43,43 @@ FLAG_SETS = [
     dict(),                                                                                          # defaults 1/1: the IPEX baseline
     dict(prefill_policy=0, decoding_policy=1, gpu_percentage=34, pin_weight=True),                   # README online configs (0/1)
     dict(prefill_policy=1, decoding_policy=2, gpu_percentage=0, pin_weight=True),
+    # --enable-cxl (lia/modeling_opt.py:167-227, lia/cxl/numa_alloc.py:28-55): the streamed layers live in the NUMA / CXL
+    # pool (numa_alloc_interleave on LIA_CXL_NODES = the box's own nodes, hipHostRegister'ed) and stream from there
+    dict(prefill_policy=0, decoding_policy=2, gpu_percentage=25, pin_weight=True, enable_cxl=True),   # BASELINE config 3's tier
+    dict(prefill_policy=0, decoding_policy=1, gpu_percentage=25, pin_weight=True, enable_cxl=True),   # README.md:78 (0/1): host cores read the tier
+    dict(prefill_policy=0, decoding_policy=2, gpu_percentage=0, enable_cxl=True),                     # no --pin-weight: the flag is inert (:1214-1217)
 ]
+WIRE = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}
+
+
+@pytest.fixture(autouse=True)
+def cxl_nodes_of_this_box():
+    """The reference hard-codes NUMA nodes {2, 3} for its CXL pool (lia/cxl/numa_alloc.c:80-81); a test box has whatever it
+    has: interleave over its first two nodes with memory."""
+    from lia_amd import hostinfo
+    from lia_amd.cxl.numa_alloc import set_cxl_nodes
+    nodes = hostinfo.numa_nodes()[:2] or [0]
+    set_cxl_nodes(nodes)
+    yield nodes
+
+
+def _check_tiers(model, c, flags, fmt):
+    """every streamed layer sits in the tier and the wire format the flags ask for (`pack10` used to be
+    silently replaced by pack12 here)"""
+    n_gpu = int(c["L"] * flags.get("gpu_percentage", 0) / 100)
+    pin, cxl = bool(flags.get("pin_weight")), bool(flags.get("enable_cxl"))
+    host_compute = flags.get("prefill_policy", 1) == 1 or flags.get("decoding_policy", 1) == 1
+    want_fmt = WIRE[fmt] if (pin and not host_compute) else 0
+    want_tier = "cxl" if (cxl and pin) else "pinned" if pin else "pageable"
+    assert all(st.tier == "device" for st in model.layers[:n_gpu])
+    for i, st in enumerate(model.layers[n_gpu:]):
+        assert st.tier == want_tier and st.packed == want_fmt, (n_gpu + i, st.tier, st.packed, want_tier, want_fmt)
+        assert (st.stream_bytes < st.nbytes) == bool(want_fmt)
 
 
 @pytest.mark.parametrize("name", GEN_CASES)
 @pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k[:4]}{int(v)}" for k, v in f.items()) or "defaults")
-@pytest.mark.parametrize("fmt", ["raw", "pack12", "pack11", "pack10"])
+@pytest.mark.parametrize("fmt", ["raw", "pack10"])
 def test_generate_ids_match_hf_golden(name, flags, fmt, monkeypatch):
     import torch
     from lia_amd.generation import generate
@@ -63,6 +94,50 @@ def test_generate_ids_match_hf_golden(name, flags, fmt, monkeypatch):
                         num_beams=1, token_latency=True, **flags)
     assert out.shape == (c["B"], c["T"] + c["new"]) and len(lat) == c["new"]
     assert (out.numpy() == z["ids_bf16"]).all(), (out[0, c["T"]:].tolist(), z["ids_bf16"][0, c["T"]:].tolist())
+    _check_tiers(model, c, flags, fmt)
+    model._lia_scheduler.close()
+    model.close()
+
+
+@pytest.mark.parametrize("fmt", ["pack11", "pack12"])
+def test_generate_older_wire_formats(fmt, monkeypatch):
+    """pack11 / pack12 (the first two generations of the wire format, kept selectable): one end-to-end case each"""
+    import torch
+    from lia_amd.generation import generate
+    monkeypatch.setenv("LIA_STREAM_FORMAT", fmt)
+    z, m, ids, c = _load("generate_h256")
+    model = _model(m, c)
+    flags = dict(prefill_policy=0, decoding_policy=2, gpu_percentage=25, pin_weight=True)
+    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], **flags)
+    assert (out.numpy() == z["ids_bf16"]).all()
+    _check_tiers(model, c, flags, fmt)
+    model._lia_scheduler.close()
+    model.close()
+
+
+def test_one_model_object_retiers_across_flag_sets(monkeypatch):
+    """The reference's scripts run one process per flag set (llm/scripts/lia_offline.sh:13-29); a harness that keeps ONE model
+    object and changes flags between generate() calls must get the layers re-placed -- pack10 pinned -> raw for the host cores
+    (policy 1) -> another gpu% with the cache in HBM -> the CXL tier -> fewer resident layers -- with the same ids every time."""
+    import torch
+    from lia_amd.generation import generate
+    monkeypatch.setenv("LIA_STREAM_FORMAT", "pack10")
+    z, m, ids, c = _load("generate_h256")           # 4 layers: 50 / 75 / 25 / 0 % resident are all different placements
+    model = _model(m, c)
+    t = torch.from_numpy(ids)
+    sequence = [
+        dict(prefill_policy=0, decoding_policy=2, gpu_percentage=50, pin_weight=True),
+        dict(),                                                                                  # 1/1: raw, pageable is fine
+        dict(prefill_policy=3, decoding_policy=3, gpu_percentage=75, pin_weight=True, num_minibatch=1),
+        dict(prefill_policy=0, decoding_policy=2, gpu_percentage=25, pin_weight=True, enable_cxl=True),
+        dict(prefill_policy=0, decoding_policy=1, gpu_percentage=25, pin_weight=True),          # host cores: raw pinned
+        dict(prefill_policy=0, decoding_policy=2, gpu_percentage=0, pin_weight=True),           # every resident layer demoted
+    ]
+    for flags in sequence:
+        out = generate(model, t, max_new_tokens=c["new"], min_new_tokens=c["new"], **flags)
+        assert (out.numpy() == z["ids_bf16"]).all(), (flags, out[0, c["T"]:].tolist(), z["ids_bf16"][0, c["T"]:].tolist())
+        if flags:
+            _check_tiers(model, c, flags, "pack10")
     model._lia_scheduler.close()
     model.close()
 
@@ -83,7 +158,7 @@ def test_generate_logits_match_oracle(oracle, name):
         gf, rf = synth.bf16_bits_to_f32(gb), synth.bf16_bits_to_f32(r)
         scale = np.abs(rf).max()
         err = np.abs(gf - rf).max()
-        assert err <= 1e-2 * max(scale, 1.0) + 0.03, f"step {s}: max logit err {err:.4f} at logit scale {scale:.2f}"
+        assert err <= 1e-2 * max(scale, 1.0), f"step {s}: max logit err {err:.4f} at logit scale {scale:.2f}"      # BASELINE.json: within 1e-2
     model._lia_scheduler.close()
     model.close()
 
