@@ -57,6 +57,7 @@ typedef struct {
   long skinny_launches; double skinny_ms, skinny_bytes, skinny_flops; /* decode regime (M <= 256)  */
   long tiled_launches;  double tiled_ms, tiled_bytes, tiled_flops;    /* prefill regime            */
   double empty_bracket_ms; /* what an event pair around NOTHING reads on this stream: the bracket's own cost, measured at stop */
+  long host_attention_calls; double host_attention_ms; /* policy-2 host attention (wall clock of lia_host_attention inside lia_layer_forward) */
 } lia_prof_result;
 int lia_prof_start(lia_ctx* ctx, int max_launches);
 int lia_prof_stop(lia_ctx* ctx, lia_prof_result* out); /* synchronises the compute stream */

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "../../include/lia_hip.h"
@@ -76,6 +77,8 @@ struct lia_ctx {
   struct ProfRec { int regime; double bytes, flops; };
   std::vector<ProfRec>* prof_recs;
   size_t prof_cap;
+  long prof_host_attn_calls;
+  double prof_host_attn_ms;
 };
 
 extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out) {
@@ -153,6 +156,8 @@ extern "C" int lia_prof_start(lia_ctx* c, int max_launches) {
     c->prof_events->push_back(e);
   }
   c->prof_recs->clear();
+  c->prof_host_attn_calls = 0;
+  c->prof_host_attn_ms = 0.0;
   c->prof_cap = max_launches;
   c->prof_on = true;
   return LIA_OK;
@@ -162,6 +167,8 @@ extern "C" int lia_prof_stop(lia_ctx* c, lia_prof_result* out) {
   if (!c || !out || !c->prof_events) return LIA_ERR_INVALID;
   c->prof_on = false;
   memset(out, 0, sizeof(*out));
+  out->host_attention_calls = c->prof_host_attn_calls;
+  out->host_attention_ms = c->prof_host_attn_ms;
   HIP_TRY(hipStreamSynchronize(c->compute));
   for (size_t i = 0; i < c->prof_recs->size(); ++i) {
     float ms = 0.f;
@@ -518,8 +525,13 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
     lia_blit_launch(hk, kb, one, st);
     lia_blit_launch(hv, vb, one, st);
     HIP_TRY(hipStreamSynchronize(st));
+    const auto ha_t0 = std::chrono::steady_clock::now();
     rc = lia_host_attention(hq, hk, hv, kv->k, kv->v, ha, B, T, pos0, d->heads, hd, kv->batch, b0, ctx->host_threads);
     if (rc) return rc;
+    if (ctx->prof_on) {
+      ctx->prof_host_attn_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ha_t0).count();
+      ctx->prof_host_attn_calls++;
+    }
     lia_blit_launch(ao, ha, one, st);
   } else {
     // GPU attention (attentions.py:443-536)

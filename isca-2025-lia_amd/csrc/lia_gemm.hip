@@ -72,23 +72,31 @@ __device__ __forceinline__ int tl_swz(int row) { return (row >> 1) & 7; }
 // 16 bytes per lane, whole 128-byte lines per row, the residual read the same way.  Rounding points are
 // unchanged: bf16(acc) -> bf16(+bias) -> relu -> bf16(residual + .).
 // ---------------------------------------------------------------------------------------------
+// (MBT, J0, MB: the m-blocks J0 .. J0+MB-1 of an accumulator array with MBT of them; m_base = first row of block J0)
+// the residual rows of a wave tile of 16 MB rows x 64 columns, all requested at once (clamped addresses, no branch
+// around a load: a load inside a per-row `if` is waited for on the spot -- 16 dependent round trips, ~13 us per tile)
 template <int MB>
-__device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char* region, int m_base, int n_base, int M, int N,
-                                                 const LiaEpilogue& ep, const LiaOutMap& om, int lane) {
+__device__ __forceinline__ void epilogue_load_residual(uint4 (&rres)[2 * MB], int m_base, int n_base, int M, int N, const LiaEpilogue& ep,
+                                                       int lane) {
+  if (ep.residual == nullptr) return;
+  const int c = lane & 7;
+#pragma unroll
+  for (int r = 0; r < 2 * MB; ++r) {
+    const int gm = min(m_base + r * 8 + (lane >> 3), M - 1), gn = min(n_base + c * 8, N - 8);
+    rres[r] = *(const uint4*)(ep.residual + (long)gm * ep.ldr + gn);
+  }
+}
+
+// Instruction count matters here: stamped on MI355X the epilogue of a 256 x 256 tile took 11 us with the chip otherwise
+// idle -- VALU time, not memory (the second half, whose residual rows had long arrived, alone took 5 us).  So: no integer
+// division per store (the output segment of a lane's 8 columns and the cache row of its first tile row are worked out
+// once, rows then advance by 8), and the two roundings of a pair of values share one v_cvt_pk.
+template <int MBT, int J0, int MB>
+__device__ __forceinline__ void epilogue_via_lds_part(const f32x4 (&acc)[4][MBT], const uint4 (&rres)[2 * MB], char* region, int m_base,
+                                                      int n_base, int M, int N, const LiaEpilogue& ep, const LiaOutMap& om, int lane) {
   const int l15 = lane & 15, lq = lane >> 4;
   const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
   const int c = lane & 7;
-  // the residual rows of the whole wave tile, all requested up front (clamped addresses, no branch around a load: a load
-  // inside the per-row `if` below is waited for on the spot -- 16 dependent round trips, ~13 us per tile): their latency
-  // then hides behind the accumulator -> LDS pass
-  uint4 rres[2 * MB];
-  if (hr) {
-#pragma unroll
-    for (int r = 0; r < 2 * MB; ++r) {
-      const int gm = min(m_base + r * 8 + (lane >> 3), M - 1), gn = min(n_base + c * 8, N - 8);
-      rres[r] = *(const uint4*)(ep.residual + (long)gm * ep.ldr + gn);
-    }
-  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -100,25 +108,33 @@ __device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
       const int m = j * 16 + l15;
-      float t[4];
+      uint32_t o2[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        t[e] = rbf(acc[i][j][e]);
-        if (hb) t[e] = rbf(t[e] + b[e]);
-        if (ep.relu) t[e] = fmaxf(t[e], 0.f);
+      for (int h = 0; h < 2; ++h) {
+        // bf16(acc) -> bf16(+bias) -> relu, two values per packed conversion (relu commutes with the rounding)
+        uint32_t p = pack_bf16x2(acc[i][J0 + j][2 * h], acc[i][J0 + j][2 * h + 1]);
+        float t0 = __uint_as_float(p << 16), t1 = __uint_as_float(p & 0xffff0000u);
+        if (hb) { t0 += b[2 * h]; t1 += b[2 * h + 1]; }
+        if (ep.relu) { t0 = fmaxf(t0, 0.f); t1 = fmaxf(t1, 0.f); }
+        o2[h] = (hb || ep.relu) ? pack_bf16x2(t0, t1) : p;
       }
-      uint2 o;
-      o.x = pack_bf16x2(t[0], t[1]);
-      o.y = pack_bf16x2(t[2], t[3]);
       const int chunk = (2 * i + (lq >> 1)) ^ (m & 7);
-      *(uint2*)(region + m * 128 + chunk * 16 + (lq & 1) * 8) = o;
+      *(uint2*)(region + m * 128 + chunk * 16 + (lq & 1) * 8) = uint2{o2[0], o2[1]};
     }
   }
+  // where my 8 columns go: segment and column inside it (constant over the rows), cache row of my first tile row
+  const int gn = n_base + c * 8;
+  const int seg = gn / om.seg_n;
+  bf16_t* const obase = om.base[seg] + (gn - seg * om.seg_n);
+  const long old = om.ld[seg];
+  const bool cmode = om.cache_mode[seg] != 0;
+  int gm = m_base + (lane >> 3);
+  int cb = 0, ct = 0;
+  if (cmode) { cb = gm / om.T; ct = gm - cb * om.T; }
   // same-wave LDS write -> read: program order + the compiler's lgkmcnt wait suffice (the region is private)
 #pragma unroll
   for (int r = 0; r < 2 * MB; ++r) {
     const int m = r * 8 + (lane >> 3);
-    const int gm = m_base + m, gn = n_base + c * 8;
     uint4 v = *(const uint4*)(region + m * 128 + ((c ^ (m & 7)) << 4));
     if (hr) {
       const uint4 rr = rres[r];
@@ -126,11 +142,24 @@ __device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char
       uint32_t ow[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        ow[e] = pack_bf16x2(bf2f(rw[e] & 0xffff) + bf2f(vw[e] & 0xffff), bf2f(rw[e] >> 16) + bf2f(vw[e] >> 16));
+        ow[e] = pack_bf16x2(__uint_as_float(rw[e] << 16) + __uint_as_float(vw[e] << 16),
+                            __uint_as_float(rw[e] & 0xffff0000u) + __uint_as_float(vw[e] & 0xffff0000u));
       v = uint4{ow[0], ow[1], ow[2], ow[3]};
     }
-    if (gm < M && gn < N) *(uint4*)lia_out_ptr(om, gm, gn) = v;
+    const long row = cmode ? (long)(om.pos0 + ct) * om.Bc + om.b0 + cb : (long)gm;
+    if (gm < M && gn < N) *(uint4*)(obase + row * old) = v;
+    gm += 8;
+    if (cmode) { ct += 8; while (ct >= om.T) { ct -= om.T; ++cb; } }
   }
+}
+
+template <int MB>
+__device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char* region, int m_base, int n_base, int M, int N,
+                                                 const LiaEpilogue& ep, const LiaOutMap& om, int lane) {
+  // the residual loads' latency hides behind the accumulator -> LDS pass
+  uint4 rres[2 * MB];
+  epilogue_load_residual<MB>(rres, m_base, n_base, M, N, ep, lane);
+  epilogue_via_lds_part<MB, 0, MB>(acc, rres, region, m_base, n_base, M, N, ep, om, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,6 +193,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+  else if constexpr (N == 38) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
   else static_assert(N < 0, "add the immediate");
 }
 
@@ -655,10 +686,251 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// tiled regime, large, PHASED schedule (r02).  Same 256 x 256 x 64 tile, LDS image ([W 256 rows | x 256 rows] x 128 B,
+// XOR-swizzled chunks, two buffers = 128 KB), fragment convention and accumulation order (k ascending inside every
+// accumulator: outputs are bit-identical to lia_gemm_tiled256_kernel) -- what changes is WHEN bytes move:
+//   * the K-tile is staged as four half-tiles of 128 rows (W0 = W rows 0-127, W1, X0 = x rows 0-127, X1), ONE per phase,
+//     four phases per K-tile, so the LDS-DMA queue carries a steady 16 KB per phase instead of a 64 KB burst per K-tile
+//     that every CU of the chip fires at the same moment;
+//   * a wave's 128 x rows are 64 rows of X0 + 64 rows of X1 (m-blocks 0-3 / 4-7) and each phase multiplies one quadrant
+//     (2 W row-blocks x 4 x row-blocks x K 64 = 16 MFMA), in the order (Wq0,X0) (Wq1,X0) (Wq1,X1) (Wq0,X1): X0 is last
+//     read in phase 1, W in phase 2, X1 in phase 3, so their regions can be re-staged for tile t+2 from phases 3 / 4 / 1' /
+//     2' on -- up to FOUR half-tiles (64 KB) in flight behind counted vmcnt waits, never a drain inside the loop
+//     (cdna_hip_programming.md "The 256^2 8-phase template"; the one-barrier kernel above drains vmcnt(0) per K-tile and
+//     so exposes one full load latency, ~1.7 us, per 64-deep K-step: 1.2 PFLOP/s);
+//   * waves 0-3 (x rows wm = 0) and waves 4-7 run half a phase apart (one extra barrier for group 1): while one wave of a
+//     SIMD issues its 16 MFMAs the other reads its fragments and issues LDS-DMA.
+// Phase = [ds_read fragments | LDS-DMA one half-tile | (counted vmcnt) | barrier | lgkmcnt(0) | 16 MFMA | barrier].
+//   P1(t): read Wq0 + X0 part (12)   stage W1(t+1)                  MFMA acc0[0..1]
+//   P2(t): read Wq1 (4)              stage X1(t+1)   vmcnt(8)       MFMA acc0[2..3]     (X1(t) landed: read in P3)
+//   P3(t): read X1 part (8)          stage X0(t+2)                  MFMA acc1[2..3]
+//   P4(t): --                        stage W0(t+2)   vmcnt(6)       MFMA acc1[0..1]     (X0, W0, W1 of t+1 landed: P1(t+1))
+// Ordering: RAW -- a half-tile is read one phase after the wait that retires it, and both groups pass their wait and a
+// barrier in between; WAR -- a region is re-staged two phases after its last read, i.e. after a barrier every reader
+// crossed with lgkmcnt(0) done (group 1 lags half a phase: still a full phase of margin).
+// ---------------------------------------------------------------------------------------------
+constexpr int T4_BUF_BYTES = 65536;   // one K-tile: W rows 0-255 at row * 128, x rows at 32768 + row * 128
+#ifdef LIA_GEMM_STAMPS
+__device__ unsigned long long g_t4_stamps[8192 * 8];   // per workgroup: start, after the prologue, after the K loop, after the epilogue (100 MHz ticks)
+#define T4_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_t4_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define T4_STAMP(i) do { } while (0)
+#endif
+
+// DBG (tools/gemm_bench.hip only; 0 in the product): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMA (timing-only,
+// wrong results); 8 no stagger, 16 no s_setprio around the MFMA clusters (correct results)
+// PH = 4: the four-phase schedule above.  PH = 2: two phases per K-tile (32 MFMA each, four barriers per K-tile instead of
+// eight): PA reads all W fragments + the X0 part (16 reads), stages W1(t+1), X1(t+1), waits vmcnt(8), multiplies acc0; PB
+// reads the X1 part (8), stages X0(t+2), W0(t+2), waits vmcnt(6), multiplies acc1.  A region is then re-staged ONE phase
+// after its last read, which is legal because the reading phase waits lgkmcnt(0) BEFORE its first barrier.
+// BUF = 1: the LDS-DMA goes through buffer_load ... lds with a per-tile resource, a per-lane 32-bit row offset and the K
+// offset in an SGPR -- no 64-bit address arithmetic per piece (cdna_hip_programming.md T8).
+template <int DBG, int PH, int BUF>
+__global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                  const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
+                                                                  int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wn = wave & 3, wm = wave >> 2;   // wave tile: W rows [64 wn, +64) x (x rows [64 wm, +64) and [128 + 64 wm, +64))
+
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+#ifdef LIA_GM
+  constexpr int GM = LIA_GM;
+#else
+  constexpr int GM = 4;
+#endif
+  const int group = lin / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int in_g = lin - group * GM * tiles_n;
+  const int tm = (DBG & 32) ? 0 : first_m + in_g % gsz, tn = (DBG & 32) ? 0 : in_g / gsz;   // DBG 32: every workgroup reads tile (0, 0)
+  const int m0 = tm * T2_BM, n0 = tn * T2_BN;
+
+  f32x4 acc0[4][4], acc1[4][4];   // [W row-block][x row-block]: acc0 = the X0 part of the wave's x rows, acc1 = the X1 part
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc0[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // -- staging: a half-tile = two LDS-DMA rounds of the whole workgroup, 64 rows each; my lane moves chunk (tid & 7) of
+  // row 64 q + (tid >> 3) of the 256-row operand tile, q = 2 half + round, into LDS slot tid & 7 of that row (linear
+  // destination, swizzle on the source: rule 21)
+  const int srow = tid >> 3;
+  const int sck = ((tid & 7) ^ tl_swz(srow)) << 3;
+  const bf16_t* const ws0 = W + (long)min(n0 + srow, N - 1) * ldw + sck;
+  const bf16_t* const ws1 = W + (long)min(n0 + 64 + srow, N - 1) * ldw + sck;
+  const bf16_t* const ws2 = W + (long)min(n0 + 128 + srow, N - 1) * ldw + sck;
+  const bf16_t* const ws3 = W + (long)min(n0 + 192 + srow, N - 1) * ldw + sck;
+  const bf16_t* const xs0 = x + (long)min(m0 + srow, M - 1) * ldx + sck;
+  const bf16_t* const xs1 = x + (long)min(m0 + 64 + srow, M - 1) * ldx + sck;
+  const bf16_t* const xs2 = x + (long)min(m0 + 128 + srow, M - 1) * ldx + sck;
+  const bf16_t* const xs3 = x + (long)min(m0 + 192 + srow, M - 1) * ldx + sck;
+  char* const sdst = smem + wave * 1024;
+  // BUF: resources over the tile's first row; voffset = (clamped row - first row) * ld * 2 + chunk * 16 (< 2^31: 256 rows)
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * ldw), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)m0 * ldx), 0, 0x7fffffff, 0x00020000);
+  const int wv0 = (int)((min(n0 + srow, N - 1) - n0) * ldw + sck) * 2, wv1 = (int)((min(n0 + 64 + srow, N - 1) - n0) * ldw + sck) * 2;
+  const int wv2 = (int)((min(n0 + 128 + srow, N - 1) - n0) * ldw + sck) * 2, wv3 = (int)((min(n0 + 192 + srow, N - 1) - n0) * ldw + sck) * 2;
+  const int xv0 = (int)((min(m0 + srow, M - 1) - m0) * ldx + sck) * 2, xv1 = (int)((min(m0 + 64 + srow, M - 1) - m0) * ldx + sck) * 2;
+  const int xv2 = (int)((min(m0 + 128 + srow, M - 1) - m0) * ldx + sck) * 2, xv3 = (int)((min(m0 + 192 + srow, M - 1) - m0) * ldx + sck) * 2;
+#define T4_GLDS(src, dst) __builtin_amdgcn_global_load_lds(GL_AS1(src), LDS_AS3(dst), 16, 0, 0)
+#define T4_BLDS(rs, vo, so, dst) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_AS3(dst), 16, vo, so, 0, 0)
+#define T4_PIECE(rs, vo, ptr, t, dst) do { const int t_ = (DBG & 128) ? 0 : (int)(t); if (BUF) T4_BLDS(rs, vo, t_ * (T2_BK * 2), dst); else T4_GLDS((ptr) + (long)t_ * T2_BK, dst); } while (0)
+#define T4_STAGE_W0(t, buf) do { T4_PIECE(rsw, wv0, ws0, t, sdst + (buf) * T4_BUF_BYTES);         T4_PIECE(rsw, wv1, ws1, t, sdst + (buf) * T4_BUF_BYTES + 8192); } while (0)
+#define T4_STAGE_W1(t, buf) do { T4_PIECE(rsw, wv2, ws2, t, sdst + (buf) * T4_BUF_BYTES + 16384); T4_PIECE(rsw, wv3, ws3, t, sdst + (buf) * T4_BUF_BYTES + 24576); } while (0)
+#define T4_STAGE_X0(t, buf) do { T4_PIECE(rsx, xv0, xs0, t, sdst + (buf) * T4_BUF_BYTES + 32768); T4_PIECE(rsx, xv1, xs1, t, sdst + (buf) * T4_BUF_BYTES + 40960); } while (0)
+#define T4_STAGE_X1(t, buf) do { T4_PIECE(rsx, xv2, xs2, t, sdst + (buf) * T4_BUF_BYTES + 49152); T4_PIECE(rsx, xv3, xs3, t, sdst + (buf) * T4_BUF_BYTES + 57344); } while (0)
+
+  // -- fragment reads: lane (l15, lq) reads chunk 4 ks + lq of row base + l15, stored in slot chunk ^ swz(row);
+  // swz(row) = (row >> 1) & 7 depends on l15 only (row bases are multiples of 16), and the two k-steps differ in bit 6
+  const int c0 = (lq ^ tl_swz(l15)) << 4;
+  const char* const wf0 = smem + (wn * 64 + l15) * 128 + c0;               // k-step 0; k-step 1 = ^ 64
+  const char* const wf1 = smem + (wn * 64 + l15) * 128 + (c0 ^ 64);
+  const char* const xf0 = smem + 32768 + (wm * 64 + l15) * 128 + c0;
+  const char* const xf1 = smem + 32768 + (wm * 64 + l15) * 128 + (c0 ^ 64);
+  bf16x8 a[4][2], b[4][2];
+#define T4_LD(p) __builtin_bit_cast(bf16x8, *(const uint4*)(p))
+#define T4_READ_W(buf, i0) do {                                                                                          \
+    a[i0][0] = T4_LD(wf0 + (buf) * T4_BUF_BYTES + (i0) * 2048);       a[i0][1] = T4_LD(wf1 + (buf) * T4_BUF_BYTES + (i0) * 2048);             \
+    a[i0 + 1][0] = T4_LD(wf0 + (buf) * T4_BUF_BYTES + (i0 + 1) * 2048); a[i0 + 1][1] = T4_LD(wf1 + (buf) * T4_BUF_BYTES + (i0 + 1) * 2048);   \
+  } while (0)
+#define T4_READ_X(buf, part) do {                                                                                        \
+    b[0][0] = T4_LD(xf0 + (buf) * T4_BUF_BYTES + (part) * 16384);        b[0][1] = T4_LD(xf1 + (buf) * T4_BUF_BYTES + (part) * 16384);        \
+    b[1][0] = T4_LD(xf0 + (buf) * T4_BUF_BYTES + (part) * 16384 + 2048); b[1][1] = T4_LD(xf1 + (buf) * T4_BUF_BYTES + (part) * 16384 + 2048); \
+    b[2][0] = T4_LD(xf0 + (buf) * T4_BUF_BYTES + (part) * 16384 + 4096); b[2][1] = T4_LD(xf1 + (buf) * T4_BUF_BYTES + (part) * 16384 + 4096); \
+    b[3][0] = T4_LD(xf0 + (buf) * T4_BUF_BYTES + (part) * 16384 + 6144); b[3][1] = T4_LD(xf1 + (buf) * T4_BUF_BYTES + (part) * 16384 + 6144); \
+  } while (0)
+#define T4_MMA(ACC, i0) do {                                                                                             \
+    if (DBG & 4) {   /* keep the fragment reads alive without the MFMAs */                                                \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                               \
+        _Pragma("unroll") for (int i_ = (i0); i_ < (i0) + 2; ++i_) asm volatile("" :: "v"(a[i_][ks_]));                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) asm volatile("" :: "v"(b[j_][ks_]));                             \
+      }                                                                                                                   \
+      break;                                                                                                              \
+    }                                                                                                                     \
+    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                                   \
+      _Pragma("unroll") for (int i_ = (i0); i_ < (i0) + 2; ++i_)                                                          \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
+          ACC[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i_][ks_], b[j_][ks_], ACC[i_][j_], 0, 0, 0);            \
+    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+#define T4_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define T4_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // one K-tile.  S12: tile t+1 exists (stage its W1, X1); S34: tile t+2 exists (stage its X0, W0); W2 / W4: the vmcnt
+  // immediates of the two waits (-1 = no wait); LAST: group 1 skips the closing barrier (it entered one barrier late)
+#define T4_TILE(t, buf, S12, S34, W2, W4, LAST) do {                                                                     \
+    if (!(DBG & 2) || (t) == 0) { T4_READ_W(buf, 0); T4_READ_X(buf, 0); }                                                 \
+    if ((S12) && !(DBG & 1)) T4_STAGE_W1((t) + 1, (buf) ^ 1);                                                             \
+    T4_BARRIER(); T4_LGKM0(); T4_MMA(acc0, 0); T4_BARRIER();                                                              \
+    if (!(DBG & 2) || (t) == 0) T4_READ_W(buf, 2);                                                                        \
+    if ((S12) && !(DBG & 1)) T4_STAGE_X1((t) + 1, (buf) ^ 1);                                                             \
+    if (DBG & 1) wait_vmcnt<0>(); else wait_vmcnt<W2>();                                                                  \
+    T4_BARRIER(); T4_LGKM0(); T4_MMA(acc0, 2); T4_BARRIER();                                                              \
+    if (!(DBG & 2)) T4_READ_X(buf, 1);                                                                                    \
+    if ((S34) && !(DBG & 1)) T4_STAGE_X0((t) + 2, buf);                                                                   \
+    T4_BARRIER(); T4_LGKM0(); T4_MMA(acc1, 2); T4_BARRIER();                                                              \
+    if ((S34) && !(DBG & 1)) T4_STAGE_W0((t) + 2, buf);                                                                   \
+    if (DBG & 1) wait_vmcnt<0>(); else if (W4 >= 0) wait_vmcnt<(W4 >= 0 ? W4 : 0)>();                                     \
+    T4_BARRIER(); T4_MMA(acc1, 0);                                                                                        \
+    if (!(LAST) || wm == 0 || (DBG & 8)) T4_BARRIER();                                                                    \
+  } while (0)
+
+  // two-phase K-tile (PH = 2).  Every half-tile gets two phases (one K-tile time) between its LDS-DMA and the wait that
+  // retires it: W1 is staged with X0 and W0 in PB, one phase after the last read of those regions in PA (with W1 issued in PA,
+  // as in the four-phase order, it had ONE phase and the kernel ran 20 % slower when the waits were tightened further).
+  //   PA(t): read all W + the X0 part (16)   stage X1(t+1) -> other buffer        vmcnt(8): X1(t) has landed
+  //   PB(t): read the X1 part (8)            stage X0, W0, W1 (t+2) -> this one   vmcnt(8): X0, W0, W1 (t+1) have landed
+#define T4_TILE2(t, buf, S12, S34, W2, W4, LAST) do {                                                                    \
+    if (!(DBG & 2) || (t) == 0) { T4_READ_W(buf, 0); T4_READ_W(buf, 2); T4_READ_X(buf, 0); }                              \
+    if ((S12) && !(DBG & 1)) T4_STAGE_X1((t) + 1, (buf) ^ 1);                                                             \
+    if (DBG & 1) wait_vmcnt<0>(); else if (DBG & 256) wait_vmcnt<(W2 >= 4 ? 4 : W2)>(); else wait_vmcnt<W2>();             \
+    T4_LGKM0(); T4_BARRIER(); T4_MMA(acc0, 0); T4_MMA(acc0, 2); T4_BARRIER();                                             \
+    if (!(DBG & 2)) T4_READ_X(buf, 1);                                                                                    \
+    if ((S34) && !(DBG & 1)) { T4_STAGE_X0((t) + 2, buf); T4_STAGE_W0((t) + 2, buf); T4_STAGE_W1((t) + 2, buf); }         \
+    if (DBG & 1) wait_vmcnt<0>(); else if ((DBG & 256) && W4 >= 2) wait_vmcnt<2>(); else if (W4 >= 0) wait_vmcnt<(W4 >= 0 ? W4 : 0)>(); \
+    T4_LGKM0(); T4_BARRIER(); T4_MMA(acc1, 2); T4_MMA(acc1, 0);                                                           \
+    if (!(LAST) || wm == 0 || (DBG & 8)) T4_BARRIER();                                                                    \
+  } while (0)
+
+  const int nk = K / T2_BK;      // even and >= 4 (the launcher falls back to the one-barrier kernel otherwise)
+  T4_STAMP(0);
+  if (PH == 4) {
+    T4_STAGE_X0(0, 0); T4_STAGE_W0(0, 0); T4_STAGE_W1(0, 0); T4_STAGE_X1(0, 0);
+    T4_STAGE_X0(1, 1); T4_STAGE_W0(1, 1);
+    wait_vmcnt<6>();             // X0, W0, W1 of tile 0 have landed (X1(0) is waited for in P2)
+  } else {
+    T4_STAGE_X0(0, 0); T4_STAGE_W0(0, 0); T4_STAGE_W1(0, 0); T4_STAGE_X1(0, 0);
+    T4_STAGE_X0(1, 1); T4_STAGE_W0(1, 1); T4_STAGE_W1(1, 1);
+    wait_vmcnt<8>();             // X0, W0, W1 of tile 0 have landed (X1(0) is waited for in PA)
+  }
+  T4_BARRIER();
+  T4_STAMP(1);
+  if (wm == 1 && !(DBG & 8)) T4_BARRIER();     // the stagger
+  int t = 0;
+  if (PH == 4) {
+    for (; t + 2 < nk; t += 2) {
+      T4_TILE(t, 0, true, true, 8, 6, false);
+      T4_TILE(t + 1, 1, true, true, 8, 6, false);
+    }
+    T4_TILE(t, 0, true, false, 8, 2, false);
+    T4_TILE(t + 1, 1, false, false, 0, -1, true);
+  } else {
+    for (; t + 2 < nk; t += 2) {
+      T4_TILE2(t, 0, true, true, 8, 8, false);
+      T4_TILE2(t + 1, 1, true, true, 8, 8, false);
+    }
+    T4_TILE2(t, 0, true, false, 8, 2, false);
+    T4_TILE2(t + 1, 1, false, false, 0, -1, true);
+  }
+#undef T4_TILE2
+#undef T4_TILE
+#undef T4_LGKM0
+#undef T4_BARRIER
+#undef T4_MMA
+#undef T4_READ_X
+#undef T4_READ_W
+#undef T4_LD
+#undef T4_STAGE_X1
+#undef T4_STAGE_X0
+#undef T4_STAGE_W1
+#undef T4_STAGE_W0
+#undef T4_PIECE
+#undef T4_BLDS
+#undef T4_GLDS
+  // group 0's closing barrier is the one group 1 crossed before its last MFMAs: every LDS read of the workgroup has been
+  // retired (P4 reads nothing, P3's reads were waited for), no LDS-DMA is pending (the last wait was vmcnt(0)), and each
+  // wave's epilogue region is its own
+  T4_STAMP(2);
+  // the residual rows of BOTH halves of the wave tile are requested before the first store: vmcnt retires in order, so a
+  // residual load issued behind the first half's stores would wait for them as well (the fragment registers are free now)
+  if (!(DBG & 64) || acc0[0][0][0] == 12345.678f || acc1[3][3][1] == 12345.678f) {     // DBG 64: no epilogue (timing only)
+    uint4 rres0[8], rres1[8];
+    epilogue_load_residual<4>(rres0, m0 + wm * 64, n0 + wn * 64, M, N, ep, lane);
+    epilogue_load_residual<4>(rres1, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, lane);
+    T4_STAMP(4);
+    epilogue_via_lds_part<4, 0, 4>(acc0, rres0, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
+    T4_STAMP(5);
+    epilogue_via_lds_part<4, 0, 4>(acc1, rres1, smem + wave * 16384 + 8192, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
+    T4_STAMP(6);
+  }
+#ifdef LIA_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  T4_STAMP(3);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------------------------
-// 256: one-barrier-per-K-tile kernel; 257: staggered kernel.  LIA_GEMM_TILED_VARIANT overrides (A/B runs, tests).
-static int g_tiled_variant = [] { const char* e = getenv("LIA_GEMM_TILED_VARIANT"); return e ? atoi(e) : 256; }();
+// 262 (default): phased kernel, two phases per K-tile, buffer-load LDS-DMA; 259 / 260 / 261: its four-phase and global_load_lds
+// forms; 256: the one-barrier-per-K-tile kernel of r01 (also the fallback for K / 64 odd or < 4); 257 / 258: r01's staggered
+// k-half kernel.  All produce bit-identical outputs.  LIA_GEMM_TILED_VARIANT overrides (A/B runs, tests).
+static int g_tiled_variant = [] { const char* e = getenv("LIA_GEMM_TILED_VARIANT"); return e ? atoi(e) : 262; }();
 extern "C" void lia_gemm_set_tiled_variant(int v) { g_tiled_variant = v; }
 
 extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
@@ -802,7 +1074,34 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     if (ev1) (void)hipEventRecord(ev1, st);
     return 0;
   }
-  if (M >= 1024 && N >= 512 && g_tiled_variant == 256) {
+  if (M >= 1024 && N >= 512 && g_tiled_variant >= 259 && g_tiled_variant <= 262 && (K / T2_BK) >= 4 && ((K / T2_BK) & 1) == 0) {
+    int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
+    if (ev0) (void)hipEventRecord(ev0, st);
+#define T4_LAUNCH(D, PH, BUF) do {                                                                                         \
+      static bool set_ = false;                                                                                           \
+      if (!set_) { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256p_kernel<D, PH, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF_BYTES); set_ = true; } \
+      hipLaunchKernelGGL((lia_gemm_tiled256p_kernel<D, PH, BUF>), dim3(tiles_m * tiles_n), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); \
+    } while (0)
+#ifdef LIA_GEMM_ABLATE
+    static int dbg = [] { const char* e = getenv("T4_DBG"); return e ? atoi(e) : 0; }();
+    if (g_tiled_variant == 259) switch (dbg) {
+      case 1: T4_LAUNCH(1, 4, 0); break; case 4: T4_LAUNCH(4, 4, 0); break; case 5: T4_LAUNCH(5, 4, 0); break; case 6: T4_LAUNCH(6, 4, 0); break;
+      case 8: T4_LAUNCH(8, 4, 0); break; default: T4_LAUNCH(0, 4, 0); break;
+    } else switch (dbg) {
+      case 1: T4_LAUNCH(1, 2, 1); break; case 4: T4_LAUNCH(4, 2, 1); break; case 5: T4_LAUNCH(5, 2, 1); break; case 6: T4_LAUNCH(6, 2, 1); break;
+      case 8: T4_LAUNCH(8, 2, 1); break; case 38: T4_LAUNCH(38, 2, 1); break; case 32: T4_LAUNCH(32, 2, 1); break; case 64: T4_LAUNCH(64, 2, 1); break; case 128: T4_LAUNCH(128, 2, 1); break; case 256: T4_LAUNCH(256, 2, 1); break; case 192: T4_LAUNCH(192, 2, 1); break; default: T4_LAUNCH(0, 2, 1); break;
+    }
+#else
+    if (g_tiled_variant == 259) T4_LAUNCH(0, 4, 0);
+    else if (g_tiled_variant == 260) T4_LAUNCH(0, 2, 0);
+    else if (g_tiled_variant == 261) T4_LAUNCH(0, 4, 1);
+    else T4_LAUNCH(0, 2, 1);
+#endif
+#undef T4_LAUNCH
+    if (ev1) (void)hipEventRecord(ev1, st);
+    return 0;
+  }
+  if (M >= 1024 && N >= 512 && (g_tiled_variant == 256 || (g_tiled_variant >= 259 && g_tiled_variant <= 262))) {
     int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
     static bool attr_set = false;
     if (!attr_set) {

@@ -27,7 +27,7 @@ class LayerDesc(ctypes.Structure):
 class ProfResult(ctypes.Structure):
     _fields_ = [("skinny_launches", c_long), ("skinny_ms", c_double), ("skinny_bytes", c_double), ("skinny_flops", c_double),
                 ("tiled_launches", c_long), ("tiled_ms", c_double), ("tiled_bytes", c_double), ("tiled_flops", c_double),
-                ("empty_bracket_ms", c_double)]
+                ("empty_bracket_ms", c_double), ("host_attention_calls", c_long), ("host_attention_ms", c_double)]
 
 
 class LlamaDesc(ctypes.Structure):

@@ -50,13 +50,16 @@ def generate(model, input_ids, max_new_tokens=None, min_new_tokens=None, do_samp
            "enable_cxl": bool(lia["enable_cxl"])}
     if model_kwargs.get("cpu_layers"):           # build-defined extension (scheduler.forward): host-computed decode layers
         lia["cpu_layers"] = int(model_kwargs.pop("cpu_layers"))
+    # build-defined, for bench.py: step_hook(i) runs before greedy iteration i (barriers / profiler brackets around exactly the
+    # timed steps); max_steps ends the loop early while the caches stay sized for max_new_tokens (a short warm-up call)
+    hooks = {"step_hook": model_kwargs.pop("step_hook", None), "max_steps": model_kwargs.pop("max_steps", None)}
     min_new = min_new_tokens or 0
     return _greedy_search(model, input_ids, max_new_tokens, min_new, eos_token_id, pad_token_id, token_latency,
-                          return_logits, lia)
+                          return_logits, lia, **hooks)
 
 
 def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_id, pad_token_id, token_latency,
-                   return_logits, lia):
+                   return_logits, lia, step_hook=None, max_steps=None):
     sched = _scheduler_of(model)
     ids = torch.as_tensor(input_ids, dtype=torch.int64).cpu()
     if ids.dim() != 2:
@@ -79,6 +82,8 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
     cur = ids
     step = 0
     while True:
+        if step_hook is not None:
+            step_hook(step)
         tic = time.time()
         # EOS is suppressed while fewer than min_new_tokens were generated (HF MinNewTokensLengthLogitsProcessor)
         suppress = eos_token_id if (eos_token_id is not None and step < min_new_tokens) else -1
@@ -94,7 +99,7 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         if return_logits:
             logits_list.append(logits.clone())
         latency_list.append(time.time() - tic)                                         # :424
-        if unfinished.max() == 0 or step >= max_new_tokens:
+        if unfinished.max() == 0 or step >= max_new_tokens or (max_steps is not None and step >= max_steps):
             break
     out = ids
     if return_logits:

@@ -355,7 +355,8 @@ class LiaOPTModel:
         """Random-init weights of the exact architecture, generated ON THE GPU one layer at a time and
         moved straight to their tier (an OPT-30B would take minutes to draw on the CPU).
         init="normal": HF _init_weights (lia/modeling_opt.py:895-904): Linear/Embedding ~ N(0, 0.02), zero
-        bias, LN = (1, 0).  init="uniform01": the reference's dummy recipe (opt-weight-gen.py:61-62), seeded.
+        bias, LN = (1, 0).  init="uniform01": the reference's dummy recipe (opt-weight-gen.py:61-62: torch.rand_like on EVERY
+        parameter -- weights, biases, LayerNorm weights and biases, embeddings), seeded.
         Every tensor group has its own seed, so data-parallel ranks draw identical resident layers;
         host_owner=False (non-root DP ranks) skips the streamed layers, which arrive by broadcast.
         raw_layers: layers whose host copy stays raw bf16 whatever the wire format (the host cores compute them)."""
@@ -375,8 +376,11 @@ class LiaOPTModel:
 
         self.embed_tokens = draw(shape.vocab, H)
         self.embed_positions = draw(shape.max_pos + 2, H)
-        self.final_ln_w = torch.ones(H, dtype=torch.bfloat16, device="cuda")
-        self.final_ln_b = torch.zeros(H, dtype=torch.bfloat16, device="cuda")
+        if init == "uniform01":      # opt-weight-gen.py:61-62 draws EVERY parameter, LayerNorm weights and biases included
+            self.final_ln_w, self.final_ln_b = draw(H), draw(H)
+        else:
+            self.final_ln_w = torch.ones(H, dtype=torch.bfloat16, device="cuda")
+            self.final_ln_b = torch.zeros(H, dtype=torch.bfloat16, device="cuda")
         shapes = {"q_w": (H, H), "k_w": (H, H), "v_w": (H, H), "out_w": (H, H), "fc1_w": (F, H), "fc2_w": (H, F)}
         for li, st in enumerate(self.layers):
             if li >= n_gpu_layers and not host_owner:
@@ -389,11 +393,11 @@ class LiaOPTModel:
                 if n in shapes:
                     r, c = shapes[n]
                     flat[o:o + r * c] = draw(r, c).reshape(-1)
-                elif n in ("ln1_w", "ln2_w"):
-                    flat[o:o + H] = 1.0
                 elif init == "uniform01":
                     k = F if n == "fc1_b" else H
                     flat[o:o + k] = draw(k)
+                elif n in ("ln1_w", "ln2_w"):
+                    flat[o:o + H] = 1.0
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu_layers:
                 fmt = LayerStore._fmt_of(pack12)

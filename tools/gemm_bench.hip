@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("ERR %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 __global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed) {
@@ -43,6 +44,36 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
 #ifdef LIA_GEMM_STAMPS
+  if (getenv("T4STAMPS")) {
+    // phased kernel (variant 262): where a workgroup's time goes -- prologue / K loop / epilogue, and the gap to the next
+    // workgroup on the same CU slot (start-to-start minus the three), averaged over the workgroups of one launch
+    for (auto& sh : shapes) {
+      if (!strcmp(sh.name, "dummy")) continue;
+      LiaEpilogue ep{bias, res, sh.N, 0};
+      LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
+      lia_gemm_set_tiled_variant(atoi(getenv("T4STAMPS")));
+      for (int rep = 0; rep < 3; ++rep) lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, 0, st, nullptr, nullptr, nullptr);
+      CK(hipStreamSynchronize(st));
+      const int nwg = std::min(8192, ((M + 255) / 256) * ((sh.N + 255) / 256));
+      std::vector<unsigned long long> h(8192 * 8);
+      CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_t4_stamps), h.size() * 8));
+      double pro = 0, loop = 0, epi = 0, e_issue = 0, e_p0 = 0, e_p1 = 0, e_drain = 0; unsigned long long first = ~0ull, last = 0;
+      for (int g = 0; g < nwg; ++g) {
+        const unsigned long long* q = h.data() + 8 * g;
+        pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]);
+        e_issue += (double)(q[4] - q[2]); e_p0 += (double)(q[5] - q[4]); e_p1 += (double)(q[6] - q[5]); e_drain += (double)(q[3] - q[6]);
+        first = std::min(first, q[0]); last = std::max(last, q[3]);
+      }
+      printf("   epilogue of wave 0: residual loads issued %.2f us, first half (wait + LDS pass + stores issued) %.2f us, second half %.2f us, store drain %.2f us\n",
+             e_issue * 0.01 / nwg, e_p0 * 0.01 / nwg, e_p1 * 0.01 / nwg, e_drain * 0.01 / nwg);
+      const double per_wg_wall = (double)(last - first) * 0.01 / (nwg / 256.0);
+      printf("%-8s N=%d K=%d: %d workgroups; per workgroup: prologue %.2f us, K loop %.2f us (%.3f us per K-tile), epilogue %.2f us; "
+             "kernel span / (workgroups per CU) = %.2f us -> unaccounted %.2f us per workgroup\n", sh.name, sh.N, sh.K, nwg, pro * 0.01 / nwg,
+             loop * 0.01 / nwg, loop * 0.01 / nwg / (sh.K / 64), epi * 0.01 / nwg, per_wg_wall,
+             per_wg_wall - (pro + loop + epi) * 0.01 / nwg);
+    }
+    return 0;
+  }
   {
     // one launch of the staggered kernel, then the barrier-to-barrier intervals of waves 0 (group 0) and 4 (group 1)
     auto& sh = shapes[0];
