@@ -446,30 +446,36 @@ extern "C" int lia_pack11_encode(const bf16_t* src, size_t n_values, char* dst, 
 // =====================================================================================================
 // "pack10": three-level exponent code, the closest of the three to the exponent entropy (10.55 bits per value for
 // N(0, sigma) weights).  Level 1: 2 bits per value as two bit-planes - codes 0..2 = the three most frequent
-// exponents of the layer, 3 = "see level 2".  Level 2: 2 bits per level-1 escape, compacted in value order - codes
+// exponents, 3 = "see level 2".  Level 2: 2 bits per level-1 escape, compacted in value order - codes
 // 0..2 = the next three exponents, 3 = "see level 3".  Level 3: pack12's 4-bit alphabet per level-2 escape (14-binade
-// window, 14 = exponent 0 i.e. +-0 and denormals, 15 = escape record).  The symbol sets are arbitrary exponents
-// (header tables), so +-0 and denormals need no special case.  Two u32 offset tables (one entry per 1024 values each)
-// + two wave prefix sums of popcounts locate every lane's level-2 / level-3 codes.
-// 8 + 2 + 0.274*2 + 0.041*4 + 0.06 = 10.77 bits per value for N(0, sigma) = 67.3 % of the raw bytes.
-// Buffer: [header 256][plane A: n][b0: n/8][b1: n/8][tab2: n/1024 u32][tab3: n/1024 u32][level 2][level 3][escapes]
+// window, 14 = exponent 0 i.e. +-0 and denormals, 15 = escape record).  The symbol sets are arbitrary exponents, so +-0
+// and denormals need no special case.
+// The symbol sets are PER REGION of 65536 values (a table of {sym1, sym2, e3} entries behind the header, built on the
+// device from a histogram of each region): the 16 tensors of a real checkpoint's layer differ in scale (q/k/v vs fc1/fc2,
+// LayerNorm weights near 1, biases near 0) and one table per layer would spread over all their binades -- r01 measured the
+// format only on one-sigma Gaussians.  16 bytes per 128 KB of values: 0.002 bits per value.
+// Two u32 offset tables (one entry per 1024 values each) + two wave prefix sums of popcounts locate every lane's
+// level-2 / level-3 codes.  8 + 2 + 0.274*2 + 0.041*4 + 0.06 = 10.77 bits per value for N(0, sigma) = 67.3 % of the raw bytes.
+// Buffer: [header 256][region tables: 16 B each][plane A: n][b0: n/8][b1: n/8][tab2: n/1024 u32][tab3: n/1024 u32][level 2][level 3][escapes]
 // =====================================================================================================
+constexpr int LP10_REGION_SHIFT = 6;     // 2^6 blocks of 1024 values per region
 struct LiaPack10Header {
   uint32_t magic;        // 'LP10'
-  uint32_t sym1;         // bytes 0..2: exponents of level-1 codes 0..2
-  uint32_t sym2;         // bytes 0..2: exponents of level-2 codes 0..2
-  uint32_t e3;           // first exponent of the 14-binade level-3 window
+  uint32_t version;      // 2: per-region symbol tables
+  uint32_t n_regions;
+  uint32_t region_shift; // blocks per region = 1 << region_shift
   uint64_t n;            // values, multiple of 1024
   uint64_t n_l2;         // level-2 codes (2 bits each)
   uint64_t n_l3;         // level-3 codes (4 bits each)
-  uint64_t off_a, off_b0, off_b1, off_tab2, off_tab3, off_l2, off_l3, off_esc;
+  uint64_t off_rtab, off_a, off_b0, off_b1, off_tab2, off_tab3, off_l2, off_l3, off_esc;
   uint64_t l2_cap, l3_cap;
   uint32_t n_esc, esc_cap;
   uint32_t overflow;
-  uint32_t pad[31];
+  uint32_t pad[29];
 };
 static_assert(sizeof(LiaPack10Header) == 256, "header is 256 bytes");
 constexpr uint32_t LP10_MAGIC = 0x3031504cu;
+struct Lp10Region { uint32_t sym1, sym2, e3, pad; };   // sym1 / sym2: bytes 0..2 = the exponents of codes 0..2
 
 struct Lp10Codes {
   uint32_t a[4];       // sign|mantissa bytes
@@ -513,20 +519,69 @@ __device__ __forceinline__ void lp10_load16(const bf16_t* p, uint32_t (&w)[8]) {
   w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
 }
 
+// pass 0: one workgroup per region -- exponent histogram, then the six most frequent exponents (by count, ties: lower
+// exponent first, never the same exponent twice) and the 14 consecutive exponents (>= 1) that cover most of the rest
+__global__ __launch_bounds__(256) void lia_pack10_region_kernel(const bf16_t* __restrict__ src, char* __restrict__ dst) {
+  LiaPack10Header* hd = (LiaPack10Header*)dst;
+  Lp10Region* rtab = (Lp10Region*)(dst + hd->off_rtab);
+  __shared__ unsigned h[256];
+  const size_t per = (size_t)1024 << hd->region_shift;
+  for (unsigned reg = blockIdx.x; reg < hd->n_regions; reg += gridDim.x) {
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)reg * per, hi = min(hd->n, lo + per);
+    for (size_t i = lo + threadIdx.x * 8; i < hi; i += 256 * 8) {
+      const uint4 v = *(const uint4*)(src + i);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { atomicAdd(&h[(w[k] >> 7) & 0xff], 1u); atomicAdd(&h[(w[k] >> 23) & 0xff], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int top[6];
+      unsigned taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int t = 0; t < 6; ++t) {
+        int best = -1;
+        for (int e = 0; e < 256; ++e)
+          if (!((taken[e >> 5] >> (e & 31)) & 1) && (best < 0 || h[e] > h[best])) best = e;
+        top[t] = best; taken[best >> 5] |= 1u << (best & 31);
+      }
+      int e3 = 1;
+      unsigned long long bestc = 0, cur = 0;
+      for (int k = 1; k <= 14; ++k) cur += ((taken[k >> 5] >> (k & 31)) & 1) ? 0 : h[k];
+      bestc = cur;
+      for (int st = 2; st <= 255 - 14 + 1; ++st) {          // slide the window [st, st + 13]
+        const int out = st - 1, in = st + 13;
+        cur -= ((taken[out >> 5] >> (out & 31)) & 1) ? 0 : h[out];
+        cur += ((taken[in >> 5] >> (in & 31)) & 1) ? 0 : h[in];
+        if (cur > bestc) { bestc = cur; e3 = st; }
+      }
+      Lp10Region r;
+      r.sym1 = (uint32_t)top[0] | ((uint32_t)top[1] << 8) | ((uint32_t)top[2] << 16);
+      r.sym2 = (uint32_t)top[3] | ((uint32_t)top[4] << 8) | ((uint32_t)top[5] << 16);
+      r.e3 = (uint32_t)e3; r.pad = 0;
+      rtab[reg] = r;
+    }
+    __syncthreads();
+  }
+}
+
 // pass 1: level-2 and level-3 code counts per 1024-value block
 __global__ __launch_bounds__(256) void lia_pack10_count_kernel(const bf16_t* __restrict__ src, char* __restrict__ dst) {
   LiaPack10Header* hd = (LiaPack10Header*)dst;
   const size_t nblk = hd->n / 1024;
   uint32_t* tab2 = (uint32_t*)(dst + hd->off_tab2);
   uint32_t* tab3 = (uint32_t*)(dst + hd->off_tab3);
-  const uint32_t sym1 = hd->sym1, sym2 = hd->sym2, e3 = hd->e3;
+  const Lp10Region* rtab = (const Lp10Region*)(dst + hd->off_rtab);
+  const int rshift = (int)hd->region_shift;
   const int lane = threadIdx.x & 63;
   size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t stride = (size_t)gridDim.x * 4;
   for (; blk < nblk; blk += stride) {
+    const Lp10Region rt = rtab[blk >> rshift];
     uint32_t w[8];
     lp10_load16(src + blk * 1024 + lane * 16, w);
-    const Lp10Codes c = lp10_codes(w, sym1, sym2, e3);
+    const Lp10Codes c = lp10_codes(w, rt.sym1, rt.sym2, rt.e3);
     int t2, t3;
     (void)wave_excl_scan(c.n2, lane, t2);
     (void)wave_excl_scan(c.n3, lane, t3);
@@ -583,15 +638,17 @@ __global__ __launch_bounds__(256) void lia_pack10_encode_kernel(const bf16_t* __
   uint32_t* l2w = (uint32_t*)(dst + hd->off_l2);
   uint32_t* l3w = (uint32_t*)(dst + hd->off_l3);
   uint2* esc = (uint2*)(dst + hd->off_esc);
-  const uint32_t sym1 = hd->sym1, sym2 = hd->sym2, e3 = hd->e3;
+  const Lp10Region* rtab = (const Lp10Region*)(dst + hd->off_rtab);
+  const int rshift = (int)hd->region_shift;
   const int lane = threadIdx.x & 63;
   size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t stride = (size_t)gridDim.x * 4;
   for (; blk < nblk; blk += stride) {
+    const Lp10Region rt = rtab[blk >> rshift];
     const size_t g = blk * 64 + lane;           // 16-value group index
     uint32_t w[8];
     lp10_load16(src + g * 16, w);
-    const Lp10Codes c = lp10_codes(w, sym1, sym2, e3);
+    const Lp10Codes c = lp10_codes(w, rt.sym1, rt.sym2, rt.e3);
     *(uint4*)(pa + g * 16) = uint4{c.a[0], c.a[1], c.a[2], c.a[3]};
     p0[g] = (uint16_t)c.b0; p1[g] = (uint16_t)c.b1;
     int t2, t3;
@@ -632,7 +689,8 @@ __device__ __forceinline__ uint64_t lp10_get_bits(const uint32_t* stream, uint64
 __global__ __launch_bounds__(256) void lia_pack10_decode_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
   const LiaPack10Header* hd = (const LiaPack10Header*)src;
   const size_t nblk = hd->n / 1024;
-  const uint32_t sym1 = hd->sym1, sym2 = hd->sym2, e3 = hd->e3;
+  const Lp10Region* rtab = (const Lp10Region*)(src + hd->off_rtab);
+  const int rshift = (int)hd->region_shift;
   const uint8_t* pa = (const uint8_t*)(src + hd->off_a);
   const uint16_t *p0 = (const uint16_t*)(src + hd->off_b0), *p1 = (const uint16_t*)(src + hd->off_b1);
   const uint32_t* tab2 = (const uint32_t*)(src + hd->off_tab2);
@@ -643,6 +701,8 @@ __global__ __launch_bounds__(256) void lia_pack10_decode_kernel(const char* __re
   size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t stride = (size_t)gridDim.x * 4;
   for (; blk < nblk; blk += stride) {
+    const Lp10Region rt = rtab[blk >> rshift];
+    const uint32_t sym1 = rt.sym1, sym2 = rt.sym2, e3 = rt.e3;
     const size_t g = blk * 64 + lane;
     const uint4 av = *(const uint4*)(pa + g * 16);
     const uint32_t a[4] = {av.x, av.y, av.z, av.w};
@@ -695,55 +755,30 @@ __global__ __launch_bounds__(256) void lia_pack10_patch_kernel(const char* __res
 }
 
 // room an encode may need: level 2 up to n codes, level 3 up to n/2 nibbles, escapes n/16 records
+static inline size_t lp10_regions(size_t n_values) { return (n_values / 1024 + ((size_t)1 << LP10_REGION_SHIFT) - 1) >> LP10_REGION_SHIFT; }
 extern "C" size_t lia_pack10_bound(size_t n_values) {
-  return 256 + lp12_align(n_values) + 2 * lp12_align(n_values / 8) + 2 * lp12_align((n_values / 1024) * 4 + 16) +
+  return 256 + lp12_align(lp10_regions(n_values) * sizeof(Lp10Region)) + lp12_align(n_values) + 2 * lp12_align(n_values / 8) + 2 * lp12_align((n_values / 1024) * 4 + 16) +
          2 * lp12_align(n_values / 4 + 16) + lp12_align((n_values / 16) * 8);
 }
 
 // Same contract as lia_pack12_encode; n_values must be a multiple of 1024.  Returns 1 when the layer does not fit.
 extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, size_t dst_capacity, size_t* out_bytes) {
   if (!src || !dst || !out_bytes || (n_values % 1024) || dst_capacity < lia_pack10_bound(n_values)) return -1;
-  unsigned* hist = nullptr;
-  if (hipMalloc((void**)&hist, 256 * sizeof(unsigned)) != hipSuccess) return -2;
-  (void)hipMemset(hist, 0, 256 * sizeof(unsigned));
-  hipLaunchKernelGGL(lia_pack12_hist_kernel, dim3(1024), dim3(256), 0, 0, src, n_values, hist);
-  unsigned h[256];
-  if (hipMemcpy(h, hist, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(hist); return -3; }
-  (void)hipFree(hist);
-  // the six most frequent exponents, by count (ties: lower exponent first); never the same exponent twice
-  int top[6];
-  bool used[256] = {false};
-  for (int t = 0; t < 6; ++t) {
-    int best = -1;
-    for (int e = 0; e < 256; ++e)
-      if (!used[e] && (best < 0 || h[e] > h[best])) best = e;
-    top[t] = best; used[best] = true;
-  }
-  // level-3 window: the 14 consecutive exponents (>= 1) that cover most of what is left
-  int e3 = 1;
-  {
-    unsigned long long best = 0;
-    for (int s = 1; s <= 255 - 14 + 1; ++s) {
-      unsigned long long cur = 0;
-      for (int k = 0; k < 14; ++k) cur += used[s + k] ? 0 : h[s + k];
-      if (cur > best) { best = cur; e3 = s; }
-    }
-  }
   LiaPack10Header hd;
   memset(&hd, 0, sizeof(hd));
-  hd.magic = LP10_MAGIC;
-  hd.sym1 = (uint32_t)top[0] | ((uint32_t)top[1] << 8) | ((uint32_t)top[2] << 16);
-  hd.sym2 = (uint32_t)top[3] | ((uint32_t)top[4] << 8) | ((uint32_t)top[5] << 16);
-  hd.e3 = (uint32_t)e3; hd.n = n_values;
+  hd.magic = LP10_MAGIC; hd.version = 2;
+  hd.n = n_values; hd.region_shift = LP10_REGION_SHIFT; hd.n_regions = (uint32_t)lp10_regions(n_values);
   hd.esc_cap = (uint32_t)(n_values / 16); hd.l2_cap = n_values; hd.l3_cap = n_values / 2;
   const size_t tab_bytes = lp12_align((n_values / 1024) * 4 + 16);
   const size_t l2_bytes = lp12_align(n_values / 4 + 16), l3_bytes = lp12_align(n_values / 4 + 16);
-  hd.off_a = 256; hd.off_b0 = hd.off_a + lp12_align(n_values); hd.off_b1 = hd.off_b0 + lp12_align(n_values / 8);
+  hd.off_rtab = 256; hd.off_a = hd.off_rtab + lp12_align((size_t)hd.n_regions * sizeof(Lp10Region));
+  hd.off_b0 = hd.off_a + lp12_align(n_values); hd.off_b1 = hd.off_b0 + lp12_align(n_values / 8);
   hd.off_tab2 = hd.off_b1 + lp12_align(n_values / 8); hd.off_tab3 = hd.off_tab2 + tab_bytes;
   // provisional stream positions at full capacity; compacted below once the real sizes are known
   hd.off_l2 = hd.off_tab3 + tab_bytes; hd.off_l3 = hd.off_l2 + l2_bytes; hd.off_esc = hd.off_l3 + l3_bytes;
   if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
   (void)hipMemset(dst + hd.off_l2, 0, l2_bytes + l3_bytes);
+  hipLaunchKernelGGL(lia_pack10_region_kernel, dim3(hd.n_regions < 4096 ? hd.n_regions : 4096), dim3(256), 0, 0, src, dst);
   hipLaunchKernelGGL(lia_pack10_count_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
   hipLaunchKernelGGL(lia_pack10_scan_kernel, dim3(1), dim3(1024), 0, 0, dst, 2);
   hipLaunchKernelGGL(lia_pack10_scan_kernel, dim3(1), dim3(1024), 0, 0, dst, 3);

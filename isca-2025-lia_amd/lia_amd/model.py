@@ -60,13 +60,55 @@ def resolve_shape(name):
     return SHAPES[key]
 
 
+def _drawer(init, g):
+    def draw(*size):
+        if init == "uniform01":
+            return torch.rand(*size, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        return (0.02 * torch.randn(*size, generator=g, device="cuda", dtype=torch.float32)).to(torch.bfloat16)
+    return draw
+
+
+def draw_head(shape, seed=0, init="normal"):
+    """embed_tokens, embed_positions, final LN weight / bias of a seeded random model (see LiaOPTModel.random_init)"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed * 100003)
+    draw = _drawer(init, g)
+    H = shape.hidden
+    tok, pos = draw(shape.vocab, H), draw(shape.max_pos + 2, H)
+    if init == "uniform01":      # opt-weight-gen.py:61-62 draws EVERY parameter, LayerNorm weights and biases included
+        return tok, pos, draw(H), draw(H)
+    return tok, pos, torch.ones(H, dtype=torch.bfloat16, device="cuda"), torch.zeros(H, dtype=torch.bfloat16, device="cuda")
+
+
+def draw_layer(shape, offsets, layer_bytes, li, seed=0, init="normal"):
+    """Layer li of a seeded random model as the packed flat buffer (CUDA bf16): every layer has its own seed, so any subset of
+    layers -- one at a time in the checkpoint writer, the resident prefix on a data-parallel peer -- draws the same values."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed * 100003 + li + 1)
+    draw = _drawer(init, g)
+    H, F = shape.hidden, shape.ffn
+    shapes = {"q_w": (H, H), "k_w": (H, H), "v_w": (H, H), "out_w": (H, H), "fc1_w": (F, H), "fc2_w": (H, F)}
+    flat = torch.zeros(layer_bytes // 2, dtype=torch.bfloat16, device="cuda")
+    for i, n in enumerate(LAYER_TENSORS):
+        o = offsets[i] // 2
+        if n in shapes:
+            r, c = shapes[n]
+            flat[o:o + r * c] = draw(r, c).reshape(-1)
+        elif init == "uniform01":
+            k = F if n == "fc1_b" else H
+            flat[o:o + k] = draw(k)
+        elif n in ("ln1_w", "ln2_w"):
+            flat[o:o + H] = 1.0
+    return flat
+
+
 class LayerStore:
     """One decoder layer's 16 tensors packed into a flat 256-byte-aligned buffer (lia_layer_pack_offsets),
     living in exactly one tier at a time."""
 
     def __init__(self, desc, offsets, total_bytes):
         self.desc, self.offsets, self.nbytes = desc, offsets, total_bytes
-        self.tier = None          # "device" | "pinned" | "cxl" | "pageable" | "remote"
+        self.tier = None          # "device" | "pinned" | "cxl" | "mapped" | "pageable" | "remote"
         self.packed = 0           # 0: host copy is raw bf16; 10 / 11 / 12: it holds that lossless encoding (lia_pack12.hip)
         self.shard = None         # (rank, world, slice bytes) when the host copy is one slice of the wire bytes
         self.stream_bytes = total_bytes   # bytes that cross the host link per use
@@ -99,14 +141,14 @@ class LayerStore:
     def _host_view(self):
         if self.tier == "pageable":
             return self._np
-        if self.tier in ("pinned", "cxl") and not self.packed and not self.shard:
+        if self.tier in ("pinned", "cxl", "mapped") and not self.packed and not self.shard:
             return np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self._ptr))
         raise RuntimeError(f"no raw host view of a layer in tier {self.tier!r} (packed={self.packed}, shard={self.shard})")
 
     def host_ptr(self):
         if self.tier == "pageable":
             return self._np.ctypes.data
-        if self.tier in ("pinned", "cxl"):
+        if self.tier in ("pinned", "cxl", "mapped"):
             return self._ptr
         raise RuntimeError("layer is on the device")
 
@@ -115,7 +157,7 @@ class LayerStore:
         streamed copy is packed, else the host copy itself; None when there is none"""
         if getattr(self, "_raw_ptr", None):
             return self._raw_ptr
-        return None if (self.packed or self.shard or self.tier not in ("pinned", "cxl", "pageable")) else self.host_ptr()
+        return None if (self.packed or self.shard or self.tier not in ("pinned", "cxl", "mapped", "pageable")) else self.host_ptr()
 
     def device_ptr(self):
         assert self.tier == "device"
@@ -294,8 +336,32 @@ class LayerStore:
         self._ptr, self.tier = ptr, "cxl"
         self.packed, self.stream_bytes, self.want_fmt = (fmt if enc else 0), nbytes, fmt
 
+    def set_from_mapped_file(self, path, offset, nbytes, fmt):
+        """The layer's wire bytes straight from a checkpoint file of the build's on-disk format (lia_amd.packed_checkpoint):
+        a private mmap of the file range, registered with the driver (hipHostRegister) so the copy engine DMAs from the page
+        cache copy -- no second host copy of the model.  fmt = 0 (raw bf16) or the packed format the file holds."""
+        import mmap
+        if fmt == 0 and nbytes != self.nbytes:
+            raise ValueError(f"{path}: raw layer of {nbytes} bytes, expected {self.nbytes}")
+        self._free()
+        gran = mmap.ALLOCATIONGRANULARITY
+        start = offset // gran * gran
+        f = open(path, "rb")
+        try:
+            mm = mmap.mmap(f.fileno(), nbytes + (offset - start), access=mmap.ACCESS_COPY, offset=start)
+        finally:
+            f.close()
+        base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+        rc = self._lib.lia_numa_register(base, len(mm))
+        if rc != 0:
+            mm.close()
+            N.check(rc, f"hipHostRegister of {path}")
+        self._mm, self._mm_base = mm, base
+        self._ptr, self.tier = base + (offset - start), "mapped"
+        self.packed, self.stream_bytes, self.want_fmt = int(fmt), nbytes, int(fmt)
+
     def is_dma_able(self):
-        return self.tier in ("pinned", "cxl")
+        return self.tier in ("pinned", "cxl", "mapped")
 
     def _free(self):
         if getattr(self, "_raw_ptr", None):
@@ -306,6 +372,13 @@ class LayerStore:
         elif self.tier == "cxl" and self._ptr:
             self._lib.lia_numa_unregister(self._ptr)
             self._lib.numa_free_node(self._ptr, self.stream_bytes)      # the size it was allocated with
+        elif self.tier == "mapped" and getattr(self, "_mm", None) is not None:
+            self._lib.lia_numa_unregister(self._mm_base)
+            try:
+                self._mm.close()
+            except BufferError:
+                pass                      # a ctypes view still points into it; the mapping goes with the last reference
+            self._mm = None
         self._ptr = self._dev = self._np = None
         self.tier = None
         self.packed, self.stream_bytes, self.shard, self.want_fmt = 0, self.nbytes, None, 0
@@ -365,39 +438,12 @@ class LiaOPTModel:
             from . import hostinfo
             hostinfo.check_host_allocation(int(self.streamed_bytes(n_gpu_layers) * (0.76 if pack12 else 1.0) / (shard[1] if shard else 1)),
                                            f"{shape.name}: {shape.layers - n_gpu_layers} streamed layers")
-        g = torch.Generator(device="cuda")
-        g.manual_seed(seed * 100003)
-        H, F = shape.hidden, shape.ffn
-
-        def draw(*size):
-            if init == "uniform01":
-                return torch.rand(*size, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
-            return (0.02 * torch.randn(*size, generator=g, device="cuda", dtype=torch.float32)).to(torch.bfloat16)
-
-        self.embed_tokens = draw(shape.vocab, H)
-        self.embed_positions = draw(shape.max_pos + 2, H)
-        if init == "uniform01":      # opt-weight-gen.py:61-62 draws EVERY parameter, LayerNorm weights and biases included
-            self.final_ln_w, self.final_ln_b = draw(H), draw(H)
-        else:
-            self.final_ln_w = torch.ones(H, dtype=torch.bfloat16, device="cuda")
-            self.final_ln_b = torch.zeros(H, dtype=torch.bfloat16, device="cuda")
-        shapes = {"q_w": (H, H), "k_w": (H, H), "v_w": (H, H), "out_w": (H, H), "fc1_w": (F, H), "fc2_w": (H, F)}
+        self.embed_tokens, self.embed_positions, self.final_ln_w, self.final_ln_b = draw_head(shape, seed, init)
         for li, st in enumerate(self.layers):
             if li >= n_gpu_layers and not host_owner:
                 st.tier = "remote"          # lives on the DP root's host; reaches this rank by broadcast
                 continue
-            g.manual_seed(seed * 100003 + li + 1)
-            flat = torch.zeros(self.layer_bytes // 2, dtype=torch.bfloat16, device="cuda")
-            for i, n in enumerate(LAYER_TENSORS):
-                o = self.offsets[i] // 2
-                if n in shapes:
-                    r, c = shapes[n]
-                    flat[o:o + r * c] = draw(r, c).reshape(-1)
-                elif init == "uniform01":
-                    k = F if n == "fc1_b" else H
-                    flat[o:o + k] = draw(k)
-                elif n in ("ln1_w", "ln2_w"):
-                    flat[o:o + H] = 1.0
+            flat = draw_layer(shape, self.offsets, self.layer_bytes, li, seed, init)
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu_layers:
                 fmt = LayerStore._fmt_of(pack12)
@@ -441,6 +487,8 @@ class LiaOPTModel:
             if enable_cxl and pin_weight:
                 st.to_cxl(0 if i in raw_layers else fmt)
             elif pin_weight:
+                if st.tier == "mapped" and st.want_fmt == fmt and not shard and i not in raw_layers:
+                    continue                  # a registered mapping of the checkpoint file in the wire format asked for IS pinned memory
                 st.to_pinned(fmt, shard=shard, keep_raw=(i in raw_layers))
             elif st.tier == "device" or st.packed or st.shard:
                 st.to_pageable()              # no --pin-weight: plain host memory, staged through the bounce buffer

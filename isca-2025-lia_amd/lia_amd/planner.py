@@ -29,6 +29,7 @@ class Box:
     wire_ratio: float = 0.675         # bytes shipped per weight byte: pack10 0.675, pack11 0.696, pack12 0.751, raw 1.0
     host_threads: int = 0
     host_mem_gb: float = 0.0
+    calibrated: dict = None           # set by calibrate(): the measured numbers, for the log
 
     def __post_init__(self):
         if not self.host_threads:
@@ -36,6 +37,106 @@ class Box:
         if not self.host_mem_gb:
             b = hostinfo.host_memory_budget()
             self.host_mem_gb = (b / 2**30) if b else 1e9
+
+
+def calibrate(device=0, host_threads=0, budget_s=8.0, verbose=False):
+    """Measure this box instead of trusting the defaults above (the reference hand-picks per script
+    line, llm/scripts/lia_offline.sh:13-29): pinned H2D rate, the decode GEMM's weight-read rate at M = 64, the decode
+    attention's KV-read rate, the prefill GEMM's TFLOP/s, and the host attention / host linear rates at the thread count the
+    scheduler will use -- every number through the same C ABI entry points the hot path calls.  Takes a few seconds."""
+    import ctypes
+    import time
+
+    import numpy as np
+    import torch
+
+    from . import _native as N, ops
+    L = N.lib()
+    threads = host_threads or hostinfo.default_host_threads(1)
+    box = Box(host_threads=threads)
+    t_start = time.time()
+    torch.cuda.set_device(device)
+    ctx = ops.Context(device, 1 << 30)
+
+    def timed(fn, reps):
+        fn()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        return (time.time() - t0) / reps
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rnd = lambda *s: (0.02 * torch.randn(*s, generator=g, device="cuda")).to(torch.bfloat16)  # noqa: E731
+    # host link: one pinned 256 MB block, blocking copies
+    nb = 256 << 20
+    hp = L.lia_host_alloc_pinned(nb)
+    if not hp:
+        raise MemoryError("calibrate: cannot pin 256 MB")
+    dbuf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dt = timed(lambda: N.check(L.lia_memcpy_h2d(ctypes.c_void_p(dbuf.data_ptr()), ctypes.c_void_p(hp), nb)), 3)
+    box.link_gbs = nb / dt / 1e9
+    L.lia_host_free_pinned(hp)
+    del dbuf
+    # decode GEMM at M = 64: four weight buffers of 117 MB take turns (beyond the 256 MB Infinity Cache)
+    K, Nw = 7168, 8192
+    ws = [rnd(Nw, K) for _ in range(4)]
+    x = rnd(64, K)
+    it = [0]
+
+    def skinny():
+        ctx.linear(x, ws[it[0] % 4])
+        it[0] += 1
+    dt = timed(skinny, 12)
+    box.hbm_gbs = 2.0 * Nw * K / dt / 1e9
+    # prefill GEMM
+    xb = rnd(4096, K)
+    dt = timed(lambda: ctx.linear(xb, ws[0]), 4)
+    box.mfma_tflops = 2.0 * 4096 * Nw * K / dt / 1e12
+    del ws, xb
+    # decode attention over an HBM-resident cache
+    B, S, heads, d = 64, 512, 56, 128
+    kc = rnd(S, B, heads, d)
+    vc = rnd(S, B, heads, d)
+    q = rnd(B, 1, heads * d)
+    dt = timed(lambda: ctx.attention(q, kc, vc, S, heads), 6)
+    box.attn_gbs = 2.0 * S * B * heads * d * 2 / dt / 1e9
+    del kc, vc, q
+    # host attention and host linear at the scheduler's thread count (numpy buffers: pageable host memory is what they read)
+    Bh, Sh = 16, 256
+    hk = np.zeros((Sh + 1, Bh, heads, d), np.uint16)
+    hv = np.zeros_like(hk)
+    hq = np.zeros((Bh, 1, heads * d), np.uint16)
+    ho = np.zeros_like(hq)
+    args = (hq.ctypes.data, hq.ctypes.data, hq.ctypes.data, hk.ctypes.data, hv.ctypes.data, ho.ctypes.data, Bh, 1, Sh, heads, d, Bh, 0, threads)
+    N.check(L.lia_host_attention(*args))
+    t0 = time.time()
+    reps = 6
+    for _ in range(reps):
+        N.check(L.lia_host_attention(*args))
+    rate = 2.0 * Sh * Bh * heads * d * 2 / ((time.time() - t0) / reps) / 1e9
+    box.host_gbs_per_thread, box.host_gbs_cap = rate / threads, rate
+    if L.lia_host_has_avx512_bf16() and time.time() - t_start < budget_s:
+        Nh = 4096
+        hw = np.zeros((Nh, K), np.uint16)
+        hx = np.zeros((64, K), np.uint16)
+        hy = np.zeros((64, Nh), np.uint16)
+        largs = (hx.ctypes.data, hw.ctypes.data, None, None, hy.ctypes.data, 64, Nh, K, 0, threads)
+        N.check(L.lia_host_linear(*largs))
+        t0 = time.time()
+        for _ in range(3):
+            N.check(L.lia_host_linear(*largs))
+        box.host_linear_gbs_per_thread = 2.0 * Nh * K / ((time.time() - t0) / 3) / 1e9 / threads
+    ctx.close()
+    box.calibrated = {"seconds": round(time.time() - t_start, 2), "link_gbs": round(box.link_gbs, 1), "hbm_gbs": round(box.hbm_gbs),
+                      "attn_gbs": round(box.attn_gbs), "mfma_tflops": round(box.mfma_tflops), "host_attention_gbs": round(rate, 1),
+                      "host_linear_gbs_per_thread": round(box.host_linear_gbs_per_thread, 2), "host_threads": threads}
+    if verbose:
+        print("planner.calibrate:", box.calibrated)
+    return box
 
 
 @dataclass
@@ -119,12 +220,12 @@ def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None, kv_in_hbm=False)
     return best
 
 
-def plan(shape, B, T, new, box=None, objective="decode"):
+def plan(shape, B, T, new, box=None, objective="decode", max_gpu_percentage=100):
     """Best (gpu%, decode policy) under the HBM and host-memory capacities.  objective: "decode" (tokens/s) or "latency"
-    (prefill + new * decode)."""
+    (prefill + new * decode).  max_gpu_percentage: an upper bound on the resident share (what-if runs, tests)."""
     box = box or Box()
     best = None
-    for pct in range(0, 101, 1):
+    for pct in range(0, min(100, int(max_gpu_percentage)) + 1, 1):
         if int(shape.layers * pct / 100) == int(shape.layers * (pct - 1) / 100) and pct > 0:
             continue
         for pol in (2, 3):

@@ -40,8 +40,12 @@ def build_parser():
     p.add_argument("--num-minibatch", default=1, type=int)
     p.add_argument("--enable-cxl", action="store_true")
     # build-specific
-    p.add_argument("--stream-format", default=os.environ.get("LIA_STREAM_FORMAT", "raw"), choices=["raw", "pack12", "pack11", "pack10"],
-                   help="wire format of the pinned streamed layers: raw bf16 (what the reference ships) or a lossless packed format")
+    p.add_argument("--stream-format", default=None, choices=["raw", "pack12", "pack11", "pack10"],
+                   help="wire format of the pinned streamed layers: raw bf16 (what the reference ships; default, or $LIA_STREAM_FORMAT) "
+                        "or a lossless packed format; a model directory in the build's packed format defaults to the format on disk")
+    p.add_argument("--auto-plan", action="store_true",
+                   help="measure this box (lia_amd.planner.calibrate, a few seconds) and let the planner choose --gpu-percentage, "
+                        "the policies and --cpu-layers instead of the hand-picked values of llm/scripts/lia_*.sh")
     p.add_argument("--cpu-layers", default=0, type=int,
                    help="with --decoding-policy 2: this many streamed layers take their decode step on the host cores (policy 1 per layer)")
     p.add_argument("--seed", default=0, type=int)
@@ -57,13 +61,59 @@ def synthetic_prompt(vocab, n_tokens, batch, seed=0):
     return row[None, :].repeat(batch, 1)          # prompt = [prompt] * batch_size  (run_generation.py:285)
 
 
+def model_shape(args):
+    """shape of the model `-m` names, without loading it (the planner needs it first)"""
+    if os.path.isdir(args.model_id):
+        import json
+        from . import packed_checkpoint
+        from .model import OPTShape
+        if packed_checkpoint.is_packed_dir(args.model_id):
+            sh = json.load(open(os.path.join(args.model_id, packed_checkpoint.MANIFEST)))["shape"]
+            return OPTShape(sh["name"], sh["hidden"], sh["heads"], sh["ffn"], sh["layers"], vocab=sh["vocab"], max_pos=sh["max_pos"])
+        cfg = json.load(open(os.path.join(args.model_id, "config.json")))
+        return OPTShape(os.path.basename(args.model_id.rstrip("/")), cfg["hidden_size"], cfg["num_attention_heads"], cfg["ffn_dim"],
+                        cfg["num_hidden_layers"], vocab=cfg["vocab_size"], max_pos=cfg["max_position_embeddings"])
+    return resolve_shape(args.model_id)
+
+
+def auto_plan(args, out=print):
+    """--auto-plan: calibrate the box, plan, overwrite the LIA flags with the plan (f-3)."""
+    from . import planner
+    box = planner.calibrate(verbose=False)
+    if os.environ.get("LIA_PLAN_HBM_GB"):          # what-if: pretend the GPU is smaller
+        box.hbm_gb = float(os.environ["LIA_PLAN_HBM_GB"])
+    max_pct = int(os.environ.get("LIA_PLAN_MAX_GPU_PCT", "100"))     # what-if / tests: cap the resident share
+    fmt = args.stream_format or os.environ.get("LIA_STREAM_FORMAT", "pack10")
+    box.wire_ratio = {"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[fmt]
+    shape = model_shape(args)
+    pl = planner.plan(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, box, max_gpu_percentage=max_pct)
+    args.gpu_percentage, args.prefill_policy, args.decoding_policy = pl.gpu_percentage, pl.prefill_policy, pl.decoding_policy
+    args.num_minibatch, args.pin_weight, args.stream_format = pl.num_minibatch, True, fmt
+    if pl.n_gpu_layers < shape.layers and pl.decoding_policy == 2:
+        args.cpu_layers, _ = planner.plan_cpu_layers(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, pl.gpu_percentage, box)
+    out(f"auto-plan: calibrated {box.calibrated}")
+    out(f"auto-plan: gpu%={pl.gpu_percentage} ({pl.n_gpu_layers} resident layers) prefill policy {pl.prefill_policy} decode policy "
+        f"{pl.decoding_policy} cpu-layers {args.cpu_layers} wire {fmt}; predicted prefill {pl.prefill_ms:.0f} ms, "
+        f"{pl.decode_tokens_per_s:.1f} tokens/s ({pl.note})")
+    return pl
+
+
 def load_model(args):
     if os.path.isdir(args.model_id):
+        from . import packed_checkpoint
+        if packed_checkpoint.is_packed_dir(args.model_id):
+            import json
+            man = json.load(open(os.path.join(args.model_id, packed_checkpoint.MANIFEST)))
+            shape_layers = man["shape"]["layers"]
+            if args.stream_format is None:       # stream what is on disk, as it is
+                wires = [e["wire"] for e in man["layers"]]
+                args.stream_format = {0: "raw", 10: "pack10", 11: "pack11", 12: "pack12"}[max(set(wires), key=wires.count)]
+            return packed_checkpoint.load_packed(args.model_id, n_gpu_layers=int(shape_layers * args.gpu_percentage / 100))
         from .checkpoint import load_hf_opt
         return load_hf_opt(args.model_id)
     shape = resolve_shape(args.model_id)
     n_gpu = int(shape.layers * args.gpu_percentage / 100)
-    fmt = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[args.stream_format]
+    fmt = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[args.stream_format or os.environ.get("LIA_STREAM_FORMAT", "raw")]
     if args.prefill_policy == 1 or args.decoding_policy == 1:
         fmt = 0                      # the host path reads the raw copy in place
     from .scheduler import OffloadScheduler
@@ -108,8 +158,13 @@ def main(argv=None):
         node = int(os.environ["LIA_PIN_NODE"]) if os.environ.get("LIA_PIN_NODE") is not None else hostinfo.gpu_numa_node(0)
         if node >= 0 and hostinfo.pin_to_node(node):
             print(f"host threads pinned to NUMA node {node}")
-    os.environ["LIA_STREAM_FORMAT"] = args.stream_format          # the scheduler generate() creates reads it
+    if args.auto_plan:
+        auto_plan(args)
     model = load_model(args)
+    if args.stream_format is None:
+        args.stream_format = os.environ.get("LIA_STREAM_FORMAT", "raw")
+    from .scheduler import OffloadScheduler
+    model._lia_scheduler = OffloadScheduler(model, pack12=args.stream_format)     # generate() drives this scheduler
     generate_kwargs = dict(do_sample=False, num_beams=1, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
                            token_latency=args.token_latency, prefill_policy=args.prefill_policy,
                            decoding_policy=args.decoding_policy, no_overlap=args.no_overlap, pin_weight=args.pin_weight,

@@ -339,3 +339,73 @@ def test_run_generation_main_on_a_checkpoint_directory(tmp_path, capsys, blocked
     want = str(z["ids_bf16"][0, T:].tolist())
     assert text.count(want) == 3, text[-2000:]
     assert seen["ids"].shape == (B, T)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f-2: the on-disk streaming format + the dummy-weight generator twin; f-3: --auto-plan
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wire", ["pack10", "raw"])
+def test_dummy_checkpoint_directory_streams_like_the_generator(tmp_path, wire):
+    """`python -m lia_amd.packed_checkpoint --model M --save_dir D` (twin of llm/utils/opt-weight-gen.py): the directory holds
+    one wire buffer per layer; load_packed maps the files (mmap + hipHostRegister, no second host copy) and the run from the
+    directory reproduces the run from LiaOPTModel.random_init with the same seed bit for bit (ids AND logits)."""
+    import torch
+    from lia_amd import packed_checkpoint as pc
+    from lia_amd.generation import generate
+    from lia_amd.model import SHAPES, LiaOPTModel, OPTShape
+    shape = OPTShape("opt-dummy", 512, 4, 2048, 4, vocab=1024, max_pos=64)
+    SHAPES["opt-dummy"] = shape
+    try:
+        man = pc.main(["--model", "opt-dummy", "--save_dir", str(tmp_path / "d"), "--seed", "9", "--wire", wire])
+    finally:
+        del SHAPES["opt-dummy"]
+    assert man["format"] == pc.FORMAT and len(man["layers"]) == 4 and all(e["wire"] == {"pack10": 10, "raw": 0}[wire] for e in man["layers"])
+    if wire == "pack10":
+        assert sum(e["bytes"] for e in man["layers"]) < 0.66 * sum(e["raw_bytes"] for e in man["layers"])
+    ids = torch.from_numpy(synth.make_prompt_ids(5, 4, 12, 1024))
+    ref_model = LiaOPTModel.random_init(shape, seed=9, init="uniform01", n_gpu_layers=4)
+    ref, _, ref_logits = generate(ref_model, ids, max_new_tokens=4, min_new_tokens=4, return_logits=True, prefill_policy=0,
+                                  decoding_policy=2, gpu_percentage=100, pin_weight=True)
+    model = pc.load_packed(str(tmp_path / "d"), n_gpu_layers=1)
+    assert [st.tier for st in model.layers] == ["device", "mapped", "mapped", "mapped"]
+    assert all(st.packed == {"pack10": 10, "raw": 0}[wire] and st.is_dma_able() for st in model.layers[1:])
+    from lia_amd.scheduler import OffloadScheduler
+    model._lia_scheduler = OffloadScheduler(model, pack12=wire)
+    out, _, logits = generate(model, ids, max_new_tokens=4, min_new_tokens=4, return_logits=True, prefill_policy=3, decoding_policy=3,
+                              gpu_percentage=25, pin_weight=True)
+    assert [st.tier for st in model.layers] == ["device", "mapped", "mapped", "mapped"]      # streamed straight from the files
+    assert torch.equal(out, ref) and all(torch.equal(a, b) for a, b in zip(logits, ref_logits))
+    # the mapped layers re-tier like any others: policy 1 wants raw host copies
+    out1 = generate(model, ids, max_new_tokens=2, min_new_tokens=2, prefill_policy=0, decoding_policy=1, gpu_percentage=25, pin_weight=True)
+    assert out1.shape == (4, 14) and all(st.packed == 0 for st in model.layers[1:])
+    model._lia_scheduler.close()
+    model.close()
+    ref_model.close()
+
+
+def test_save_packed_round_trip_and_auto_plan_through_the_harness(tmp_path, capsys, monkeypatch):
+    """save_packed(model) -> `run.py -m <dir> --auto-plan ...`: the planner calibrates the box through the C ABI (a few
+    seconds), chooses gpu% / policies (LIA_PLAN_MAX_GPU_PCT caps the resident share, so layers MUST stream), the harness loads the
+    packed directory, and the ids are the HF golden ids."""
+    from lia_amd import packed_checkpoint as pc, planner, run_generation
+    from lia_amd.model import LiaOPTModel, OPTShape
+    z = np.load(os.path.join(GOLD, "generate_h256.npz"))
+    vocab, max_pos, H, heads, F, L, B, T, new, seed = [int(v) for v in z["cfg"]]
+    m = synth.make_model(seed, vocab, max_pos, H, F, L, float(z["w_std"][0]))
+    model = LiaOPTModel.from_numpy(OPTShape("opt-golden", H, heads, F, L, vocab=vocab, max_pos=max_pos), m)
+    d = str(tmp_path / "packed")
+    man = pc.save_packed(model, d, wire=10)
+    model.close()
+    assert all(e["wire"] == 10 and e["bytes"] < e["raw_bytes"] for e in man["layers"])
+    box = planner.calibrate()
+    c = box.calibrated
+    assert c["seconds"] < 10 and 15 < c["link_gbs"] < 70 and 1500 < c["hbm_gbs"] < 8000 and 400 < c["mfma_tflops"] < 2500 and c["host_attention_gbs"] > 1
+    monkeypatch.setenv("LIA_PLAN_MAX_GPU_PCT", "50")      # at most half of the layers may be resident: the others MUST stream
+    prompt = synth.make_prompt_ids(seed + 1, B, T, vocab)[0]
+    monkeypatch.setattr(run_generation, "synthetic_prompt",
+                        lambda vocab_, n, batch, seed=0: __import__("torch").from_numpy(np.tile(prompt[None, :], (batch, 1))))
+    res = run_generation.main(["--benchmark", "-m", d, "--dtype", "bfloat16", "--input-tokens", str(T), "--max-new-tokens", str(new),
+                               "--batch-size", str(B), "--token-latency", "--num-iter", "2", "--num-warmup", "1", "--greedy", "--auto-plan"])
+    text = capsys.readouterr().out
+    assert "auto-plan: gpu%=" in text and "auto-plan: gpu%=100" not in text and res["decode_tokens_per_s"] > 0
+    assert text.count(str(z["ids_bf16"][0, T:].tolist())) == 2, text[-3000:]

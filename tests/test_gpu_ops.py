@@ -358,6 +358,42 @@ def test_pack12_roundtrip_is_bit_exact(gpu, kind, fmt):
     L.lia_stream_destroy(h)
 
 
+@pytest.mark.parametrize("kind", ["sigma-spread", "student-t", "real-layer-like"])
+def test_pack10_bits_per_value_on_heterogeneous_weights(gpu, kind):
+    """pack10's symbol tables are per region of 65536 values (per-layer tables were only ever measured on one-sigma
+    Gaussians).  A layer whose tensors differ in scale by 8x, heavy-tailed weights, and a layer shaped like a trained one
+    (LayerNorm weights near 1, small biases, weight matrices of different sigma) must all stay <= 0.70 of the raw bytes
+    (11.2 bits per value) and decode bit-exactly through lia_pack_decode."""
+    import ctypes
+    ctx, ops, torch = gpu
+    from lia_amd import _native as N
+    L = N.lib()
+    rs = np.random.RandomState(11)
+    per = 1 << 18
+    if kind == "sigma-spread":          # 16 tensors, sigma from 0.004 to 0.032 (8x)
+        parts = [(0.004 * 2 ** (3.0 * i / 15)) * rs.standard_normal(per) for i in range(16)]
+    elif kind == "student-t":           # t(4): tails far beyond a Gaussian's, per-tensor scales 4x apart
+        parts = [(0.01 * 2 ** (2.0 * i / 15)) * rs.standard_t(4, per) for i in range(16)]
+    else:                               # trained-layer-like: q/k/v/out 0.02, fc1 0.012, fc2 0.03, LN gamma ~ 1, biases ~ 0.01 / 0.1
+        parts = [0.02 * rs.standard_normal(per) for _ in range(4)] + [0.012 * rs.standard_normal(4 * per), 0.03 * rs.standard_normal(4 * per),
+                 1.0 + 0.05 * rs.standard_normal(8192), 0.1 * rs.standard_normal(8192), 0.01 * rs.standard_normal(16384)]
+    flat = np.concatenate(parts).astype(np.float32)
+    flat = flat[: flat.size // 1024 * 1024]
+    bits = synth.f32_to_bf16_bits(flat)
+    n = bits.size
+    src = to_dev(torch, bits)
+    cap = L.lia_pack10_bound(n)
+    enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    out = ctypes.c_size_t()
+    assert L.lia_pack10_encode(ctypes.c_void_p(src.data_ptr()), n, ctypes.c_void_p(enc.data_ptr()), cap, ctypes.byref(out)) == 0
+    bpv = 8.0 * out.value / n
+    assert bpv <= 11.2, f"{kind}: {bpv:.2f} bits per value"
+    back = torch.zeros(n, dtype=torch.int16, device="cuda")
+    N.check(L.lia_pack_decode(ctypes.c_void_p(enc.data_ptr()), ctypes.c_void_p(back.data_ptr()), n, 10, None))
+    torch.cuda.synchronize()
+    assert (back.cpu().numpy().view(np.uint16) == bits).all()
+
+
 def test_blit_and_pinned_pool_round_trip(gpu):
     """lia_blit (kernel copy over mapped pinned memory: the activation hops of the cooperative policies) and the exact-size
     pinned pool behind the host KV caches: device -> pinned -> device round trip, block recycling, argument errors."""
