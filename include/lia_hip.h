@@ -48,7 +48,8 @@ const char* lia_version(void);
 int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out);
 void lia_ctx_destroy(lia_ctx* ctx);
 void* lia_ctx_compute_stream(lia_ctx* ctx); /* hipStream_t created by the context */
-int lia_ctx_synchronize(lia_ctx* ctx);
+int lia_ctx_synchronize(lia_ctx* ctx);          /* compute AND K/V delivery streams */
+int lia_ctx_synchronize_compute(lia_ctx* ctx);  /* the compute stream only (deferred K/V deliveries keep running) */
 int lia_ctx_set_host_threads(lia_ctx* ctx, int n); /* OpenMP threads of the policy-2 host attention */
 
 /* Live kernel timing for the benchmark's roofline report: while enabled, every GEMM main-kernel launch made
@@ -112,6 +113,14 @@ int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int policy, const v
  * the small activation hops of the cooperative policies (modeling_opt.py:320-355 load_activation / store_hidden). */
 int lia_blit(void* dst, const void* src, size_t bytes, void* stream);
 int lia_ctx_kv_store_wait(lia_ctx* ctx); /* host-blocks until every policy-0 K/V delivery has landed */
+/* Deferred form of the policy-0 K/V delivery (store_cache, lia/modeling_opt.py:334-345): the prefill of a streamed layer writes
+ * its K/V rows into a DEVICE holding cache (policy 3 arithmetic, `dev`: on_device = 1, same batch as `host`), and this call
+ * enqueues the copy of rows [0, T) into the host cache behind everything already queued on the compute stream.  The scheduler
+ * issues the deliveries after the prefill's last layer, so the 23 GB of K/V do not share the host link with the weight stream
+ * of the prefill (H2D runs 8 % slower beside them); the first decode step waits per layer with lia_kv_deliver_wait(ticket)
+ * right before that layer's host attention.  row_elems = heads * head_dim. */
+int lia_kv_deliver(lia_ctx* ctx, const lia_kv* dev, lia_kv* host, int T, int row_elems, int* ticket);
+int lia_kv_deliver_wait(lia_ctx* ctx, int ticket);
 
 /* ---- individual sub-layer ops (same kernels the layer call uses; exposed for parity tests) ------ */
 /* F.layer_norm, decoder.py:107-119 */

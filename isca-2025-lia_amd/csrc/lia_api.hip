@@ -79,6 +79,8 @@ struct lia_ctx {
   size_t prof_cap;
   long prof_host_attn_calls;
   double prof_host_attn_ms;
+  std::vector<hipEvent_t>* deliver_events;   // lia_kv_deliver tickets (events on the d2h stream), recycled round-robin
+  std::vector<char>* deliver_pending;
 };
 
 extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out) {
@@ -122,6 +124,11 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
   }
   if (c->ws) (void)hipFree(c->ws);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
+  if (c->deliver_events) {
+    for (hipEvent_t e : *c->deliver_events) (void)hipEventDestroy(e);
+    delete c->deliver_events;
+    delete c->deliver_pending;
+  }
   if (c->prof_events) {
     for (hipEvent_t e : *c->prof_events) (void)hipEventDestroy(e);
     delete c->prof_events;
@@ -138,6 +145,12 @@ extern "C" int lia_ctx_synchronize(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
   HIP_TRY(hipStreamSynchronize(c->compute));
   HIP_TRY(hipStreamSynchronize(c->d2h));
+  return LIA_OK;
+}
+
+extern "C" int lia_ctx_synchronize_compute(lia_ctx* c) {
+  if (!c) return LIA_ERR_INVALID;
+  HIP_TRY(hipStreamSynchronize(c->compute));
   return LIA_OK;
 }
 
@@ -198,6 +211,47 @@ extern "C" int lia_prof_stop(lia_ctx* c, lia_prof_result* out) {
 extern "C" int lia_ctx_kv_store_wait(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
   HIP_TRY(hipStreamSynchronize(c->d2h));
+  return LIA_OK;
+}
+
+extern "C" int lia_kv_deliver(lia_ctx* c, const lia_kv* dev, lia_kv* host, int T, int row_elems, int* ticket) {
+  if (!c || !dev || !host || !ticket) return LIA_ERR_INVALID;
+  if (!dev->k || !dev->v || !host->k || !host->v) { lia_set_error("lia_kv_deliver: NULL cache"); return LIA_ERR_MISSING; }
+  if (!dev->on_device || host->on_device || dev->batch != host->batch || T <= 0 || T > dev->smax || T > host->smax || row_elems <= 0) {
+    lia_set_error("lia_kv_deliver: dev(on_device=%d batch=%d smax=%d) host(on_device=%d batch=%d smax=%d) T=%d", dev->on_device, dev->batch,
+                  dev->smax, host->on_device, host->batch, host->smax, T);
+    return LIA_ERR_INVALID;
+  }
+  if (!c->deliver_events) { c->deliver_events = new std::vector<hipEvent_t>(); c->deliver_pending = new std::vector<char>(); }
+  int id = -1;
+  for (size_t i = 0; i < c->deliver_pending->size(); ++i)
+    if (!(*c->deliver_pending)[i]) { id = (int)i; break; }
+  if (id < 0) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->deliver_events->push_back(e);
+    c->deliver_pending->push_back(0);
+    id = (int)c->deliver_events->size() - 1;
+  }
+  // behind the compute stream's work so far (the layer that filled the holding cache), on the K/V delivery stream
+  HIP_TRY(hipEventRecord((*c->deliver_events)[id], c->compute));
+  HIP_TRY(hipStreamWaitEvent(c->d2h, (*c->deliver_events)[id], 0));
+  // the strided 2-D form even though the rows are contiguous: the runtime serves it with a blit kernel, a linear copy would
+  // queue on the SDMA engine behind the next step's weight copies (see the policy-0 delivery in lia_layer_forward)
+  const size_t width = (size_t)dev->batch * row_elems * 2;
+  HIP_TRY(hipMemcpy2DAsync(host->k, width, dev->k, width, width, T, hipMemcpyDeviceToHost, c->d2h));
+  HIP_TRY(hipMemcpy2DAsync(host->v, width, dev->v, width, width, T, hipMemcpyDeviceToHost, c->d2h));
+  HIP_TRY(hipEventRecord((*c->deliver_events)[id], c->d2h));
+  (*c->deliver_pending)[id] = 1;
+  *ticket = id;
+  return LIA_OK;
+}
+
+extern "C" int lia_kv_deliver_wait(lia_ctx* c, int ticket) {
+  if (!c || !c->deliver_events || ticket < 0 || ticket >= (int)c->deliver_events->size()) { lia_set_error("lia_kv_deliver_wait: ticket %d", ticket); return LIA_ERR_INVALID; }
+  if (!(*c->deliver_pending)[ticket]) return LIA_OK;
+  HIP_TRY(hipEventSynchronize((*c->deliver_events)[ticket]));
+  (*c->deliver_pending)[ticket] = 0;
   return LIA_OK;
 }
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "lia_ctx_destroy": (None, [c_void_p]),
     "lia_ctx_compute_stream": (c_void_p, [c_void_p]),
     "lia_ctx_synchronize": (c_int, [c_void_p]),
+    "lia_ctx_synchronize_compute": (c_int, [c_void_p]),
     "lia_ctx_set_host_threads": (c_int, [c_void_p, c_int]),
     "lia_prof_start": (c_int, [c_void_p, c_int]),
     "lia_prof_stop": (c_int, [c_void_p, ctypes.POINTER(ProfResult)]),
@@ -55,6 +56,8 @@ SIGNATURES = {
     "lia_layer_forward": (c_int, [c_void_p, ctypes.POINTER(LayerDesc), c_int, ctypes.POINTER(c_void_p * 16), c_void_p,
                                   c_void_p, ctypes.POINTER(KV), c_int, c_int, c_int, c_int, c_void_p]),
     "lia_ctx_kv_store_wait": (c_int, [c_void_p]),
+    "lia_kv_deliver": (c_int, [c_void_p, ctypes.POINTER(KV), ctypes.POINTER(KV), c_int, c_int, ctypes.POINTER(c_int)]),
+    "lia_kv_deliver_wait": (c_int, [c_void_p, c_int]),
     "lia_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
     "lia_linear": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int,
                            c_int, c_int, c_int, c_int, c_void_p]),

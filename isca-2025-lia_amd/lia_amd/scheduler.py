@@ -244,6 +244,7 @@ class KVState:
         cooperative split computes on the host cores (scheduler.forward cpu_layers)."""
         sh = model.shape
         self.B, self.smax, self.len = B, smax, 0
+        self.pending = {}          # layer -> ticket of a deferred K/V delivery (scheduler.forward, lia_kv_deliver)
         self.all_on_device = all_on_device
         host_layers = frozenset(host_layers) if all_on_device else frozenset()
         if all_on_device:
@@ -299,6 +300,10 @@ class OffloadScheduler:
         self.resident_ptrs = {}
         self.last_step_ms = {}
         self.host_threads = None    # OpenMP team of the host attention / host layers; default = hostinfo.default_host_threads
+        # policy-0 prefill: keep the fresh K/V of the streamed layers in HBM until the prefill's last layer has run and deliver
+        # them to the host caches then (lia_kv_deliver), instead of beside the prefill's weight stream.  LIA_DEFER_KV=0: deliver at once.
+        self.defer_kv = os.environ.get("LIA_DEFER_KV", "1") != "0"
+        self._kv_hold = None        # ((B, T, first streamed layer), [(k, v, KV struct) per streamed layer])
 
     # -- resources -----------------------------------------------------------------------------------
     def _ensure(self, rows, B, T, n_gpu):
@@ -328,6 +333,36 @@ class OffloadScheduler:
             self.hidden[key] = (torch.empty((B, T, sh.hidden), dtype=torch.bfloat16, device="cuda"),
                                 torch.empty((B, T, sh.hidden), dtype=torch.bfloat16, device="cuda"))
         return self.hidden[key]
+
+    def _hold_caches(self, B, T, n_gpu):
+        """Device holding caches [T, B, h, d] x 2 for every streamed layer (20.7 GB for OPT-30B at B = 64, T = 256), or None when
+        HBM has no room for them (the deliveries then run beside the prefill as in r01)."""
+        sh = self.model.shape
+        key = (B, T, n_gpu)
+        if self._kv_hold is not None and self._kv_hold[0] == key:
+            return self._kv_hold[1]
+        self._kv_hold = None
+        need = 2 * (sh.layers - n_gpu) * T * B * sh.hidden * 2
+        free, _ = torch.cuda.mem_get_info()
+        if need > 0.5 * free:
+            return None
+        out = []
+        for _ in range(n_gpu, sh.layers):
+            k = torch.empty((T, B, sh.heads, sh.head_dim), dtype=torch.bfloat16, device="cuda")
+            v = torch.empty_like(k)
+            out.append((k, v, N.KV(k.data_ptr(), v.data_ptr(), T, B, 1)))
+        self._kv_hold = (key, out)
+        return out
+
+    def _await_kv(self, kv_state, idx=None):
+        """block until the deferred K/V delivery of layer idx (None: of every layer) has reached the host cache"""
+        pend = getattr(kv_state, "pending", None)
+        if not pend:
+            return
+        for i in ([idx] if idx is not None else sorted(pend)):
+            t = pend.pop(i, None)
+            if t is not None:
+                N.check(self.ctx.lib.lia_kv_deliver_wait(self.ctx.handle, t), "lia_kv_deliver_wait")
 
     def _resident(self, idx):
         if idx not in self.resident_ptrs:
@@ -388,7 +423,11 @@ class OffloadScheduler:
                                   sh.hidden, ctypes.c_void_p(ctx.stream)), "lia_embed")
 
         first_streamed = n_gpu
+        hold = None
+        if is_prefill and policy == 0 and n_gpu < L and self.defer_kv and pos0 == 0:
+            hold = self._hold_caches(B, T, n_gpu)
         if policy == 1 and n_gpu < L:
+            self._await_kv(kv_state)
             x = self._host_layers(x, kv_state, n_gpu, B, T, pos0)  # resident prefix on the GPU, the rest on the CPU
             logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
             ctx.synchronize()
@@ -411,6 +450,8 @@ class OffloadScheduler:
                 ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
                 x, y = y, x
                 continue
+            if not is_prefill:
+                self._await_kv(kv_state, idx)                      # a deferred K/V delivery of the prefill: the host cache must be complete
             if idx in host_now:
                 x, y = self._host_decode_layer(idx, x, y, kv_state, B, T, pos0)
                 continue
@@ -433,9 +474,12 @@ class OffloadScheduler:
                 # a host-computed layer keeps its cache on the host: its prefill delivers K/V there (policy 0) even when the
                 # other streamed layers keep theirs in HBM (policy 3)
                 pol = 0 if (policy == 3 and idx in cpu_set) else policy
+                kvl = kv_state.kv[idx]
+                if hold is not None and pol == 0:
+                    pol, kvl = 3, hold[idx - n_gpu][2]             # same arithmetic, rows land in the HBM holding cache
                 for i in range(B // mini):
                     sl = slice(i * mini, (i + 1) * mini)
-                    ctx.layer_forward(m.desc, pol, wptrs, x[sl], y[sl], kv_state.kv[idx], mini, T, pos0, i * mini)
+                    ctx.layer_forward(m.desc, pol, wptrs, x[sl], y[sl], kvl, mini, T, pos0, i * mini)
             else:
                 ctx.layer_forward(m.desc, 2, wptrs, x, y, kv_state.kv[idx], B, T, pos0, 0)   # :1493-1543
             pipe.release(idx)
@@ -444,9 +488,21 @@ class OffloadScheduler:
                 ctx.synchronize()
 
         logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
-        ctx.synchronize()
-        if policy == 0 or (is_prefill and cpu_set):
-            ctx.kv_store_wait()                                    # host cache complete before the next step reads it
+        if hold is not None:
+            # the deferred deliveries, in the order the first decode step will need them; tickets are awaited per layer there
+            kv_state.pending = {}
+            for idx in range(n_gpu, L):
+                if kv_state.kv[idx].on_device:
+                    continue
+                t = ctypes.c_int()
+                N.check(ctx.lib.lia_kv_deliver(ctx.handle, ctypes.byref(hold[idx - n_gpu][2]), ctypes.byref(kv_state.kv[idx]), T,
+                                               sh.hidden, ctypes.byref(t)), "lia_kv_deliver")
+                kv_state.pending[idx] = t.value
+            N.check(ctx.lib.lia_ctx_synchronize_compute(ctx.handle), "lia_ctx_synchronize_compute")
+        else:
+            ctx.synchronize()
+            if policy == 0 or (is_prefill and cpu_set):
+                ctx.kv_store_wait()                                # host cache complete before the next step reads it
         kv_state.len = pos0 + T
         return logits, nxt
 

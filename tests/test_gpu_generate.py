@@ -99,6 +99,24 @@ def test_generate_ids_match_hf_golden(name, flags, fmt, monkeypatch):
     model.close()
 
 
+@pytest.mark.parametrize("name", GEN_CASES)
+def test_generate_with_immediate_kv_delivery(name, monkeypatch):
+    """LIA_DEFER_KV=0: the policy-0 prefill delivers each layer's K/V to the host cache at once (r01's order, and what happens
+    when HBM has no room for the holding caches) instead of after the prefill's last layer (the default, exercised by every
+    other 0/2 case here)."""
+    import torch
+    from lia_amd.generation import generate
+    monkeypatch.setenv("LIA_DEFER_KV", "0")
+    z, m, ids, c = _load(name)
+    model = _model(m, c)
+    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], prefill_policy=0, decoding_policy=2,
+                   gpu_percentage=25, pin_weight=True, num_minibatch=2 if c["B"] % 2 == 0 else 1)
+    assert model._lia_scheduler.defer_kv is False and model._lia_scheduler._kv_hold is None
+    assert (out.numpy() == z["ids_bf16"]).all()
+    model._lia_scheduler.close()
+    model.close()
+
+
 @pytest.mark.parametrize("fmt", ["pack11", "pack12"])
 def test_generate_older_wire_formats(fmt, monkeypatch):
     """pack11 / pack12 (the first two generations of the wire format, kept selectable): one end-to-end case each"""
