@@ -313,7 +313,9 @@ static WsLayout ws_layout(const lia_layer_desc* d, long rows, long slab_rows) {
   w.f1 = take(R * F * 2);
   w.slab[0] = take(2 * (size_t)slab_rows * H * 2);
   w.slab[1] = take(2 * (size_t)slab_rows * H * 2);
-  w.gemm_bytes = rows <= 256 ? (size_t)8 * R * std::max(3 * H, F) * 4 : 0;
+  // split-K slabs of the skinny regime (M <= 256).  Reserved for larger calls too, so that the size is monotonic in `rows`: a
+  // context sized for a 292-row call must also serve a 256-row one (r01 sized 16 MB for 292 rows and then needed 82 MB for 256)
+  w.gemm_bytes = (size_t)8 * std::min(R, (size_t)256) * std::max(3 * H, F) * 4;
   w.gemm = take(w.gemm_bytes);
   w.total = p;
   return w;
@@ -682,7 +684,7 @@ static LlamaWs llama_ws(const lia_llama_desc* d, long rows) {
   auto take = [&](size_t bytes) { size_t o = p; p = align_up(p + bytes, 256); return o; };
   w.ln = take(R * H * 2); w.q = take(R * H * 2); w.attn = take(R * H * 2); w.h1 = take(R * H * 2);
   w.gu = take(R * 2 * F * 2); w.act = take(R * F * 2);
-  w.gemm_bytes = rows <= 256 ? (size_t)8 * R * 2 * F * 4 : 0;
+  w.gemm_bytes = (size_t)8 * std::min(R, (size_t)256) * 2 * F * 4;   // monotonic in rows, see ws_layout
   w.gemm = take(w.gemm_bytes);
   w.total = p;
   return w;

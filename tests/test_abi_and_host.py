@@ -71,6 +71,10 @@ def test_pack_offsets_layout(native):
     with pytest.raises(ValueError):
         ops.pack_offsets(ops.make_desc(250, 5, 1024))
     assert ops.workspace_bytes(d, 64) > 0
+    # the workspace size is monotonic in the row count: a context sized for the largest call of a forward (e.g. 292 rows of a
+    # policy-0 decode slab) must also serve its smaller calls (a 256-row prefill wants split-K slabs, r01 did not reserve them)
+    sizes = [ops.workspace_bytes(ops.make_desc(2048, 32, 8192), r) for r in (1, 64, 255, 256, 257, 292, 1024, 16384)]
+    assert sizes == sorted(sizes) and len(set(sizes)) == len(sizes)
 
 
 @pytest.mark.parametrize("B,T,pos0,heads,d", [(2, 1, 8, 4, 32), (3, 1, 33, 4, 64), (2, 1, 40, 4, 128), (2, 5, 0, 8, 64),
