@@ -49,11 +49,76 @@ __global__ __launch_bounds__(256) void lia_layernorm_kernel(const bf16_t* __rest
   }
 }
 
+// The same arithmetic (same per-lane summation order: bit-identical results) with the row held in registers: every lane
+// requests its NV 16-byte pieces at once and the row crosses the memory system ONCE.  The three-pass kernel above issues
+// 3 x NV dependent round trips per lane: 13 us for 64 decode rows (latency), 2.7 TB/s at 16384 prefill rows.
+template <int NV>
+__global__ __launch_bounds__(256) void lia_layernorm_reg_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                 const bf16_t* __restrict__ g, const bf16_t* __restrict__ b,
+                                                                 bf16_t* __restrict__ y, long ldy, long rows, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  const int nv = H >> 3;
+  uint4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = lane + 64 * k;
+    v[k] = i < nv ? *(const uint4*)(xr + 8 * i) : uint4{0u, 0u, 0u, 0u};
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (lane + 64 * k < nv) {
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += bf2f(w[j] & 0xffff) + bf2f(w[j] >> 16);
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (lane + 64 * k < nv) {
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = bf2f(w[j] & 0xffff) - mean, c = bf2f(w[j] >> 16) - mean;
+        q += a * a + c * c;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+  bf16_t* yr = y + row * ldy;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < nv) {
+      const uint4 gv = *(const uint4*)(g + 8 * i), bv = *(const uint4*)(b + 8 * i);
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv.x, gv.y, gv.z, gv.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = (bf2f(w[j] & 0xffff) - mean) * rstd * bf2f(gw[j] & 0xffff) + bf2f(bw[j] & 0xffff);
+        float hi = (bf2f(w[j] >> 16) - mean) * rstd * bf2f(gw[j] >> 16) + bf2f(bw[j] >> 16);
+        o[j] = pack_bf16x2(lo, hi);
+      }
+      *(uint4*)(yr + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(lia_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, g, b, y, ldy, rows,
-                     H, eps);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const int nvl = ((H >> 3) + 63) / 64;            // 16-byte pieces per lane
+  if (nvl <= 4) hipLaunchKernelGGL(lia_layernorm_reg_kernel<4>, grid, block, 0, st, x, ldx, g, b, y, ldy, rows, H, eps);          // H <= 2048
+  else if (nvl <= 8) hipLaunchKernelGGL(lia_layernorm_reg_kernel<8>, grid, block, 0, st, x, ldx, g, b, y, ldy, rows, H, eps);     // H <= 4096
+  else if (nvl <= 14) hipLaunchKernelGGL(lia_layernorm_reg_kernel<14>, grid, block, 0, st, x, ldx, g, b, y, ldy, rows, H, eps);   // H <= 7168 (OPT-30B)
+  else if (nvl <= 24) hipLaunchKernelGGL(lia_layernorm_reg_kernel<24>, grid, block, 0, st, x, ldx, g, b, y, ldy, rows, H, eps);   // H <= 12288 (OPT-175B)
+  else hipLaunchKernelGGL(lia_layernorm_kernel, grid, block, 0, st, x, ldx, g, b, y, ldy, rows, H, eps);
 }
 
 // hidden = embed_tokens[ids] + embed_positions[past_len + t + 2], one bf16 add
