@@ -15,7 +15,7 @@
 // kernels' host launchers
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime);
+                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime);
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st);
 extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* y, int B, int T,
@@ -79,6 +79,7 @@ struct lia_ctx {
   size_t prof_cap;
   long prof_host_attn_calls;
   double prof_host_attn_ms;
+  unsigned* gemm_tickets;    // 16384 zeroed split-K tile tickets (lia_gemm.hip: the in-launch combine re-arms them)
   std::vector<hipEvent_t>* deliver_events;   // lia_kv_deliver tickets (events on the d2h stream), recycled round-robin
   std::vector<char>* deliver_pending;
 };
@@ -109,6 +110,8 @@ extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out)
   }
   c->ws_bytes = workspace_bytes;
   if (workspace_bytes) HIP_TRY(hipMalloc((void**)&c->ws, workspace_bytes));
+  HIP_TRY(hipMalloc((void**)&c->gemm_tickets, 16384 * sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->gemm_tickets, 0, 16384 * sizeof(unsigned)));
   *out = c;
   return LIA_OK;
 }
@@ -123,6 +126,7 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
     (void)hipEventDestroy(c->slab_done[i]);
   }
   if (c->ws) (void)hipFree(c->ws);
+  if (c->gemm_tickets) (void)hipFree(c->gemm_tickets);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->deliver_events) {
     for (hipEvent_t e : *c->deliver_events) (void)hipEventDestroy(e);
@@ -362,7 +366,7 @@ static int gemm_checked(lia_ctx* ctx, const bf16_t* x, long ldx, const bf16_t* w
     e0 = (*ctx->prof_events)[2 * i];
     e1 = (*ctx->prof_events)[2 * i + 1];
   }
-  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, split, st, e0, e1, &regime);
+  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, ctx ? ctx->gemm_tickets : nullptr, split, st, e0, e1, &regime);
   if (timed && rc == 0 && regime != 0) {
     // algorithmic traffic of the op: the weight once, the activations in and out once
     double bytes = 2.0 * ((double)N * K + (double)M * K + (double)M * N);

@@ -15,6 +15,7 @@
 //     (global_load_lds, 16 B/lane) with the XOR swizzle applied on the SOURCE address
 //     (cdna_hip_programming.md rule 21), double-buffered, XCD-aware tile order.
 #include <cstdio>
+#include <cstring>
 #include "lia_common.h"
 
 #define GL_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -177,6 +178,7 @@ __device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char
 // at 4.2 TB/s.
 // ---------------------------------------------------------------------------------------------
 constexpr int S2_BK = 64;     // K per chunk: 128-byte rows
+constexpr int LIA_GEMM_MAX_TICKETS = 16384;   // split-K tile tickets a context provides (N / 128 tiles x up to 16 row blocks)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,8 +204,8 @@ template <int MT, int S, int NT, int WAVES, int RT = 1>
 __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                        const bf16_t* __restrict__ W, long ldw, int M, int N,
                                                                        int K, int chunks_per_split,
-                                                                       float* __restrict__ partial, LiaEpilogue ep,
-                                                                       LiaOutMap om) {
+                                                                       float* __restrict__ partial, unsigned* __restrict__ tickets,
+                                                                       LiaEpilogue ep, LiaOutMap om) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 16 * WAVES * RT;               // W rows per workgroup (RT MFMA row tiles of 16 per wave)
   constexpr int RR = 8 * WAVES;                     // rows one LDS-DMA round of the workgroup covers (128 B each)
@@ -314,6 +316,42 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
         if (m < M) store_quad(acc[t][p], m, nn, ep, om);
       }
     }
+  }
+  if (partial == nullptr || tickets == nullptr) return;
+  // ---- in-launch split-K combine: the slice that arrives LAST at this tile's ticket adds the slabs (slice 0, 1, ... in that
+  // order, as lia_splitk_reduce_kernel does: same bits) and applies the epilogue; no second kernel, no launch boundary.
+  // Publication is the agent-scope hand-off of cdna_hip_programming.md ("In-launch split-K reduction"): every storing wave
+  // drains its stores, the workgroup meets, ONE lane releases (fence + the explicit vmcnt wait ROCm 7.2 may drop) and takes a
+  // ticket; the last arriver acquires once, the workgroup meets again, then plain loads.  Correct for any placement of a
+  // tile's slices over CUs / XCDs.  The last arriver also re-arms the ticket for the next launch.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* const flag = (int*)smem;                      // the staging ring is dead now; one LDS object only (no second __shared__)
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned* tk = tickets + (blockIdx.z * gridDim.x + blockIdx.x);
+    const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == gridDim.y - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  const int S_ = gridDim.y;
+  constexpr int QN = BN / 4;                         // quads per tile row
+  const int rows_here = min(XR, Mloc);
+  for (int q = tid; q < rows_here * QN; q += 64 * WAVES) {
+    const int m = m_base + q / QN;
+    const int n = n_tile + (q % QN) * 4;
+    if (n >= N) continue;
+    f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
+    for (int s_ = 1; s_ < S_; ++s_) a += *(const f32x4*)(partial + ((long)s_ * M + m) * N + n);
+    store_quad(a, m, n, ep, om);
   }
 }
 
@@ -941,7 +979,7 @@ extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
 
 template <int MT, int S, int NT, int WAVES, int RT = 1>
 static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K, int split, int cps,
-                           float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
+                           float* partial, unsigned* tickets, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
   constexpr int BN = 16 * WAVES * RT, RR = 8 * WAVES;
   constexpr int XL = (16 * MT + RR - 1) / RR;
   dim3 grid((N + BN - 1) / BN, split, (M + 16 * MT - 1) / (16 * MT));
@@ -952,7 +990,7 @@ static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw,
     attr_set = true;
   }
   hipLaunchKernelGGL((lia_gemm_skinny2_kernel<MT, S, NT, WAVES, RT>), grid, dim3(64 * WAVES), lds, st, x, ldx, W, ldw, M, N, K, cps,
-                     split > 1 ? partial : nullptr, ep, om);
+                     split > 1 ? partial : nullptr, tickets, ep, om);
 }
 
 // experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row,
@@ -961,9 +999,11 @@ static int g_skinny_variant = 0;
 extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
 
 // Returns 0 on success, -1 on unsupported shape.  workspace is only touched when split-K is chosen.
+// tickets: LIA_GEMM_MAX_TICKETS zero-initialised counters owned by the caller's context (one per output tile of a split-K
+// launch; the kernel leaves them zero again).  NULL: the slabs are combined by a second kernel as in r01.
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime) {
+                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime) {
   // ev0/ev1 (nullable): recorded on `st` immediately around the MAIN kernel launch only (bench.py's live
   // roofline timing; the split-K combine kernel is outside the bracket).  *regime: 1 skinny, 2 tiled.
   if (regime) *regime = 0;
@@ -1018,20 +1058,28 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     int cps = (nchunks + split - 1) / split;
     split = (nchunks + cps - 1) / cps;
     if (regime) *regime = 1;
+    // How the split-K slabs are combined.  Default: the small second kernel.  LIA_GEMM_SPLITK=inlaunch: by the last-arriving
+    // slice inside the launch (bit-identical, tools/splitk_ab.py) -- measured on MI355X it is SLOWER at these sizes: a tile's
+    // slabs are 3-8 x 64 KB, the last arriver reads them alone while its CU's neighbours still stream, and every slice pays an
+    // agent-scope release (L2 write-back): OPT-30B M = 64 qkv 58 -> 78 us, fc2 77 -> 104 us, Llama-3-8B M = 128 qkv 23 -> 38 us
+    // (the two-kernel figures include the 5 us combine kernel).  cdna_hip_programming.md says as much: in-launch pays only
+    // when split x slab bytes per tile is a few tens of KB.
+    static const bool in_launch = [] { const char* e = getenv("LIA_GEMM_SPLITK"); return e && !strcmp(e, "inlaunch"); }();
+    unsigned* tk = (split > 1 && tickets && in_launch && (long)((N + 127) / 128) * 16 <= LIA_GEMM_MAX_TICKETS) ? tickets : nullptr;
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-    else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
+    else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     else if (M <= 64) {
-      if (rt == 2) launch_skinny2<4, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-      else launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+      if (rt == 2) launch_skinny2<4, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
+      else launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     } else if (M <= 128) {
-      if (rt == 2) launch_skinny2<8, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
-      else if (mcut) launch_skinny2<4, 3, 0, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);   // default cache policy: the other x block re-reads W
-      else launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+      if (rt == 2) launch_skinny2<8, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
+      else if (mcut) launch_skinny2<4, 3, 0, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);   // default cache policy: the other x block re-reads W
+      else launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     }
-    else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     if (ev1) (void)hipEventRecord(ev1, st);
-    if (split > 1) {
+    if (split > 1 && tk == nullptr) {
       long nq = (long)M * (N / 4);
       hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace,
                          split, M, N, *ep, *om);
