@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/results_round.sh <tag>: every configuration of BASELINE.md section 4 through bench.py on the GPU box, one JSON line each
+# under gpurun_out/results_<tag>/ (copy into results/ to keep them).
+set -u
+tag=${1:-r02}
+cd "${GRAFT_REPO_ROOT:-.}"
+out=gpurun_out/results_$tag
+mkdir -p "$out"
+run() { name=$1; shift; echo "== $name: bench.py $*"; timeout 1500 python3 bench.py "$@" > "$out/$name.log" 2>&1; tail -1 "$out/$name.log" > "$out/$name.json"; cut -c1-220 "$out/$name.json"; echo; }
+run opt30b_gpu10_p0p2_pack10
+run opt30b_gpu10_p0p2_mb2_pack10 --num-minibatch 2 --no-raw-leg --no-cpu-baseline
+run opt30b_gpu10_p3p3_pack10 --prefill-policy 3 --decoding-policy 3 --no-raw-leg --no-cpu-baseline
+run opt30b_gpu100_resident --gpu-percentage 100 --no-raw-leg --no-cpu-baseline
+run opt30b_gpu10_p0p2_pack10_cpu19 --cpu-layers 19 --no-raw-leg --no-cpu-baseline
+run opt30b_gpu10_p3p3_pack10_cpu20 --prefill-policy 3 --decoding-policy 3 --cpu-layers 20 --no-raw-leg --no-cpu-baseline
+run llama3_8b_gpu100_b128_t1024_n128 --model llama-3-8b --gpu-percentage 100 --batch 128 --prompt 1024 --steps 127
+run opt66b_gpu5_cxl_pack10 --model opt-66b --gpu-percentage 5 --enable-cxl --cxl-nodes 0,1 --batch 32 --no-raw-leg --no-cpu-baseline
+run opt175b_gpu5_cxl_pack10_uniform01 --model opt-175b --gpu-percentage 5 --enable-cxl --cxl-nodes 0,1 --batch 32 --init uniform01 --no-raw-leg --no-cpu-baseline
