@@ -169,10 +169,11 @@ def cpu_oracle_sample(shape, B, T, threads):
 
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
-    (profiles/r*_bench_opt30b_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).
+    (profiles/r02_opt30b_bench_pmc_hbm.json, tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).
     PMC collection cannot run inside the timed benchmark, so the live line carries the committed measurement and names it."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_opt30b_pmc_hbm.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_opt30b_pmc_hbm.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_opt30b_bench_pmc_hbm.json")), key=os.path.basename)
     if not files:
         return None, None
     try:
