@@ -426,13 +426,18 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   const float qscale = post_scale ? 1.0f : scaling;
   const int sub = tid % LPK, kslot = tid / LPK;
 
-  float qs[G][8];
+  // the (scaled, bf16-rounded) query slice of each head of the group as packed bf16 pairs: q . k runs on v_dot2c_f32_bf16,
+  // two products per instruction and no unpacking of the key (the products of two bf16 are exact in fp32 either way; the
+  // sum is rounded to bf16 right after): Llama-3-8B's grouped decode attention 119.6 -> 114.5 us per layer.  (Requesting
+  // the next pass's rows before multiplying this pass's was tried too: 122 us -- four workgroups per CU already overlap.)
+  typedef __attribute__((ext_vector_type(2))) __bf16 lia_bf16x2;
+  uint32_t qp[G][4];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     uint4 v = *(const uint4*)(q + (long)b * ldq + (long)(kh * G + g) * D + 8 * sub);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { qs[g][2 * j] = rbf(bf2f(w[j] & 0xffff) * qscale); qs[g][2 * j + 1] = rbf(bf2f(w[j] >> 16) * qscale); }
+    for (int j = 0; j < 4; ++j) qp[g][j] = pack_bf16x2(bf2f(w[j] & 0xffff) * qscale, bf2f(w[j] >> 16) * qscale);
   }
   float lmax[G];
 #pragma unroll
@@ -453,7 +458,8 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
       for (int g = 0; g < G; ++g) {
         float a = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a += qs[g][2 * e] * bf2f(w[e] & 0xffff) + qs[g][2 * e + 1] * bf2f(w[e] >> 16);
+        for (int e = 0; e < 4; ++e)
+          a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lia_bf16x2, qp[g][e]), __builtin_bit_cast(lia_bf16x2, w[e]), a, false);
 #pragma unroll
         for (int o = LPK / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
         if (j < S) {
