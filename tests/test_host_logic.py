@@ -86,3 +86,75 @@ def test_rank_core_slices_do_not_overlap():
             assert not (seen[0] & seen[1])
     finally:
         os.sched_setaffinity(0, before)
+
+
+class _FakeScheduler:
+    """stands in for OffloadScheduler / LlamaScheduler in the greedy loop: next id = (last id + 1) mod vocab, EOS at a chosen step"""
+
+    def __init__(self, vocab, eos_at=None):
+        self.vocab, self.eos_at, self.calls, self.kw = vocab, eos_at, [], None
+
+    def forward(self, ids, kv, max_new_tokens=None, suppress_token=-1, **lia):
+        import torch
+        self.calls.append((tuple(ids.shape), suppress_token))
+        self.kw = lia
+        nxt = (ids[:, -1] + 1) % self.vocab
+        if self.eos_at is not None and len(self.calls) == self.eos_at and suppress_token < 0:
+            nxt = torch.full_like(nxt, 2)
+        return torch.zeros((ids.shape[0], self.vocab)), nxt
+
+
+def _fake_model(sched, layers=4, max_pos=64):
+    import types
+    shape = types.SimpleNamespace(layers=layers, max_pos=max_pos, hidden=8, heads=2, head_dim=4)
+    m = types.SimpleNamespace(shape=shape, family="llama", _lia_scheduler=sched)      # "llama": a KV state without host allocations
+    return m
+
+
+def test_greedy_loop_protocol_hooks_and_eos(monkeypatch):
+    """generate(): latency_list has one entry per greedy iteration ([0] = the prefill), min_new_tokens suppresses EOS, the LIA
+    kwargs reach forward() with the reference's defaults, step_hook(i) runs before iteration i and max_steps ends the loop
+    early (what bench.py's bracket and warm-up are built on)."""
+    import torch
+    from lia_amd import generation, llama
+    monkeypatch.setattr(llama, "LlamaKVState", lambda model, B, smax: object())
+    ids = torch.tensor([[2, 5, 7], [2, 5, 7]])
+    s = _FakeScheduler(50)
+    seen = []
+    out, lat = generation.generate(_fake_model(s), ids, max_new_tokens=6, min_new_tokens=6, token_latency=True, step_hook=seen.append,
+                                   prefill_policy=0, decoding_policy=2, gpu_percentage=10, pin_weight=True)
+    assert out.shape == (2, 9) and out[0].tolist() == [2, 5, 7, 8, 9, 10, 11, 12, 13] and len(lat) == 6 and seen == [0, 1, 2, 3, 4, 5]
+    assert s.calls[0][0] == (2, 3) and all(c[0] == (2, 1) for c in s.calls[1:])            # prefill, then one token per step
+    assert all(c[1] == 2 for c in s.calls)                                                   # EOS suppressed while min_new_tokens is unmet
+    assert s.kw == dict(prefill_policy=0, decoding_policy=2, no_overlap=False, pin_weight=True, gpu_percentage=10, num_minibatch=1, enable_cxl=False)
+    s = _FakeScheduler(50)
+    out = generation.generate(_fake_model(s), ids, max_new_tokens=6, max_steps=3)
+    assert out.shape == (2, 6) and len(s.calls) == 3
+    assert s.kw["prefill_policy"] == 1 and s.kw["decoding_policy"] == 1 and s.kw["gpu_percentage"] == 0      # run.py defaults (IPEX baseline)
+    s = _FakeScheduler(50, eos_at=2)                                                         # EOS at the second iteration ends the batch
+    out = generation.generate(_fake_model(s), ids, max_new_tokens=6)
+    assert out.shape == (2, 5) and out[0, -1] == 2
+    with pytest.raises(ValueError):
+        generation.generate(_fake_model(s), ids, max_new_tokens=6, num_beams=2)
+    with pytest.raises(ValueError):
+        generation.generate(_fake_model(s, max_pos=8), ids, max_new_tokens=6)
+
+
+def test_planner_gpu_share_cap_and_model_shape_of_a_packed_directory(tmp_path):
+    import json
+    from lia_amd import packed_checkpoint as pc, planner, run_generation
+    from lia_amd.model import resolve_shape
+    shape = resolve_shape("opt-30b")
+    box = planner.Box(host_threads=16, host_mem_gb=300.0)
+    free = planner.plan(shape, 64, 256, 32, box)
+    capped = planner.plan(shape, 64, 256, 32, box, max_gpu_percentage=10)
+    assert free.gpu_percentage == 100 and capped.gpu_percentage <= 10 and capped.decode_tokens_per_s < free.decode_tokens_per_s
+    d = tmp_path / "m"
+    d.mkdir()
+    assert not pc.is_packed_dir(str(d))
+    json.dump({"format": pc.FORMAT, "family": "opt", "shape": {"name": "x", "hidden": 512, "heads": 4, "ffn": 2048, "layers": 3, "vocab": 100,
+                                                                 "max_pos": 32}, "layers": []}, open(d / pc.MANIFEST, "w"))
+    assert pc.is_packed_dir(str(d))
+    args = run_generation.build_parser().parse_args(["-m", str(d)])
+    sh = run_generation.model_shape(args)
+    assert (sh.hidden, sh.heads, sh.ffn, sh.layers, sh.vocab, sh.max_pos) == (512, 4, 2048, 3, 100, 32)
