@@ -228,8 +228,12 @@ extern "C" int lia_kv_deliver(lia_ctx* c, const lia_kv* dev, lia_kv* host, int T
   }
   if (!c->deliver_events) { c->deliver_events = new std::vector<hipEvent_t>(); c->deliver_pending = new std::vector<char>(); }
   int id = -1;
-  for (size_t i = 0; i < c->deliver_pending->size(); ++i)
+  for (size_t i = 0; i < c->deliver_pending->size(); ++i) {
+    // a ticket nobody waited for (a generation that ended with its prefill) is free again once its copy has completed
+    if ((*c->deliver_pending)[i] && hipEventQuery((*c->deliver_events)[i]) == hipSuccess) (*c->deliver_pending)[i] = 0;
     if (!(*c->deliver_pending)[i]) { id = (int)i; break; }
+  }
+  (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is an answer, not an error to report later
   if (id < 0) {
     hipEvent_t e;
     HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
