@@ -61,6 +61,9 @@ typedef struct {
   long host_attention_calls; double host_attention_ms; /* policy-2 host attention (wall clock of lia_host_attention inside lia_layer_forward) */
 } lia_prof_result;
 int lia_prof_start(lia_ctx* ctx, int max_launches);
+/* Bracket every stride-th GEMM launch only (default 1).  An event pair on the compute stream costs two ~6 us idle gaps, which is
+ * the whole step's slack in the all-resident configurations; a stride co-prime to the launches per step samples every shape. */
+int lia_prof_set_stride(lia_ctx* ctx, int stride);
 int lia_prof_stop(lia_ctx* ctx, lia_prof_result* out); /* synchronises the compute stream */
 
 /* ---- layer description and the 16-tensor weight set --------------------------------------------

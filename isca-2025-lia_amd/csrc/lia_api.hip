@@ -77,6 +77,8 @@ struct lia_ctx {
   struct ProfRec { int regime; double bytes, flops; };
   std::vector<ProfRec>* prof_recs;
   size_t prof_cap;
+  int prof_stride;      // every prof_stride-th GEMM launch is bracketed (an event pair costs ~2 x 6 us of stream idle)
+  long prof_seen;
   long prof_host_attn_calls;
   double prof_host_attn_ms;
   unsigned* gemm_tickets;    // 16384 zeroed split-K tile tickets (lia_gemm.hip: the in-launch combine re-arms them)
@@ -176,7 +178,15 @@ extern "C" int lia_prof_start(lia_ctx* c, int max_launches) {
   c->prof_host_attn_calls = 0;
   c->prof_host_attn_ms = 0.0;
   c->prof_cap = max_launches;
+  c->prof_seen = 0;
+  if (c->prof_stride < 1) c->prof_stride = 1;
   c->prof_on = true;
+  return LIA_OK;
+}
+
+extern "C" int lia_prof_set_stride(lia_ctx* c, int stride) {
+  if (!c || stride < 1) return LIA_ERR_INVALID;
+  c->prof_stride = stride;
   return LIA_OK;
 }
 
@@ -364,7 +374,7 @@ static int gemm_checked(lia_ctx* ctx, const bf16_t* x, long ldx, const bf16_t* w
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int regime = 0;
-  const bool timed = ctx && ctx->prof_on && ctx->prof_recs->size() < ctx->prof_cap;
+  const bool timed = ctx && ctx->prof_on && ctx->prof_recs->size() < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
   if (timed) {
     size_t i = ctx->prof_recs->size();
     e0 = (*ctx->prof_events)[2 * i];

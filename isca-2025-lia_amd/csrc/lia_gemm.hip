@@ -200,6 +200,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "add the immediate");
 }
 
+#ifdef LIA_GEMM_STAMPS
+__device__ unsigned long long g_s2_stamps[8192 * 8];   // per workgroup: start, first chunk landed, after the K loop, stores issued, stores drained
+#define S2_STAMP(i) do { if (threadIdx.x == 0) { const unsigned g_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (g_ < 8192) g_s2_stamps[g_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define S2_STAMP(i) do { } while (0)
+#endif
+
 template <int MT, int S, int NT, int WAVES, int RT = 1>
 __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                        const bf16_t* __restrict__ W, long ldw, int M, int N,
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
   const int c_begin = blockIdx.y * chunks_per_split;
   const int c_end = min(nchunks, c_begin + chunks_per_split);
   const int n = c_end - c_begin;
+  S2_STAMP(0);
 
   // per-thread source rows (clamped: out-of-range rows re-read a valid one and are never stored)
   const int srow = tid >> 3, sc = tid & 7;
@@ -273,6 +281,9 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
       else if (S > 4 && behind == S - 4) wait_vmcnt<(S > 4 ? (S - 4) : 0) * NL>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
+#ifdef LIA_GEMM_STAMPS
+      if (i == 0) S2_STAMP(1);
+#endif
       if (i + S - 1 < n) issue(c_begin + i + S - 1, (i + S - 1) % S);
       const char* wt = smem + (i % S) * STAGE;
       const char* xt = wt + WTILE;
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
   }
   // keep the last MFMA well clear of the accumulator reads below (see the note in v1)
   __builtin_amdgcn_s_barrier();
+  S2_STAMP(2);
 
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
@@ -317,6 +329,11 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
       }
     }
   }
+#ifdef LIA_GEMM_STAMPS
+  S2_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  S2_STAMP(4);
+#endif
   if (partial == nullptr || tickets == nullptr) return;
   // ---- in-launch split-K combine: the slice that arrives LAST at this tile's ticket adds the slabs (slice 0, 1, ... in that
   // order, as lia_splitk_reduce_kernel does: same bits) and applies the epilogue; no second kernel, no launch boundary.

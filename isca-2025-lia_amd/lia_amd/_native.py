@@ -50,6 +50,7 @@ SIGNATURES = {
     "lia_ctx_synchronize_compute": (c_int, [c_void_p]),
     "lia_ctx_set_host_threads": (c_int, [c_void_p, c_int]),
     "lia_prof_start": (c_int, [c_void_p, c_int]),
+    "lia_prof_set_stride": (c_int, [c_void_p, c_int]),
     "lia_prof_stop": (c_int, [c_void_p, ctypes.POINTER(ProfResult)]),
     "lia_layer_pack_offsets": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_size_t * 16), ctypes.POINTER(c_size_t)]),
     "lia_layer_workspace_bytes": (c_size_t, [ctypes.POINTER(LayerDesc), c_int]),

@@ -59,7 +59,9 @@ class Context:
     def set_host_threads(self, n):
         N.check(self.lib.lia_ctx_set_host_threads(self.handle, n))
 
-    def prof_start(self, max_launches=16384):
+    def prof_start(self, max_launches=16384, stride=1):
+        """HIP-event brackets around every stride-th GEMM launch from here on (lia_prof_start / lia_prof_set_stride)."""
+        N.check(self.lib.lia_prof_set_stride(self.handle, stride), "lia_prof_set_stride")
         N.check(self.lib.lia_prof_start(self.handle, max_launches), "lia_prof_start")
 
     def prof_stop(self):

@@ -46,6 +46,35 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
 #ifdef LIA_GEMM_STAMPS
+  if (getenv("S2STAMPS")) {
+    // skinny kernel: where a workgroup's time goes (100 MHz ticks): start -> first chunk landed -> K loop done -> stores issued -> drained
+    void* sp; CK(hipGetSymbolAddress(&sp, HIP_SYMBOL(g_s2_stamps)));
+    for (auto& sh : shapes) {
+      if (!strcmp(sh.name, "dummy")) continue;
+      LiaEpilogue ep{bias, res, sh.N, 0};
+      LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemsetAsync(sp, 0, 8192 * 8 * 8, st));
+        lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, e0, e1, nullptr);
+      }
+      CK(hipStreamSynchronize(st));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      std::vector<unsigned long long> h(8192 * 8);
+      CK(hipMemcpy(h.data(), sp, h.size() * 8, hipMemcpyDeviceToHost));
+      int nwg = 0; unsigned long long first = ~0ull, last = 0, last_start = 0, first_end = ~0ull;
+      double d01 = 0, d12 = 0, d23 = 0, d34 = 0;
+      for (int g = 0; g < 8192; ++g) {
+        const unsigned long long* q = h.data() + 8 * g;
+        if (!q[0]) continue;
+        ++nwg; first = std::min(first, q[0]); last = std::max(last, q[4]); last_start = std::max(last_start, q[0]); first_end = std::min(first_end, q[4]);
+        d01 += (double)(q[1] - q[0]); d12 += (double)(q[2] - q[1]); d23 += (double)(q[3] - q[2]); d34 += (double)(q[4] - q[3]);
+      }
+      printf("%-8s M=%d N=%d K=%d: event bracket %.1f us; %d workgroups, span %.2f us (starts spread over %.2f us, first end at %.2f us); per workgroup: "
+             "first chunk %.2f us, K loop %.2f us, stores issued %.2f us, drain %.2f us\n", sh.name, M, sh.N, sh.K, ms * 1e3, nwg, (last - first) * 0.01,
+             (last_start - first) * 0.01, (first_end - first) * 0.01, d01 * 0.01 / nwg, d12 * 0.01 / nwg, d23 * 0.01 / nwg, d34 * 0.01 / nwg);
+    }
+    return 0;
+  }
   if (getenv("T4STAMPS")) {
     // phased kernel (variant 262): where a workgroup's time goes -- prologue / K loop / epilogue, and the gap to the next
     // workgroup on the same CU slot (start-to-start minus the three), averaged over the workgroups of one launch
