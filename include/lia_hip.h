@@ -51,6 +51,13 @@ void* lia_ctx_compute_stream(lia_ctx* ctx); /* hipStream_t created by the contex
 int lia_ctx_synchronize(lia_ctx* ctx);          /* compute AND K/V delivery streams */
 int lia_ctx_synchronize_compute(lia_ctx* ctx);  /* the compute stream only (deferred K/V deliveries keep running) */
 int lia_ctx_set_host_threads(lia_ctx* ctx, int n); /* OpenMP threads of the policy-2 host attention */
+/* Cross-layer chaining for decode (build-defined; the reference launches every LayerNorm as its own kernel, decoder.py:199-206).
+ * One-shot promise about the NEXT lia_layer_forward / lia_llama_layer_forward call on this context: its output y will be the
+ * input x of the call after it, unchanged, and that layer's first norm has weights g (and b; NULL for RMSNorm).  The layer then
+ * normalises y inside the split-K combine of its last GEMM, and the following call (same x pointer, rows and width; anything
+ * else falls back to the stand-alone norm kernel) skips its first norm.  g / b must be readable on the compute stream when the
+ * hinted call is issued: chain resident layers, not a streamed layer whose copy may still be in flight. */
+int lia_ctx_chain_next_norm(lia_ctx* ctx, const lia_bf16* g, const lia_bf16* b);
 
 /* Live kernel timing for the benchmark's roofline report: while enabled, every GEMM main-kernel launch made
  * through this context is bracketed by HIP events on the stream it is launched on. */

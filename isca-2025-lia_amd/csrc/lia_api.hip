@@ -15,7 +15,8 @@
 // kernels' host launchers
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime);
+                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime,
+                               const LiaPost* post, int* post_done);
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st);
 extern "C" void lia_embed_launch(const int64_t* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* y, int B, int T,
@@ -84,7 +85,23 @@ struct lia_ctx {
   unsigned* gemm_tickets;    // 16384 zeroed split-K tile tickets (lia_gemm.hip: the in-launch combine re-arms them)
   std::vector<hipEvent_t>* deliver_events;   // lia_kv_deliver tickets (events on the d2h stream), recycled round-robin
   std::vector<char>* deliver_pending;
+  // cross-layer chaining (lia_ctx_chain_next_norm): the combine of a layer call's last GEMM also normalises the output row with
+  // the NEXT layer's first-norm weights into the workspace's norm buffer; the next call finds it there and skips its first norm
+  const bf16_t *chain_g, *chain_b;
+  bool chain_armed;                 // one-shot, consumed by the next layer call
+  const void* normed_src;           // the y whose norm sits in normed_buf ...
+  const void* normed_buf;
+  long normed_rows;                 // ... for this many rows of this width
+  int normed_h;
 };
+
+extern "C" int lia_ctx_chain_next_norm(lia_ctx* c, const lia_bf16* g, const lia_bf16* b) {
+  if (!c || !g) return LIA_ERR_INVALID;
+  c->chain_g = g;
+  c->chain_b = b;
+  c->chain_armed = true;
+  return LIA_OK;
+}
 
 extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out) {
   if (!out) return LIA_ERR_INVALID;
@@ -367,7 +384,8 @@ extern "C" int lia_layernorm(const lia_bf16* x, long ldx, const lia_bf16* g, con
 }
 
 static int gemm_checked(lia_ctx* ctx, const bf16_t* x, long ldx, const bf16_t* w, int M, int N, int K,
-                        const LiaEpilogue& ep, const LiaOutMap& om, float* ws, size_t ws_bytes, int split, hipStream_t st) {
+                        const LiaEpilogue& ep, const LiaOutMap& om, float* ws, size_t ws_bytes, int split, hipStream_t st,
+                        const LiaPost* post = nullptr, int* post_done = nullptr) {
   if (N % 16 || K % 64) {
     lia_set_error("linear: N=%d must be a multiple of 16 and K=%d of 64", N, K);
     return LIA_ERR_INVALID;
@@ -380,7 +398,7 @@ static int gemm_checked(lia_ctx* ctx, const bf16_t* x, long ldx, const bf16_t* w
     e0 = (*ctx->prof_events)[2 * i];
     e1 = (*ctx->prof_events)[2 * i + 1];
   }
-  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, ctx ? ctx->gemm_tickets : nullptr, split, st, e0, e1, &regime);
+  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, ctx ? ctx->gemm_tickets : nullptr, split, st, e0, e1, &regime, post, post_done);
   if (timed && rc == 0 && regime != 0) {
     // algorithmic traffic of the op: the weight once, the activations in and out once
     double bytes = 2.0 * ((double)N * K + (double)M * K + (double)M * N);
@@ -401,6 +419,7 @@ extern "C" int lia_linear(lia_ctx* ctx, const lia_bf16* x, long ldx, const lia_b
   LiaOutMap om = plain_out(y, ldy, N);
   size_t need = M <= 256 ? (size_t)8 * M * N * 4 : 0;
   size_t have = std::min(need, ctx->ws_bytes);
+  ctx->normed_src = nullptr; ctx->chain_armed = false;   // the workspace is about to be reused
   return gemm_checked(ctx, x, ldx, w, M, N, K, ep, om, (float*)ctx->ws, have, split_k, (hipStream_t)stream);
 }
 
@@ -427,6 +446,7 @@ extern "C" int lia_qkv_project(lia_ctx* ctx, const lia_bf16* x, const lia_bf16* 
     return LIA_ERR_INVALID;
   }
   size_t need = (size_t)B * T <= 256 ? (size_t)8 * B * T * 3 * H * 4 : 0;
+  ctx->normed_src = nullptr; ctx->chain_armed = false;   // the workspace is about to be reused
   return qkv_project(ctx, x, w, bias, qout, kcache, vcache, true, B, T, H, cache_batch, b0, pos0, (float*)ctx->ws,
                      std::min(need, ctx->ws_bytes), (hipStream_t)stream);
 }
@@ -469,6 +489,7 @@ extern "C" int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, i
   size_t gemm_need = (size_t)8 * B * vocab * 4;
   if (ctx->ws_bytes < scratch) { lia_set_error("lia_lm_head: workspace too small"); return LIA_ERR_MEMORY; }
   hipStream_t st = (hipStream_t)stream;
+  ctx->normed_src = nullptr; ctx->chain_armed = false;   // the workspace is about to be reused
   bf16_t* lno = (bf16_t*)ctx->ws;
   // hidden[:, -1, :] -> final LN (lia/modeling_opt.py:1563 applies it to all positions; only the last one feeds
   // lm_head, models.py:424-431, and LN is row-wise, so the other rows are never needed)
@@ -545,9 +566,14 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
                          (W[7] == W[5] + H);
   const float eps = d->ln_eps;
   const size_t S = (size_t)pos0 + T;
+  // chaining state: a hint for THIS call's last GEMM, and whether the previous call already left LN1(x) in `ln`
+  const bf16_t *chain_g = ctx->chain_armed ? ctx->chain_g : nullptr, *chain_b = ctx->chain_armed ? ctx->chain_b : nullptr;
+  ctx->chain_armed = false;
+  const bool have_ln1 = ctx->normed_src == (const void*)x && ctx->normed_buf == (const void*)ln && ctx->normed_rows == M && ctx->normed_h == H;
+  ctx->normed_src = nullptr;
 
   // LN1 (decoder.py:199-206)
-  lia_layernorm_launch(x, H, W[0], W[1], ln, H, M, H, eps, st);
+  if (!have_ln1) lia_layernorm_launch(x, H, W[0], W[1], ln, H, M, H, eps, st);
 
   // destinations of the fresh K/V rows
   bf16_t *kdst, *vdst;
@@ -629,15 +655,18 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
     }
   }
 
-  // out-proj + bias, residual (decoder.py:225-229)
+  // out-proj + bias, residual (decoder.py:225-229); LN2 (:268-276) rides in the split-K combine when there is one
+  int ln2_done = 0;
   {
     LiaEpilogue ep{W[9], x, H, 0};
     LiaOutMap om = plain_out(h1, H, H);
-    rc = gemm_checked(ctx, ao, H, W[8], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st);
+    LiaPost post{};
+    post.kind = LIA_POST_LAYERNORM; post.g = W[10]; post.b = W[11]; post.eps = eps; post.out = ln; post.ldo = H;
+    rc = gemm_checked(ctx, ao, H, W[8], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st, &post, &ln2_done);
     if (rc) return rc;
   }
-  // LN2 (decoder.py:268-276), fc1 + relu (:282-285), fc2 + residual (:306-310)
-  lia_layernorm_launch(h1, H, W[10], W[11], ln, H, M, H, eps, st);
+  // fc1 + relu (:282-285), fc2 + residual (:306-310)
+  if (!ln2_done) lia_layernorm_launch(h1, H, W[10], W[11], ln, H, M, H, eps, st);
   {
     LiaEpilogue ep{W[13], nullptr, 0, 1};
     LiaOutMap om = plain_out(f1, F, F);
@@ -647,8 +676,12 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
   {
     LiaEpilogue ep{W[15], h1, H, 0};
     LiaOutMap om = plain_out(y, H, H);
-    rc = gemm_checked(ctx, f1, F, W[14], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st);
+    LiaPost post{};
+    int chained = 0;
+    if (chain_g && chain_b) { post.kind = LIA_POST_LAYERNORM; post.g = chain_g; post.b = chain_b; post.eps = eps; post.out = ln; post.ldo = H; }
+    rc = gemm_checked(ctx, f1, F, W[14], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st, post.kind ? &post : nullptr, &chained);
     if (rc) return rc;
+    if (chained) { ctx->normed_src = y; ctx->normed_buf = ln; ctx->normed_rows = M; ctx->normed_h = H; }
   }
   HIP_TRY(hipGetLastError());
   return LIA_OK;
@@ -738,15 +771,37 @@ extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, co
   float* gws = (float*)(ws + w.gemm);
   const bf16_t* const* W = (const bf16_t* const*)weights;
   const LiaEpilogue none{nullptr, nullptr, 0, 0};
+  // chaining state (see lia_layer_forward)
+  const bf16_t* chain_g = ctx->chain_armed ? ctx->chain_g : nullptr;
+  ctx->chain_armed = false;
+  const bool have_norm1 = ctx->normed_src == (const void*)x && ctx->normed_buf == (const void*)ln && ctx->normed_rows == M && ctx->normed_h == H;
+  ctx->normed_src = nullptr;
 
-  lia_rmsnorm_launch(x, H, W[0], ln, H, M, H, d->rms_eps, st);
-  {  // q projection
+  if (!have_norm1) lia_rmsnorm_launch(x, H, W[0], ln, H, M, H, d->rms_eps, st);
+  const bool fused_kv = W[3] == W[2] + (size_t)KD * H;
+  const int G = d->heads / d->kv_heads;
+  // q | k | v in ONE GEMM when the three weights are adjacent (they are in lia_llama_pack_offsets' layer buffer): the q columns
+  // are G segments of the k / v width, the k and v segments scatter into the seq-major cache; in decode the rotation of the q and
+  // k heads rides in the split-K combine
+  const bool fused_qkv = fused_kv && W[2] == W[1] + (size_t)H * H && G + 2 <= LIA_OUT_SEGS;
+  int rope_done = 0;
+  if (fused_qkv) {
+    LiaOutMap om;
+    memset(&om, 0, sizeof(om));
+    for (int j = 0; j < G; ++j) { om.base[j] = qb + (size_t)j * KD; om.ld[j] = H; }
+    om.base[G] = kv->k; om.base[G + 1] = kv->v; om.ld[G] = om.ld[G + 1] = KD; om.cache_mode[G] = om.cache_mode[G + 1] = 1;
+    om.seg_n = KD; om.T = T; om.Bc = kv->batch; om.b0 = b0; om.pos0 = pos0;
+    LiaPost post{};
+    post.kind = LIA_POST_ROPE; post.cos_t = cos_table; post.sin_t = sin_table; post.rot_heads = d->heads + d->kv_heads; post.hd = hd;
+    post.pos0 = pos0; post.T = T;
+    rc = gemm_checked(ctx, ln, H, W[1], (int)M, H + 2 * KD, H, none, om, gws, w.gemm_bytes, 0, st, &post, &rope_done);
+    if (rc) return rc;
+  } else {  // q projection
     LiaOutMap om = plain_out(qb, H, H);
     rc = gemm_checked(ctx, ln, H, W[1], (int)M, H, H, none, om, gws, w.gemm_bytes, 0, st);
     if (rc) return rc;
   }
-  const bool fused_kv = W[3] == W[2] + (size_t)KD * H;
-  for (int part = 0; part < (fused_kv ? 1 : 2); ++part) {  // k | v projection, rows scattered into the seq-major cache
+  for (int part = 0; part < (fused_qkv ? 0 : (fused_kv ? 1 : 2)); ++part) {  // k | v projection, rows scattered into the seq-major cache
     LiaOutMap om;
     memset(&om, 0, sizeof(om));
     if (fused_kv) { om.base[0] = kv->k; om.base[1] = kv->v; om.cache_mode[0] = om.cache_mode[1] = 1; om.ld[0] = om.ld[1] = KD; }
@@ -756,28 +811,35 @@ extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, co
     if (rc) return rc;
   }
   // RoPE on q (token rows b*T+t) and on the K rows just written (cache rows t*Bc + b); HF caches post-RoPE keys
-  lia_rope_launch(qb, H, cos_table, sin_table, M, d->heads, hd, pos0, T, 0, st);
-  if (b0 == 0 && B == kv->batch) {
-    lia_rope_launch(kv->k + (size_t)pos0 * kv->batch * KD, KD, cos_table, sin_table, (long)T * B, d->kv_heads, hd, pos0, 0, kv->batch, st);
-  } else {
-    for (int t = 0; t < T; ++t)  // minibatch slice of the cache rows: one launch per position
-      lia_rope_launch(kv->k + ((size_t)(pos0 + t) * kv->batch + b0) * KD, KD, cos_table, sin_table, B, d->kv_heads, hd, pos0 + t, 0,
-                      kv->batch + B, st);
+  if (!rope_done) {
+    lia_rope_launch(qb, H, cos_table, sin_table, M, d->heads, hd, pos0, T, 0, st);
+    if (b0 == 0 && B == kv->batch) {
+      lia_rope_launch(kv->k + (size_t)pos0 * kv->batch * KD, KD, cos_table, sin_table, (long)T * B, d->kv_heads, hd, pos0, 0, kv->batch, st);
+    } else {
+      for (int t = 0; t < T; ++t)  // minibatch slice of the cache rows: one launch per position
+        lia_rope_launch(kv->k + ((size_t)(pos0 + t) * kv->batch + b0) * KD, KD, cos_table, sin_table, B, d->kv_heads, hd, pos0 + t, 0,
+                        kv->batch + B, st);
+    }
   }
   int arc = T == 1 ? lia_attn_decode_launch(qb, H, kv->k, kv->v, ao, H, B, pos0 + 1, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st)
                    : lia_attn_prefill_launch(qb, H, kv->k, kv->v, ao, H, B, T, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st);
   if (arc) { lia_set_error("llama attention: unsupported head_dim %d / S %d", hd, pos0 + T); return LIA_ERR_INVALID; }
-  {  // o_proj + residual
+  int norm2_done = 0, silu_done = 0;
+  {  // o_proj + residual; the post-attention RMSNorm rides in the split-K combine when there is one
     LiaEpilogue ep{nullptr, x, H, 0};
     LiaOutMap om = plain_out(h1, H, H);
-    rc = gemm_checked(ctx, ao, H, W[4], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st);
+    LiaPost post{};
+    post.kind = LIA_POST_RMSNORM; post.g = W[5]; post.eps = d->rms_eps; post.out = ln; post.ldo = H;
+    rc = gemm_checked(ctx, ao, H, W[4], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st, &post, &norm2_done);
     if (rc) return rc;
   }
-  lia_rmsnorm_launch(h1, H, W[5], ln, H, M, H, d->rms_eps, st);
+  if (!norm2_done) lia_rmsnorm_launch(h1, H, W[5], ln, H, M, H, d->rms_eps, st);
   const bool fused_gu = W[7] == W[6] + (size_t)F * H;
   if (fused_gu) {
     LiaOutMap om = plain_out(gu, 2 * F, 2 * F);
-    rc = gemm_checked(ctx, ln, H, W[6], (int)M, 2 * F, H, none, om, gws, w.gemm_bytes, 0, st);
+    LiaPost post{};
+    post.kind = LIA_POST_SILU_MUL; post.out = act; post.ldo = F;     // decode: act = silu(gate) * up straight from the combine
+    rc = gemm_checked(ctx, ln, H, W[6], (int)M, 2 * F, H, none, om, gws, w.gemm_bytes, 0, st, &post, &silu_done);
     if (rc) return rc;
   } else {
     for (int part = 0; part < 2; ++part) {
@@ -786,12 +848,16 @@ extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, co
       if (rc) return rc;
     }
   }
-  lia_silu_mul_launch(gu, act, M, F, st);
-  {  // down_proj + residual
+  if (!silu_done) lia_silu_mul_launch(gu, act, M, F, st);
+  {  // down_proj + residual (+ the next layer's input RMSNorm when the caller chained it)
     LiaEpilogue ep{nullptr, h1, H, 0};
     LiaOutMap om = plain_out(y, H, H);
-    rc = gemm_checked(ctx, act, F, W[8], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st);
+    LiaPost post{};
+    int chained = 0;
+    if (chain_g) { post.kind = LIA_POST_RMSNORM; post.g = chain_g; post.eps = d->rms_eps; post.out = ln; post.ldo = H; }
+    rc = gemm_checked(ctx, act, F, W[8], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st, post.kind ? &post : nullptr, &chained);
     if (rc) return rc;
+    if (chained) { ctx->normed_src = y; ctx->normed_buf = ln; ctx->normed_rows = M; ctx->normed_h = H; }
   }
   HIP_TRY(hipGetLastError());
   return LIA_OK;
@@ -814,6 +880,7 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
   size_t scratch = align_up((size_t)B * H * 2, 256);
   if (ctx->ws_bytes < scratch) { lia_set_error("lia_llama_lm_head: workspace too small"); return LIA_ERR_MEMORY; }
   hipStream_t st = (hipStream_t)stream;
+  ctx->normed_src = nullptr; ctx->chain_armed = false;   // the workspace is about to be reused
   bf16_t* lno = (bf16_t*)ctx->ws;
   lia_rmsnorm_launch(hidden + (long)(T - 1) * H, (long)T * H, normw, lno, H, B, H, eps, st);
   LiaEpilogue ep{nullptr, nullptr, 0, 0};

@@ -56,14 +56,15 @@ __device__ __forceinline__ float lia_epilogue_apply(float acc, float bias, bool 
   return t;
 }
 
-// Where a GEMM output row lands.  Up to three equal-width column segments (fused q|k|v projection),
+// Where a GEMM output row lands.  Up to LIA_OUT_SEGS equal-width column segments (fused q|k|v projection),
 // each with its own base / leading dimension; a segment in "cache" mode scatters token row
 // m = b*T + t to the seq-major KV-cache row (pos0 + t)*Bc + b0 + b  (attentions.py:457-458,475-476,
 // 490-491: key.permute(1,0,2,3) written into the [S,B,h,d] cache).
+#define LIA_OUT_SEGS 10
 struct LiaOutMap {
-  bf16_t* base[3];
-  long ld[3];
-  int cache_mode[3];
+  bf16_t* base[LIA_OUT_SEGS];    // (a grouped-query q|k|v projection: heads/kv_heads segments of q, then k, then v)
+  long ld[LIA_OUT_SEGS];
+  int cache_mode[LIA_OUT_SEGS];
   int seg_n;   // columns per segment (N if a single segment)
   int T;       // tokens per batch row in this call
   int Bc;      // batch size of the cache (row pitch in batch rows)
@@ -80,4 +81,128 @@ __device__ __forceinline__ bf16_t* lia_out_ptr(const LiaOutMap& o, int m, int n)
     row = (long)(o.pos0 + t) * o.Bc + o.b0 + b;
   }
   return o.base[s] + row * o.ld[s] + nn;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Work that follows a decode GEMM and can ride in its split-K combine instead of a kernel of its own
+// (lia_gemm_launch's `post`; the caller runs the stand-alone kernel when the GEMM was not split).  The arithmetic of
+// each kind is the device function the stand-alone kernel uses too, so the two routes give the same bits.
+// ---------------------------------------------------------------------------------------------
+enum { LIA_POST_NONE = 0, LIA_POST_LAYERNORM = 1, LIA_POST_RMSNORM = 2, LIA_POST_SILU_MUL = 3, LIA_POST_ROPE = 4 };
+struct LiaPost {
+  int kind;
+  // LAYERNORM / RMSNORM of the finished output row (N = hidden): out[m][:] = norm(y[m][:]; g, b, eps)
+  const bf16_t* g;
+  const bf16_t* b;
+  float eps;
+  bf16_t* out;          // norm: [M][ldo];  SILU_MUL: act[M][ldo] = silu(y[:, :N/2]) * y[:, N/2:]  (y itself is not written)
+  long ldo;
+  // ROPE: the first rot_heads heads (width hd) of every output row are rotated at position pos0 + m % T, the rest are plain
+  const bf16_t* cos_t;
+  const bf16_t* sin_t;
+  int rot_heads, hd, pos0, T;
+};
+
+// sum over the 256 threads of a workgroup, the same value in every thread (red: 4 floats of LDS, used once per call)
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One row per 256-thread workgroup; thread t holds the 8-value pieces t, t + 256, ... (packed bf16) of the row.
+// LayerNorm as torch.nn.functional.layer_norm on bf16: statistics in fp32 (two passes over the registers), one rounding.
+template <int NV>
+__device__ __forceinline__ void row_layernorm256(const uint4 (&v)[NV], const uint4 (&gv)[NV], const uint4 (&bv)[NV], int nv, int H,
+                                                 float eps, bf16_t* __restrict__ yr, float* red /* 8 floats */) {
+  const int tid = threadIdx.x;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (tid + 256 * k < nv) {
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += bf2f(w[j] & 0xffff) + bf2f(w[j] >> 16);
+    }
+  }
+  const float mean = block_sum256(s, red) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (tid + 256 * k < nv) {
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = bf2f(w[j] & 0xffff) - mean, c = bf2f(w[j] >> 16) - mean;
+        q += a * a + c * c;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(block_sum256(q, red + 4) / (float)H + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + 256 * k;
+    if (i < nv) {
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w},
+                     bw[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = (bf2f(w[j] & 0xffff) - mean) * rstd * bf2f(gw[j] & 0xffff) + bf2f(bw[j] & 0xffff);
+        float hi = (bf2f(w[j] >> 16) - mean) * rstd * bf2f(gw[j] >> 16) + bf2f(bw[j] >> 16);
+        o[j] = pack_bf16x2(lo, hi);
+      }
+      *(uint4*)(yr + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
+// LlamaRMSNorm.forward: y = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) )
+template <int NV>
+__device__ __forceinline__ void row_rmsnorm256(const uint4 (&v)[NV], const uint4 (&gv)[NV], int nv, int H, float eps,
+                                               bf16_t* __restrict__ yr, float* red /* 4 floats */) {
+  const int tid = threadIdx.x;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (tid + 256 * k < nv) {
+      const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float a = bf2f(u[j] & 0xffff), c = bf2f(u[j] >> 16); ss += a * a + c * c; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(block_sum256(ss, red) / (float)H + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + 256 * k;
+    if (i < nv) {
+      const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = pack_bf16x2(bf2f(gw[j] & 0xffff) * rbf(bf2f(u[j] & 0xffff) * rstd), bf2f(gw[j] >> 16) * rbf(bf2f(u[j] >> 16) * rstd));
+      *(uint4*)(yr + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
+// LlamaMLP act_fn(gate) * up on two packed bf16 pairs: bf16( bf16(silu(g)) * u ); silu in fp32 through the hardware exp2 /
+// reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of libm expf + an IEEE division -- the result is rounded to bf16 right
+// after, so a last-bit fp32 difference reaches the output about once in 2^15 elements (HF's own silu is no libm-exact
+// reference either: Sleef on the CPU, a fast-math kernel on GPUs)
+__device__ __forceinline__ uint32_t lia_silu_mul_pair(uint32_t gw, uint32_t uw) {
+  const float g0 = bf2f(gw & 0xffff), g1 = bf2f(gw >> 16);
+  const float s0 = rbf(g0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g0)));
+  const float s1 = rbf(g1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g1)));
+  return pack_bf16x2(s0 * bf2f(uw & 0xffff), s1 * bf2f(uw >> 16));
+}
+
+// apply_rotary_pos_emb on one packed pair of (x[i], x[i+1]) and its partner (x[i+half], x[i+half+1]):
+// out = bf16( bf16(x*cos) + bf16(rotate_half(x)*sin) ).  c0/s0: table entries at i, c1/s1: at i + half.
+__device__ __forceinline__ void lia_rope_pair(uint32_t aw, uint32_t bw, uint32_t c0, uint32_t c1, uint32_t s0, uint32_t s1,
+                                              uint32_t& oa, uint32_t& ob) {
+  const float a_lo = bf2f(aw & 0xffff), a_hi = bf2f(aw >> 16), b_lo = bf2f(bw & 0xffff), b_hi = bf2f(bw >> 16);
+  oa = pack_bf16x2(rbf(a_lo * bf2f(c0 & 0xffff)) + rbf(-b_lo * bf2f(s0 & 0xffff)), rbf(a_hi * bf2f(c0 >> 16)) + rbf(-b_hi * bf2f(s0 >> 16)));
+  ob = pack_bf16x2(rbf(b_lo * bf2f(c1 & 0xffff)) + rbf(a_lo * bf2f(s1 & 0xffff)), rbf(b_hi * bf2f(c1 >> 16)) + rbf(a_hi * bf2f(s1 >> 16)));
 }

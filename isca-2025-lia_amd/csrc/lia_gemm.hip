@@ -24,6 +24,22 @@
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: 4 consecutive columns n..n+3 of row m
 // ---------------------------------------------------------------------------------------------
+// the four finished values (every reference rounding point applied: they are bf16-representable)
+__device__ __forceinline__ f32x4 epilogue_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep) {
+  float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+  if (hb) {
+    uint2 bb = *(const uint2*)(ep.bias + n);
+    b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
+  }
+  if (hr) {
+    uint2 rr = *(const uint2*)(ep.residual + (long)m * ep.ldr + n);
+    r[0] = bf2f(rr.x & 0xffff); r[1] = bf2f(rr.x >> 16); r[2] = bf2f(rr.y & 0xffff); r[3] = bf2f(rr.y >> 16);
+  }
+  return f32x4{lia_epilogue_apply(v[0], b[0], hb, ep.relu, r[0], hr), lia_epilogue_apply(v[1], b[1], hb, ep.relu, r[1], hr),
+               lia_epilogue_apply(v[2], b[2], hb, ep.relu, r[2], hr), lia_epilogue_apply(v[3], b[3], hb, ep.relu, r[3], hr)};
+}
+
 __device__ __forceinline__ void store_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep, const LiaOutMap& om) {
   float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
   const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
@@ -59,6 +75,106 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __r
     a += b;
   }
   store_quad(a, m, n, ep, om);
+}
+
+__device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ partial, int S, int M, int N, int m, int n) {
+  f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
+  for (int s = 1; s < S; ++s) a += *(const f32x4*)(partial + ((long)s * M + m) * N + n);     // slice 0, 1, ...: the order of the plain combine
+  return a;
+}
+
+// ---- split-K combines that also do the next op of the decode layer (LiaPost, lia_common.h) ----
+// LAYERNORM / RMSNORM: one workgroup per output row; the row is combined, finished (bias / residual), stored, and normalised
+// from registers into post.out -- the out-proj / fc2 (o / down) combine and the norm kernel behind it in one launch.
+template <int KIND, int NV>
+__global__ __launch_bounds__(256) void lia_splitk_reduce_norm_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                                      LiaEpilogue ep, LiaOutMap om, LiaPost post) {
+  __shared__ float red[8];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int nv = N >> 3;
+  uint4 v[NV], gv[NV], bv[NV];
+  // slice-outer: the 2 NV loads of one slice are in flight together, S round trips in all (a per-piece loop over the slices
+  // waits 2 NV x S times: 16 us for the 64 rows of OPT-30B's fc2); the sum per element is still slice 0 + 1 + ...
+  f32x4 acc[NV][2];
+  const float* prow = partial + (long)m * N;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = min(tid + 256 * k, nv - 1);          // (clamped: idle lanes re-read the last piece and drop it)
+    gv[k] = *(const uint4*)(post.g + 8 * i);
+    if (KIND == LIA_POST_LAYERNORM) bv[k] = *(const uint4*)(post.b + 8 * i);
+    acc[k][0] = *(const f32x4*)(prow + 8 * i);
+    acc[k][1] = *(const f32x4*)(prow + 8 * i + 4);
+  }
+  for (int s = 1; s < S; ++s) {
+    const float* ps = prow + (long)s * M * N;
+    f32x4 t[NV][2];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = min(tid + 256 * k, nv - 1);
+      t[k][0] = *(const f32x4*)(ps + 8 * i);
+      t[k][1] = *(const f32x4*)(ps + 8 * i + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { acc[k][0] += t[k][0]; acc[k][1] += t[k][1]; }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + 256 * k;
+    v[k] = uint4{0u, 0u, 0u, 0u};
+    if (i < nv) {
+      const f32x4 lo = epilogue_quad(acc[k][0], m, 8 * i, ep);
+      const f32x4 hi = epilogue_quad(acc[k][1], m, 8 * i + 4, ep);
+      v[k] = uint4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+      *(uint4*)(om.base[0] + (long)m * om.ld[0] + 8 * i) = v[k];
+    }
+  }
+  bf16_t* yr = post.out + (long)m * post.ldo;
+  if (KIND == LIA_POST_LAYERNORM) row_layernorm256<NV>(v, gv, bv, nv, N, post.eps, yr, red);
+  else row_rmsnorm256<NV>(v, gv, nv, N, post.eps, yr, red);
+}
+
+// SILU_MUL: the gate | up projection's combine writes act = silu(gate) * up directly; the [M][2F] intermediate never exists.
+__global__ __launch_bounds__(256) void lia_splitk_reduce_silu_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                                      LiaEpilogue ep, LiaPost post) {
+  const int F = N >> 1;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (long)M * (F >> 2)) return;
+  const int m = (int)(q / (F >> 2));
+  const int c = (int)(q - (long)m * (F >> 2)) * 4;
+  const f32x4 gq = epilogue_quad(splitk_sum(partial, S, M, N, m, c), m, c, ep);
+  const f32x4 uq = epilogue_quad(splitk_sum(partial, S, M, N, m, F + c), m, F + c, ep);
+  uint2 o;
+  o.x = lia_silu_mul_pair(pack_bf16x2(gq[0], gq[1]), pack_bf16x2(uq[0], uq[1]));
+  o.y = lia_silu_mul_pair(pack_bf16x2(gq[2], gq[3]), pack_bf16x2(uq[2], uq[3]));
+  *(uint2*)(post.out + (long)m * post.ldo + c) = o;
+}
+
+// ROPE: the q | k | v projection's combine rotates the q and k heads (the first post.rot_heads heads of the row) on the way
+// out; one thread per 4 pairs (i .. i+3, i+half .. i+half+3) of one head, the v heads pass through.
+__global__ __launch_bounds__(256) void lia_splitk_reduce_rope_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                                      LiaEpilogue ep, LiaOutMap om, LiaPost post) {
+  const int hd = post.hd, half = hd >> 1, gph = half >> 2;          // groups of 4 pairs per head
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int heads = N / hd;
+  if (idx >= (long)M * heads * gph) return;
+  const int gi = (int)(idx % gph);
+  const long mh = idx / gph;
+  const int h = (int)(mh % heads), m = (int)(mh / heads);
+  const int n0 = h * hd + 4 * gi, n1 = n0 + half;
+  const f32x4 a = epilogue_quad(splitk_sum(partial, S, M, N, m, n0), m, n0, ep);
+  const f32x4 b = epilogue_quad(splitk_sum(partial, S, M, N, m, n1), m, n1, ep);
+  uint2 oa{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])}, ob{pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  if (h < post.rot_heads) {
+    const int pos = post.pos0 + m % post.T;
+    const uint2 c0 = *(const uint2*)(post.cos_t + (long)pos * hd + 4 * gi), c1 = *(const uint2*)(post.cos_t + (long)pos * hd + half + 4 * gi);
+    const uint2 s0 = *(const uint2*)(post.sin_t + (long)pos * hd + 4 * gi), s1 = *(const uint2*)(post.sin_t + (long)pos * hd + half + 4 * gi);
+    uint2 ra, rb;
+    lia_rope_pair(oa.x, ob.x, c0.x, c1.x, s0.x, s1.x, ra.x, rb.x);
+    lia_rope_pair(oa.y, ob.y, c0.y, c1.y, s0.y, s1.y, ra.y, rb.y);
+    oa = ra; ob = rb;
+  }
+  *(uint2*)lia_out_ptr(om, m, n0) = oa;
+  *(uint2*)lia_out_ptr(om, m, n1) = ob;
 }
 
 // LDS slot (row, c) holds global 16-byte chunk (c ^ swz(row)) of that row; a 128-B row is half a
@@ -1010,6 +1126,50 @@ static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw,
                      split > 1 ? partial : nullptr, tickets, ep, om);
 }
 
+// A/B switch (tests, tools): LIA_FUSE_COMBINE=0 or lia_gemm_set_fuse_combine(0) keeps every post op a kernel of its own
+static int g_fuse_combine = [] { const char* e = getenv("LIA_FUSE_COMBINE"); return (e && !strcmp(e, "0")) ? 0 : 1; }();
+extern "C" void lia_gemm_set_fuse_combine(int on) { g_fuse_combine = on; }
+static long g_fused_combines[5];     // launches per LIA_POST_* kind since the library was loaded (tests assert the route was taken)
+extern "C" long lia_gemm_fused_combine_count(int kind) { return (kind >= 0 && kind < 5) ? g_fused_combines[kind] : -1; }
+
+// the combine kernel that also runs `post`, if this shape has one; false: nothing launched
+static bool launch_fused_combine(const float* ws, int split, int M, int N, const LiaEpilogue& ep, const LiaOutMap& om, const LiaPost& post,
+                                 hipStream_t st) {
+  if (!g_fuse_combine) return false;
+  if (post.kind == LIA_POST_LAYERNORM || post.kind == LIA_POST_RMSNORM) {
+    if (om.seg_n != N || om.cache_mode[0] || (N & 7) || (N >> 3) > 256 * 8 || (om.ld[0] & 7) || (post.ldo & 7) || !post.g || !post.out) return false;
+    if (post.kind == LIA_POST_LAYERNORM && !post.b) return false;
+    const int nvt = ((N >> 3) + 255) / 256;
+#define LIA_NORM_COMBINE(K)                                                                                                            \
+    do {                                                                                                                               \
+      if (nvt <= 1) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 1>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post);      \
+      else if (nvt <= 2) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 2>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post); \
+      else if (nvt <= 4) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 4>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post); \
+      else if (nvt <= 6) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 6>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post); \
+      else hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 8>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post);               \
+    } while (0)
+    if (post.kind == LIA_POST_LAYERNORM) LIA_NORM_COMBINE(LIA_POST_LAYERNORM); else LIA_NORM_COMBINE(LIA_POST_RMSNORM);
+#undef LIA_NORM_COMBINE
+    ++g_fused_combines[post.kind];
+    return true;
+  }
+  if (post.kind == LIA_POST_SILU_MUL) {
+    if ((N & 7) || (post.ldo & 3) || !post.out) return false;
+    const long nq = (long)M * (N >> 3);
+    hipLaunchKernelGGL(lia_splitk_reduce_silu_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, ws, split, M, N, ep, post);
+    ++g_fused_combines[post.kind];
+    return true;
+  }
+  if (post.kind == LIA_POST_ROPE) {
+    if (post.hd <= 0 || (post.hd & 7) || N % post.hd || om.seg_n % post.hd || post.T <= 0 || !post.cos_t || !post.sin_t) return false;
+    const long nt = (long)M * (N / post.hd) * (post.hd >> 3);
+    hipLaunchKernelGGL(lia_splitk_reduce_rope_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, ws, split, M, N, ep, om, post);
+    ++g_fused_combines[post.kind];
+    return true;
+  }
+  return false;
+}
+
 // experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row,
 // 3 = force the two-block x cut at 64 < M <= 128, 4 = forbid it
 static int g_skinny_variant = 0;
@@ -1020,7 +1180,11 @@ extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
 // launch; the kernel leaves them zero again).  NULL: the slabs are combined by a second kernel as in r01.
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime) {
+                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime,
+                               const LiaPost* post, int* post_done) {
+  // post (nullable): the op that follows this GEMM in the decode layer; when the GEMM is split over K its combine kernel does
+  // that op too and *post_done = 1 -- otherwise *post_done = 0 and the caller launches the stand-alone kernel.
+  if (post_done) *post_done = 0;
   // ev0/ev1 (nullable): recorded on `st` immediately around the MAIN kernel launch only (bench.py's live
   // roofline timing; the split-K combine kernel is outside the bracket).  *regime: 1 skinny, 2 tiled.
   if (regime) *regime = 0;
@@ -1097,6 +1261,7 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     if (split > 1 && tk == nullptr) {
+      if (post && post_done && launch_fused_combine(workspace, split, M, N, *ep, *om, *post, st)) { *post_done = 1; return 0; }
       long nq = (long)M * (N / 4);
       hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace,
                          split, M, N, *ep, *om);

@@ -73,8 +73,37 @@ __global__ __launch_bounds__(256) void lia_rmsnorm_reg_kernel(const bf16_t* __re
   }
 }
 
+// decode-sized inputs: one workgroup per row (see lia_layernorm_row_kernel), the arithmetic of row_rmsnorm256
+template <int NV>
+__global__ __launch_bounds__(256) void lia_rmsnorm_row_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                               bf16_t* __restrict__ y, long ldy, int H, float eps) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const bf16_t* xr = x + row * ldx;
+  const int nv = H >> 3;
+  uint4 v[NV], gv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const bool in = i < nv;
+    v[k] = in ? *(const uint4*)(xr + 8 * i) : uint4{0u, 0u, 0u, 0u};
+    gv[k] = in ? *(const uint4*)(w + 8 * i) : uint4{0u, 0u, 0u, 0u};
+  }
+  row_rmsnorm256<NV>(v, gv, nv, H, eps, y + row * ldy, red);
+}
+
 extern "C" void lia_rmsnorm_launch(const bf16_t* x, long ldx, const bf16_t* w, bf16_t* y, long ldy, long rows, int H, float eps,
                                    hipStream_t st) {
+  if (rows > 0 && rows <= 1024 && (H & 7) == 0 && (H >> 3) <= 256 * 8) {
+    const int nvt = ((H >> 3) + 255) / 256;
+    const dim3 grid((unsigned)rows), block(256);
+    if (nvt <= 1) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<1>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
+    else if (nvt <= 2) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<2>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
+    else if (nvt <= 4) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<4>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
+    else if (nvt <= 6) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<6>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
+    else hipLaunchKernelGGL(lia_rmsnorm_row_kernel<8>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
+    return;
+  }
   if (rows <= 0) return;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   const int nvl = ((H >> 3) + 63) / 64;
@@ -132,13 +161,7 @@ __global__ __launch_bounds__(256) void lia_rope_vec_kernel(bf16_t* __restrict__ 
   const uint32_t s0[4] = {s0v.x, s0v.y, s0v.z, s0v.w}, s1[4] = {s1v.x, s1v.y, s1v.z, s1v.w};
   uint32_t oa[4], ob[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a_lo = bf2f(aw[j] & 0xffff), a_hi = bf2f(aw[j] >> 16), b_lo = bf2f(bw[j] & 0xffff), b_hi = bf2f(bw[j] >> 16);
-    oa[j] = pack_bf16x2(rbf(a_lo * bf2f(c0[j] & 0xffff)) + rbf(-b_lo * bf2f(s0[j] & 0xffff)),
-                        rbf(a_hi * bf2f(c0[j] >> 16)) + rbf(-b_hi * bf2f(s0[j] >> 16)));
-    ob[j] = pack_bf16x2(rbf(b_lo * bf2f(c1[j] & 0xffff)) + rbf(a_lo * bf2f(s1[j] & 0xffff)),
-                        rbf(b_hi * bf2f(c1[j] >> 16)) + rbf(a_hi * bf2f(s1[j] >> 16)));
-  }
+  for (int j = 0; j < 4; ++j) lia_rope_pair(aw[j], bw[j], c0[j], c1[j], s0[j], s1[j], oa[j], ob[j]);
   *(uint4*)p = uint4{oa[0], oa[1], oa[2], oa[3]};
   *(uint4*)(p + half) = uint4{ob[0], ob[1], ob[2], ob[3]};
 }
@@ -170,16 +193,7 @@ __global__ __launch_bounds__(256) void lia_silu_mul_kernel(const bf16_t* __restr
     const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
     uint32_t o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float g0 = bf2f(gw[j] & 0xffff), g1 = bf2f(gw[j] >> 16);
-      // silu in fp32 through the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of libm expf + an IEEE
-      // division: at B 128 x T 1024 the kernel was VALU-bound (2.4 ms per layer for 5.6 GB); the result is rounded to bf16
-      // right after, so a last-bit fp32 difference reaches the output about once in 2^15 elements (HF's own silu is no
-      // libm-exact reference either: Sleef on the CPU, a fast-math kernel on GPUs)
-      float s0 = rbf(g0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g0)));
-      float s1 = rbf(g1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g1)));
-      o[j] = pack_bf16x2(s0 * bf2f(uw[j] & 0xffff), s1 * bf2f(uw[j] >> 16));
-    }
+    for (int j = 0; j < 4; ++j) o[j] = lia_silu_mul_pair(gw[j], uw[j]);
     *(uint4*)(out + m * (long)F + c) = uint4{o[0], o[1], o[2], o[3]};
   }
 }

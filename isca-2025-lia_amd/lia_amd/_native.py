@@ -49,6 +49,7 @@ SIGNATURES = {
     "lia_ctx_synchronize": (c_int, [c_void_p]),
     "lia_ctx_synchronize_compute": (c_int, [c_void_p]),
     "lia_ctx_set_host_threads": (c_int, [c_void_p, c_int]),
+    "lia_ctx_chain_next_norm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lia_prof_start": (c_int, [c_void_p, c_int]),
     "lia_prof_set_stride": (c_int, [c_void_p, c_int]),
     "lia_prof_stop": (c_int, [c_void_p, ctypes.POINTER(ProfResult)]),

@@ -219,11 +219,16 @@ class LlamaScheduler:
                                     ctypes.c_void_p(x.data_ptr()), B, T, sh.hidden, st), "lia_llama_embed")
         if n_gpu < L:
             pipe.prefetch(n_gpu)
+        def resident(i):
+            if i not in self.resident:
+                self.resident[i] = self._ptrs(m.layers[i].device_ptr())
+            return self.resident[i]
+
         for idx in range(L):
             if idx < n_gpu:
-                if idx not in self.resident:
-                    self.resident[idx] = self._ptrs(m.layers[idx].device_ptr())
-                w = self.resident[idx]
+                w = resident(idx)
+                if T == 1 and idx + 1 < n_gpu:
+                    ctx.chain_next_norm(resident(idx + 1)[0])      # decode: the next layer's input RMSNorm rides in this layer's down-proj combine
             else:
                 w = self._ptrs(pipe.slot_ptrs[self._acquire(pipe, idx)])
                 nxt = idx

@@ -59,6 +59,11 @@ class Context:
     def set_host_threads(self, n):
         N.check(self.lib.lia_ctx_set_host_threads(self.handle, n))
 
+    def chain_next_norm(self, g_ptr, b_ptr=None):
+        """lia_ctx_chain_next_norm: the next layer call also computes the first norm (weights g, b) of the layer after it."""
+        N.check(self.lib.lia_ctx_chain_next_norm(self.handle, ctypes.c_void_p(g_ptr), ctypes.c_void_p(b_ptr) if b_ptr else None),
+                "lia_ctx_chain_next_norm")
+
     def prof_start(self, max_launches=16384, stride=1):
         """HIP-event brackets around every stride-th GEMM launch from here on (lia_prof_start / lia_prof_set_stride)."""
         N.check(self.lib.lia_prof_set_stride(self.handle, stride), "lia_prof_set_stride")

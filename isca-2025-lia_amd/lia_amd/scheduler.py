@@ -447,6 +447,9 @@ class OffloadScheduler:
         for idx in range(L):
             if idx < n_gpu:
                 # resident layer: whole batch, everything on the GPU incl. KV (policy 3; :1246-1260)
+                if not is_prefill and idx + 1 < n_gpu:
+                    nw = self._resident(idx + 1)                   # decode: LN1 of the next resident layer rides in this layer's fc2 combine
+                    ctx.chain_next_norm(nw[0], nw[1])
                 ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
                 x, y = y, x
                 continue

@@ -1,0 +1,172 @@
+"""-m gpu: the split-K combines that also run the next op of the decode layer (LayerNorm / RMSNorm of the finished row, SiLU*up,
+RoPE; lia_gemm.hip `LiaPost`, lia_ctx_chain_next_norm) give the SAME BITS as the route with one kernel per op.  The reference
+launches every one of these as its own op (decoder.py:199-206, 268-276); the oracle parity of the ops themselves is in
+test_gpu_ops.py / test_gpu_llama.py -- this file pins the fusion."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import synth
+from test_gpu_ops import _layer_setup, to_bits, to_dev
+
+pytestmark = pytest.mark.gpu
+LN, RMS, SILU, ROPE = 1, 2, 3, 4
+
+
+def _knobs():
+    from lia_amd import _native as N
+    lib = N.lib()
+    lib.lia_gemm_set_fuse_combine.argtypes = [ctypes.c_int]
+    lib.lia_gemm_set_fuse_combine.restype = None
+    lib.lia_gemm_fused_combine_count.argtypes = [ctypes.c_int]
+    lib.lia_gemm_fused_combine_count.restype = ctypes.c_long
+    return lib
+
+
+@pytest.mark.parametrize("B,H,heads,F", [(8, 1024, 8, 4096), (64, 2048, 16, 8192), (33, 1536, 12, 6144)])
+def test_opt_decode_layers_fused_equals_unfused(B, H, heads, F):
+    """two resident layers, three decode steps: LN2 in the out-proj combine, the next layer's LN1 chained into fc2's."""
+    import torch
+    from lia_amd import _native as N, ops
+    lib = _knobs()
+    ctx = ops.Context(0, 1 << 30)
+    d, T, new = H // heads, 5, 3
+    layers = [_layer_setup(torch, ops, synth.make_layer(11 + i, H, F, 0.05), H, heads, F) for i in range(2)]
+
+    def run(fused):
+        lib.lia_gemm_set_fuse_combine(1 if fused else 0)
+        kvs, keep = [], []
+        for _ in layers:
+            kc = torch.zeros((T + new, B, heads, d), dtype=torch.bfloat16, device="cuda")
+            vc = torch.zeros_like(kc)
+            keep.append((kc, vc))
+            kvs.append(N.KV(kc.data_ptr(), vc.data_ptr(), T + new, B, 1))
+        outs = []
+        a = to_dev(torch, synth.make_hidden(3, B, T, H))
+        b = torch.empty_like(a)
+        for (desc, _, wp), kv in zip(layers, kvs):       # prefill fills the caches (tiled GEMMs: nothing to fuse)
+            ctx.layer_forward(desc, 3, wp, a, b, kv, B, T, 0)
+            a, b = b, a
+        for s in range(new):
+            a = to_dev(torch, synth.make_hidden(100 + s, B, 1, H))
+            b = torch.empty_like(a)
+            for i, ((desc, _, wp), kv) in enumerate(zip(layers, kvs)):
+                if fused and i + 1 < len(layers):
+                    nw = layers[i + 1][2]
+                    ctx.chain_next_norm(nw[0], nw[1])
+                ctx.layer_forward(desc, 3, wp, a, b, kv, B, 1, T + s)
+                a, b = b, a
+            ctx.synchronize()
+            outs.append(to_bits(a).copy())
+        return outs, [to_bits(k).copy() for k, _ in keep]
+
+    n0 = lib.lia_gemm_fused_combine_count(LN)
+    fused, fk = run(True)
+    n1 = lib.lia_gemm_fused_combine_count(LN)
+    plain, pk = run(False)
+    assert lib.lia_gemm_fused_combine_count(LN) == n1, "the switch did not turn the fused combines off"
+    lib.lia_gemm_set_fuse_combine(1)
+    assert n1 - n0 >= 3 * new, f"only {n1 - n0} fused LayerNorm combines ran (expected LN2 x2 + one chained LN1 per step)"
+    for s, (f, p) in enumerate(zip(fused, plain)):
+        assert (f == p).all(), f"decode step {s}: {(f != p).sum()} of {f.size} values differ between the fused and the per-op route"
+    for f, p in zip(fk, pk):
+        assert (f == p).all()
+    ctx.close()
+
+
+def test_chain_hint_is_ignored_when_the_next_call_takes_another_input():
+    """the promise of lia_ctx_chain_next_norm is checked, not trusted: a following call on a different x computes its own LN1"""
+    import torch
+    from lia_amd import _native as N, ops
+    _knobs().lia_gemm_set_fuse_combine(1)
+    B, H, heads, F, T = 16, 1024, 8, 4096, 4
+    ctx = ops.Context(0, 1 << 30)
+    la = _layer_setup(torch, ops, synth.make_layer(21, H, F, 0.05), H, heads, F)
+    lb = _layer_setup(torch, ops, synth.make_layer(22, H, F, 0.05), H, heads, F)
+    d = H // heads
+
+    def cache():
+        kc = torch.zeros((T + 2, B, heads, d), dtype=torch.bfloat16, device="cuda")
+        return kc, torch.zeros_like(kc)
+
+    def step(chain, other_x):
+        (ka, va), (kb, vb) = cache(), cache()
+        kva, kvb = N.KV(ka.data_ptr(), va.data_ptr(), T + 2, B, 1), N.KV(kb.data_ptr(), vb.data_ptr(), T + 2, B, 1)
+        x = to_dev(torch, synth.make_hidden(5, B, 1, H))
+        y, z = torch.empty_like(x), torch.empty_like(x)
+        if chain:
+            ctx.chain_next_norm(lb[2][0], lb[2][1])
+        ctx.layer_forward(la[0], 3, la[2], x, y, kva, B, 1, 0)
+        src = to_dev(torch, synth.make_hidden(6, B, 1, H)) if other_x else y
+        ctx.layer_forward(lb[0], 3, lb[2], src, z, kvb, B, 1, 0)
+        ctx.synchronize()
+        return to_bits(z).copy()
+
+    assert (step(True, True) == step(False, True)).all()
+    assert (step(True, False) == step(False, False)).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("B,H,heads,kvh,F", [(16, 1024, 8, 2, 2816), (128, 2048, 16, 4, 5632), (40, 1024, 8, 8, 3072)])
+def test_llama_decode_layers_fused_equals_unfused(B, H, heads, kvh, F):
+    """q|k|v in one GEMM with RoPE in its combine, RMSNorm in the o-proj combine, SiLU*up in the gate|up combine, the next
+    layer's input RMSNorm chained into down-proj's: ids of the outputs and the post-RoPE K cache, bit for bit."""
+    import torch
+    from lia_amd import _native as N, ops
+    from lia_amd.llama import LiaLlamaModel, LlamaShape, rope_tables
+    lib = _knobs()
+    T, new, L = 6, 3, 2
+    m = synth.make_llama_model(7, 64, H, heads, kvh, F, L, 0.05)
+    shape = LlamaShape("t", H, heads, kvh, F, L, 64, max_pos=T + new + 4, rope_theta=10000.0)
+    model = LiaLlamaModel.from_numpy(shape, m)
+    model.place(L, True, False)
+    d = H // heads
+    ctx = ops.Context(0, max(lib.lia_llama_workspace_bytes(ctypes.byref(model.desc), B * T), 1 << 26))
+    cos, sin = rope_tables(T + new + 4, d, shape.rope_theta)
+    ws = [(ctypes.c_void_p * 9)(*[model.layers[i].device_ptr() + o for o in model.offsets]) for i in range(L)]
+
+    def call(w, x, y, kv, Tn, pos0):
+        N.check(lib.lia_llama_layer_forward(ctx.handle, ctypes.byref(model.desc), ctypes.byref(w), ctypes.c_void_p(x.data_ptr()),
+                                            ctypes.c_void_p(y.data_ptr()), ctypes.byref(kv), ctypes.c_void_p(cos.data_ptr()),
+                                            ctypes.c_void_p(sin.data_ptr()), B, Tn, pos0, 0, ctypes.c_void_p(ctx.stream)))
+
+    def run(fused):
+        lib.lia_gemm_set_fuse_combine(1 if fused else 0)
+        keep, kvs = [], []
+        for _ in range(L):
+            kc = torch.zeros((T + new, B, kvh, d), dtype=torch.bfloat16, device="cuda")
+            vc = torch.zeros_like(kc)
+            keep.append((kc, vc))
+            kvs.append(N.KV(kc.data_ptr(), vc.data_ptr(), T + new, B, 1))
+        a = to_dev(torch, synth.make_hidden(3, B, T, H))
+        b = torch.empty_like(a)
+        for w, kv in zip(ws, kvs):
+            call(w, a, b, kv, T, 0)
+            a, b = b, a
+        outs = []
+        for s in range(new):
+            a = to_dev(torch, synth.make_hidden(100 + s, B, 1, H))
+            b = torch.empty_like(a)
+            for i, (w, kv) in enumerate(zip(ws, kvs)):
+                if fused and i + 1 < L:
+                    ctx.chain_next_norm(ws[i + 1][0])
+                call(w, a, b, kv, 1, T + s)
+                a, b = b, a
+            ctx.synchronize()
+            outs.append(to_bits(a).copy())
+        return outs, [(to_bits(k).copy(), to_bits(v).copy()) for k, v in keep]
+
+    before = [lib.lia_gemm_fused_combine_count(k) for k in (RMS, SILU, ROPE)]
+    fused, fkv = run(True)
+    after = [lib.lia_gemm_fused_combine_count(k) for k in (RMS, SILU, ROPE)]
+    plain, pkv = run(False)
+    lib.lia_gemm_set_fuse_combine(1)
+    ran = [a - b for a, b in zip(after, before)]
+    assert ran[0] >= 3 * new and ran[1] >= 2 * new and ran[2] >= 2 * new, f"fused combines that ran (rmsnorm, silu, rope): {ran}"
+    for s, (f, p) in enumerate(zip(fused, plain)):
+        assert (f == p).all(), f"decode step {s}: {(f != p).sum()} of {f.size} values differ"
+    for (fk, fv), (pk, pv) in zip(fkv, pkv):
+        assert (fk == pk).all() and (fv == pv).all()
+    ctx.close()
+    model.close()

@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
       LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
       for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemsetAsync(sp, 0, 8192 * 8 * 8, st));
-        lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, e0, e1, nullptr);
+        lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, e0, e1, nullptr, nullptr, nullptr);
       }
       CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
       LiaEpilogue ep{bias, res, sh.N, 0};
       LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
       lia_gemm_set_tiled_variant(atoi(getenv("T4STAMPS")));
-      for (int rep = 0; rep < 3; ++rep) lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr);
+      for (int rep = 0; rep < 3; ++rep) lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
       CK(hipStreamSynchronize(st));
       const int nwg = std::min(8192, ((M + 255) / 256) * ((sh.N + 255) / 256));
       std::vector<unsigned long long> h(8192 * 8);
@@ -111,7 +111,7 @@ int main(int argc, char** argv) {
     LiaEpilogue ep{bias, res, sh.N, 0};
     LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
     lia_gemm_set_tiled_variant(257);
-    for (int rep = 0; rep < 2; ++rep) lia_gemm_launch(x, sh.K, w[0], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr);
+    for (int rep = 0; rep < 2; ++rep) lia_gemm_launch(x, sh.K, w[0], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
     CK(hipStreamSynchronize(st));
     std::vector<unsigned long long> h(2 * 4096);
     CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_t3_stamps), h.size() * 8));
@@ -135,9 +135,9 @@ int main(int argc, char** argv) {
       LiaOutMap om; memset(&om, 0, sizeof(om)); om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
       for (int rep = 0; rep < 3; ++rep) {
         om.base[0] = y; lia_gemm_set_tiled_variant(256);
-        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr);
+        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
         om.base[0] = y2; lia_gemm_set_tiled_variant(getenv("VARIANT") ? atoi(getenv("VARIANT")) : 257);
-        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr);
+        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
         CK(hipStreamSynchronize(st));
         size_t n = (size_t)M * s.N; h1.resize(n); h2.resize(n);
         CK(hipMemcpy(h1.data(), y, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), y2, n * 2, hipMemcpyDeviceToHost));
@@ -155,10 +155,10 @@ int main(int argc, char** argv) {
     LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
     const int iters = M > 256 ? 4 : 12;
     const long ldp = getenv("LDPAD") ? atol(getenv("LDPAD")) : 0;   // row stride = K + LDPAD elements (aliasing experiment)
-    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr);
+    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, nullptr, nullptr);
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
-    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr);
+    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, nullptr, nullptr);
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     double bytes = 2.0 * ((double)s.N * s.K + (double)M * s.K + (double)M * s.N);
