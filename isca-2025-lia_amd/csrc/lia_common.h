@@ -103,34 +103,42 @@ struct LiaPost {
   int rot_heads, hd, pos0, T;
 };
 
-// sum over the 256 threads of a workgroup, the same value in every thread (red: 4 floats of LDS, used once per call)
-__device__ __forceinline__ float block_sum256(float v, float* red) {
+// sum over the LIA_ROW_THREADS threads of a workgroup, the same value in every thread (red: LIA_ROW_WAVES floats of LDS, used
+// once per call); the wave totals are added in wave order
+#define LIA_ROW_WAVES 16
+#define LIA_ROW_THREADS (64 * LIA_ROW_WAVES)
+__device__ __forceinline__ float block_sum_row(float v, float* red) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  float t = red[0];
+#pragma unroll
+  for (int w = 1; w < LIA_ROW_WAVES; ++w) t += red[w];
+  return t;
 }
 
-// One row per 256-thread workgroup; thread t holds the 8-value pieces t, t + 256, ... (packed bf16) of the row.
+// One row per LIA_ROW_THREADS-thread workgroup (16 waves: the row ops of a decode step are pure latency, and a combine that
+// reads 8 slabs x 28 KB per row wants every load of the row in flight at once); thread t holds the 8-value pieces
+// t, t + LIA_ROW_THREADS, ... (packed bf16) of the row.
 // LayerNorm as torch.nn.functional.layer_norm on bf16: statistics in fp32 (two passes over the registers), one rounding.
 template <int NV>
-__device__ __forceinline__ void row_layernorm256(const uint4 (&v)[NV], const uint4 (&gv)[NV], const uint4 (&bv)[NV], int nv, int H,
-                                                 float eps, bf16_t* __restrict__ yr, float* red /* 8 floats */) {
+__device__ __forceinline__ void row_layernorm_block(const uint4 (&v)[NV], const uint4 (&gv)[NV], const uint4 (&bv)[NV], int nv, int H,
+                                                 float eps, bf16_t* __restrict__ yr, float* red /* 2 x LIA_ROW_WAVES floats */) {
   const int tid = threadIdx.x;
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    if (tid + 256 * k < nv) {
+    if (tid + LIA_ROW_THREADS * k < nv) {
       const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) s += bf2f(w[j] & 0xffff) + bf2f(w[j] >> 16);
     }
   }
-  const float mean = block_sum256(s, red) / (float)H;
+  const float mean = block_sum_row(s, red) / (float)H;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    if (tid + 256 * k < nv) {
+    if (tid + LIA_ROW_THREADS * k < nv) {
       const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -139,10 +147,10 @@ __device__ __forceinline__ void row_layernorm256(const uint4 (&v)[NV], const uin
       }
     }
   }
-  const float rstd = 1.0f / sqrtf(block_sum256(q, red + 4) / (float)H + eps);
+  const float rstd = 1.0f / sqrtf(block_sum_row(q, red + LIA_ROW_WAVES) / (float)H + eps);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = tid + 256 * k;
+    const int i = tid + LIA_ROW_THREADS * k;
     if (i < nv) {
       const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w},
                      bw[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
@@ -160,22 +168,22 @@ __device__ __forceinline__ void row_layernorm256(const uint4 (&v)[NV], const uin
 
 // LlamaRMSNorm.forward: y = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) )
 template <int NV>
-__device__ __forceinline__ void row_rmsnorm256(const uint4 (&v)[NV], const uint4 (&gv)[NV], int nv, int H, float eps,
-                                               bf16_t* __restrict__ yr, float* red /* 4 floats */) {
+__device__ __forceinline__ void row_rmsnorm_block(const uint4 (&v)[NV], const uint4 (&gv)[NV], int nv, int H, float eps,
+                                               bf16_t* __restrict__ yr, float* red /* LIA_ROW_WAVES floats */) {
   const int tid = threadIdx.x;
   float ss = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    if (tid + 256 * k < nv) {
+    if (tid + LIA_ROW_THREADS * k < nv) {
       const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float a = bf2f(u[j] & 0xffff), c = bf2f(u[j] >> 16); ss += a * a + c * c; }
     }
   }
-  const float rstd = 1.0f / sqrtf(block_sum256(ss, red) / (float)H + eps);
+  const float rstd = 1.0f / sqrtf(block_sum_row(ss, red) / (float)H + eps);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = tid + 256 * k;
+    const int i = tid + LIA_ROW_THREADS * k;
     if (i < nv) {
       const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
       uint32_t o[4];

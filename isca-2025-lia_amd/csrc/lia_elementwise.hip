@@ -109,27 +109,27 @@ __global__ __launch_bounds__(256) void lia_layernorm_reg_kernel(const bf16_t* __
   }
 }
 
-// Decode-sized inputs (a few hundred rows): one 256-thread workgroup per row instead of one wave -- four times the loads in
-// flight per row and four times the CUs (64 rows of OPT-30B: 10.6 -> ~5 us, the kernel is pure latency), and the same
-// device function (row_layernorm256) the fused split-K combine of lia_gemm.hip runs, so both routes give the same bits.
+// Decode-sized inputs (a few hundred rows): one 1024-thread workgroup per row instead of one wave -- every load of the row in
+// flight at once and four times the CUs (64 rows of OPT-30B: 10.6 -> 4.4 us, the kernel is pure latency), and the same
+// device function (row_layernorm_block) the fused split-K combine of lia_gemm.hip runs, so both routes give the same bits.
 template <int NV>
-__global__ __launch_bounds__(256) void lia_layernorm_row_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ g,
+__global__ __launch_bounds__(LIA_ROW_THREADS) void lia_layernorm_row_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ g,
                                                                  const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
                                                                  int H, float eps) {
-  __shared__ float red[8];
+  __shared__ float red[2 * LIA_ROW_WAVES];
   const long row = blockIdx.x;
   const bf16_t* xr = x + row * ldx;
   const int nv = H >> 3;
   uint4 v[NV], gv[NV], bv[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = threadIdx.x + 256 * k;
+    const int i = threadIdx.x + LIA_ROW_THREADS * k;
     const bool in = i < nv;
     v[k] = in ? *(const uint4*)(xr + 8 * i) : uint4{0u, 0u, 0u, 0u};
     gv[k] = in ? *(const uint4*)(g + 8 * i) : uint4{0u, 0u, 0u, 0u};
     bv[k] = in ? *(const uint4*)(b + 8 * i) : uint4{0u, 0u, 0u, 0u};
   }
-  row_layernorm256<NV>(v, gv, bv, nv, H, eps, y + row * ldy, red);
+  row_layernorm_block<NV>(v, gv, bv, nv, H, eps, y + row * ldy, red);
 }
 
 #define LIA_ROW_NORM_MAX_ROWS 1024
@@ -137,14 +137,10 @@ __global__ __launch_bounds__(256) void lia_layernorm_row_kernel(const bf16_t* __
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st) {
   if (rows <= 0) return;
-  if (rows <= LIA_ROW_NORM_MAX_ROWS && (H & 7) == 0 && (H >> 3) <= 256 * 8) {
-    const int nvt = ((H >> 3) + 255) / 256;
-    const dim3 grid((unsigned)rows), block(256);
-    if (nvt <= 1) hipLaunchKernelGGL(lia_layernorm_row_kernel<1>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
-    else if (nvt <= 2) hipLaunchKernelGGL(lia_layernorm_row_kernel<2>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
-    else if (nvt <= 4) hipLaunchKernelGGL(lia_layernorm_row_kernel<4>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
-    else if (nvt <= 6) hipLaunchKernelGGL(lia_layernorm_row_kernel<6>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
-    else hipLaunchKernelGGL(lia_layernorm_row_kernel<8>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
+  if (rows <= LIA_ROW_NORM_MAX_ROWS && (H & 7) == 0 && (H >> 3) <= LIA_ROW_THREADS * 2) {
+    const dim3 grid((unsigned)rows), block(LIA_ROW_THREADS);
+    if ((H >> 3) <= LIA_ROW_THREADS) hipLaunchKernelGGL(lia_layernorm_row_kernel<1>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
+    else hipLaunchKernelGGL(lia_layernorm_row_kernel<2>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
     return;
   }
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);

@@ -87,9 +87,9 @@ __device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ partial, i
 // LAYERNORM / RMSNORM: one workgroup per output row; the row is combined, finished (bias / residual), stored, and normalised
 // from registers into post.out -- the out-proj / fc2 (o / down) combine and the norm kernel behind it in one launch.
 template <int KIND, int NV>
-__global__ __launch_bounds__(256) void lia_splitk_reduce_norm_kernel(const float* __restrict__ partial, int S, int M, int N,
+__global__ __launch_bounds__(LIA_ROW_THREADS) void lia_splitk_reduce_norm_kernel(const float* __restrict__ partial, int S, int M, int N,
                                                                       LiaEpilogue ep, LiaOutMap om, LiaPost post) {
-  __shared__ float red[8];
+  __shared__ float red[2 * LIA_ROW_WAVES];
   const int m = blockIdx.x, tid = threadIdx.x;
   const int nv = N >> 3;
   uint4 v[NV], gv[NV], bv[NV];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_norm_kernel(const float
   const float* prow = partial + (long)m * N;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = min(tid + 256 * k, nv - 1);          // (clamped: idle lanes re-read the last piece and drop it)
+    const int i = min(tid + LIA_ROW_THREADS * k, nv - 1);          // (clamped: idle lanes re-read the last piece and drop it)
     gv[k] = *(const uint4*)(post.g + 8 * i);
     if (KIND == LIA_POST_LAYERNORM) bv[k] = *(const uint4*)(post.b + 8 * i);
     acc[k][0] = *(const f32x4*)(prow + 8 * i);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_norm_kernel(const float
     f32x4 t[NV][2];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int i = min(tid + 256 * k, nv - 1);
+      const int i = min(tid + LIA_ROW_THREADS * k, nv - 1);
       t[k][0] = *(const f32x4*)(ps + 8 * i);
       t[k][1] = *(const f32x4*)(ps + 8 * i + 4);
     }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_norm_kernel(const float
   }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = tid + 256 * k;
+    const int i = tid + LIA_ROW_THREADS * k;
     v[k] = uint4{0u, 0u, 0u, 0u};
     if (i < nv) {
       const f32x4 lo = epilogue_quad(acc[k][0], m, 8 * i, ep);
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_norm_kernel(const float
     }
   }
   bf16_t* yr = post.out + (long)m * post.ldo;
-  if (KIND == LIA_POST_LAYERNORM) row_layernorm256<NV>(v, gv, bv, nv, N, post.eps, yr, red);
-  else row_rmsnorm256<NV>(v, gv, nv, N, post.eps, yr, red);
+  if (KIND == LIA_POST_LAYERNORM) row_layernorm_block<NV>(v, gv, bv, nv, N, post.eps, yr, red);
+  else row_rmsnorm_block<NV>(v, gv, nv, N, post.eps, yr, red);
 }
 
 // SILU_MUL: the gate | up projection's combine writes act = silu(gate) * up directly; the [M][2F] intermediate never exists.
@@ -1137,16 +1137,12 @@ static bool launch_fused_combine(const float* ws, int split, int M, int N, const
                                  hipStream_t st) {
   if (!g_fuse_combine) return false;
   if (post.kind == LIA_POST_LAYERNORM || post.kind == LIA_POST_RMSNORM) {
-    if (om.seg_n != N || om.cache_mode[0] || (N & 7) || (N >> 3) > 256 * 8 || (om.ld[0] & 7) || (post.ldo & 7) || !post.g || !post.out) return false;
+    if (om.seg_n != N || om.cache_mode[0] || (N & 7) || (N >> 3) > LIA_ROW_THREADS * 2 || (om.ld[0] & 7) || (post.ldo & 7) || !post.g || !post.out) return false;
     if (post.kind == LIA_POST_LAYERNORM && !post.b) return false;
-    const int nvt = ((N >> 3) + 255) / 256;
 #define LIA_NORM_COMBINE(K)                                                                                                            \
     do {                                                                                                                               \
-      if (nvt <= 1) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 1>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post);      \
-      else if (nvt <= 2) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 2>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post); \
-      else if (nvt <= 4) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 4>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post); \
-      else if (nvt <= 6) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 6>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post); \
-      else hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 8>), dim3(M), dim3(256), 0, st, ws, split, M, N, ep, om, post);               \
+      if ((N >> 3) <= LIA_ROW_THREADS) hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 1>), dim3(M), dim3(LIA_ROW_THREADS), 0, st, ws, split, M, N, ep, om, post); \
+      else hipLaunchKernelGGL((lia_splitk_reduce_norm_kernel<K, 2>), dim3(M), dim3(LIA_ROW_THREADS), 0, st, ws, split, M, N, ep, om, post);                              \
     } while (0)
     if (post.kind == LIA_POST_LAYERNORM) LIA_NORM_COMBINE(LIA_POST_LAYERNORM); else LIA_NORM_COMBINE(LIA_POST_RMSNORM);
 #undef LIA_NORM_COMBINE
@@ -1217,6 +1213,11 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     if (rt == 1) {
       const int BN = 16 * WAVES;
       int tiles = (N + BN - 1) / BN;
+      // ... unless K is long: with >= 24 chunks per slice at eight slices the one-block workgroups (every weight byte read once)
+      // finish sooner than the two-block ones (Llama-3-8B down-proj, K = 14336, B = 128: 41.4 -> 37.7 us with the combine)
+      const bool long_k = M > 64 && M <= 128 && force_split <= 0 && tiles * 8 <= 256 && nchunks / 8 >= 24 && g_skinny_variant == 0 &&
+                          (size_t)8 * M * N * sizeof(float) <= workspace_bytes;
+      if (long_k) force_split = 8;
       if (M > 64 && M <= 128 && force_split <= 0 && (tiles * 4 <= 256 || g_skinny_variant == 3) && g_skinny_variant != 4) {
         mcut = true;
         tiles *= 2;

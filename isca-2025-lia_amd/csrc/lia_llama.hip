@@ -73,35 +73,31 @@ __global__ __launch_bounds__(256) void lia_rmsnorm_reg_kernel(const bf16_t* __re
   }
 }
 
-// decode-sized inputs: one workgroup per row (see lia_layernorm_row_kernel), the arithmetic of row_rmsnorm256
+// decode-sized inputs: one workgroup per row (see lia_layernorm_row_kernel), the arithmetic of row_rmsnorm_block
 template <int NV>
-__global__ __launch_bounds__(256) void lia_rmsnorm_row_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(LIA_ROW_THREADS) void lia_rmsnorm_row_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                                bf16_t* __restrict__ y, long ldy, int H, float eps) {
-  __shared__ float red[4];
+  __shared__ float red[LIA_ROW_WAVES];
   const long row = blockIdx.x;
   const bf16_t* xr = x + row * ldx;
   const int nv = H >> 3;
   uint4 v[NV], gv[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = threadIdx.x + 256 * k;
+    const int i = threadIdx.x + LIA_ROW_THREADS * k;
     const bool in = i < nv;
     v[k] = in ? *(const uint4*)(xr + 8 * i) : uint4{0u, 0u, 0u, 0u};
     gv[k] = in ? *(const uint4*)(w + 8 * i) : uint4{0u, 0u, 0u, 0u};
   }
-  row_rmsnorm256<NV>(v, gv, nv, H, eps, y + row * ldy, red);
+  row_rmsnorm_block<NV>(v, gv, nv, H, eps, y + row * ldy, red);
 }
 
 extern "C" void lia_rmsnorm_launch(const bf16_t* x, long ldx, const bf16_t* w, bf16_t* y, long ldy, long rows, int H, float eps,
                                    hipStream_t st) {
-  if (rows > 0 && rows <= 1024 && (H & 7) == 0 && (H >> 3) <= 256 * 8) {
-    const int nvt = ((H >> 3) + 255) / 256;
-    const dim3 grid((unsigned)rows), block(256);
-    if (nvt <= 1) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<1>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
-    else if (nvt <= 2) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<2>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
-    else if (nvt <= 4) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<4>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
-    else if (nvt <= 6) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<6>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
-    else hipLaunchKernelGGL(lia_rmsnorm_row_kernel<8>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
+  if (rows > 0 && rows <= 1024 && (H & 7) == 0 && (H >> 3) <= LIA_ROW_THREADS * 2) {
+    const dim3 grid((unsigned)rows), block(LIA_ROW_THREADS);
+    if ((H >> 3) <= LIA_ROW_THREADS) hipLaunchKernelGGL(lia_rmsnorm_row_kernel<1>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
+    else hipLaunchKernelGGL(lia_rmsnorm_row_kernel<2>, grid, block, 0, st, x, ldx, w, y, ldy, H, eps);
     return;
   }
   if (rows <= 0) return;
