@@ -405,6 +405,10 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
 // read from HBM once.  LPK = D/8 lanes share one key row (16 bytes each); scores are parked in LDS, then every
 // thread accumulates its 8 output dims over its share of the keys and the shares are combined through LDS.
 // ---------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
 template <int D, int G>
 __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __restrict__ q, long ldq,
                                                                const bf16_t* __restrict__ kc,
@@ -460,8 +464,19 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lia_bf16x2, qp[g][e]), __builtin_bit_cast(lia_bf16x2, w[e]), a, false);
+        if constexpr (LPK == 16) {
+          // the 16 lanes of a key are one DPP row: the sum over them with row rotations / quad permutes as VALU operand
+          // modifiers instead of four ds_bpermute_b32 per value (PMC, Llama-3-8B B 128: the LDS pipe was ~77 % busy with them).
+          // Rotating by 8 and 4 instead of xor 8, 4 picks a partner that holds the same partial (same lane index mod 8 resp.
+          // mod 4), so every lane still ends with ((p_l + p_l^8) + (p_l^4 + p_l^12)) + ...: the bits of the xor butterfly.
+          a += dpp_f32<0x128>(a);     // row_ror:8
+          a += dpp_f32<0x124>(a);     // row_ror:4
+          a += dpp_f32<0x4E>(a);      // quad_perm:[2,3,0,1]  (xor 2)
+          a += dpp_f32<0xB1>(a);      // quad_perm:[1,0,3,2]  (xor 1)
+        } else {
 #pragma unroll
-        for (int o = LPK / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+          for (int o = LPK / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        }
         if (j < S) {
           float sv = rbf(a);
           if (post_scale) sv = rbf(sv * scaling);

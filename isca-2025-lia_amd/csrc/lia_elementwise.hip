@@ -1,5 +1,6 @@
 // Row-wise / gather kernels of the LIA hot path (HBM-bound, 16-byte vector accesses everywhere):
 // LayerNorm, token+position embedding, last-position gather, greedy argmax.
+#include <cstdlib>
 #include "lia_common.h"
 
 // F.layer_norm on a bf16 tensor (decoder.py:107-119; final LN lia/modeling_opt.py:1563): statistics and
@@ -132,12 +133,13 @@ __global__ __launch_bounds__(LIA_ROW_THREADS) void lia_layernorm_row_kernel(cons
   row_layernorm_block<NV>(v, gv, bv, nv, H, eps, y + row * ldy, red);
 }
 
-#define LIA_ROW_NORM_MAX_ROWS 1024
+// up to this many rows the workgroup-per-row kernel is used (LIA_ROW_NORM_MAX_ROWS overrides: tools/norm_bench.py)
+static long g_row_norm_max_rows = [] { const char* e = getenv("LIA_ROW_NORM_MAX_ROWS"); return e ? atol(e) : 1024L; }();
 
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st) {
   if (rows <= 0) return;
-  if (rows <= LIA_ROW_NORM_MAX_ROWS && (H & 7) == 0 && (H >> 3) <= LIA_ROW_THREADS * 2) {
+  if (rows <= g_row_norm_max_rows && (H & 7) == 0 && (H >> 3) <= LIA_ROW_THREADS * 2) {
     const dim3 grid((unsigned)rows), block(LIA_ROW_THREADS);
     if ((H >> 3) <= LIA_ROW_THREADS) hipLaunchKernelGGL(lia_layernorm_row_kernel<1>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
     else hipLaunchKernelGGL(lia_layernorm_row_kernel<2>, grid, block, 0, st, x, ldx, g, b, y, ldy, H, eps);
