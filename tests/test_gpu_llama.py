@@ -84,3 +84,37 @@ def test_llama_generate_ids_match_hf(gpu_pct, mb, fmt, monkeypatch):
         assert all(st.packed == 10 for st in model.layers[n_gpu:])      # the streamed layers really travel encoded
     model._lia_scheduler.close()
     model.close()
+
+
+@pytest.mark.parametrize("B,S,kvh", [(3, 1, 2), (5, 127, 2), (2, 128, 1), (16, 129, 2), (128, 1037, 8), (7, 2050, 3)])
+def test_grouped_decode_attention_d128(B, S, kvh):
+    """lia_attn_decode_kernel<128, 4> (four query heads per K/V head, the DPP row sum of q.k) at sizes up to Llama-3-8B's decode
+    step, against a plain fp32 restatement of HF's eager grouped attention at one query position."""
+    import torch
+    from lia_amd import _native as N, ops
+    lib = N.lib()
+    vp, ci, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+    lib.lia_attn_decode_launch.argtypes = [vp, cl, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.lia_attn_decode_launch.restype = ci
+    ctx = ops.Context(0, 1 << 20)
+    G, d = 4, 128
+    heads = kvh * G
+    g = torch.Generator(device="cuda").manual_seed(B * 977 + S)
+    q = (1.5 * torch.randn((B, heads * d), generator=g, device="cuda")).to(torch.bfloat16)
+    kc = (1.5 * torch.randn((S + 3, B, kvh, d), generator=g, device="cuda")).to(torch.bfloat16)
+    vc = torch.randn((S + 3, B, kvh, d), generator=g, device="cuda").to(torch.bfloat16)
+    out = torch.zeros_like(q)
+    torch.cuda.synchronize()          # torch filled q / k / v / out on ITS stream; the kernel runs on the context's
+    rc = lib.lia_attn_decode_launch(q.data_ptr(), heads * d, kc.data_ptr(), vc.data_ptr(), out.data_ptr(), heads * d, B, S, heads, kvh, d,
+                                    B, 0, 1, ctypes.c_void_p(ctx.stream))
+    assert rc == 0
+    ctx.synchronize()
+    # post_scale = 1 (Llama): scores = bf16(bf16(q.k) * d^-0.5), softmax in fp32 rounded to bf16, P.V rounded to bf16
+    qf = q.float().view(B, kvh, G, d)
+    kf, vf = kc[:S].float().permute(1, 2, 0, 3), vc[:S].float().permute(1, 2, 0, 3)          # [B, kvh, S, d]
+    s = torch.einsum("bhgd,bhsd->bhgs", qf, kf).to(torch.bfloat16).float() * (d ** -0.5)
+    p = torch.softmax(s.to(torch.bfloat16).float(), dim=-1).to(torch.bfloat16).float()
+    ref = torch.einsum("bhgs,bhsd->bhgd", p, vf).reshape(B, heads * d)
+    err = (out.float() - ref).abs()
+    assert float(err.max()) <= 0.02 + 0.016 * float(ref.abs().max()), float(err.max())
+    ctx.close()
