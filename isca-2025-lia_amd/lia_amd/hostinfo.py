@@ -46,6 +46,19 @@ def default_host_threads(world=1):
     return max(1, n // max(1, world))
 
 
+def cap_torch_threads(n=None):
+    """torch sizes its intra-op thread pool by the CPUs it SEES (128 on the GPU box) -- not by the cgroup quota (16 there).  The
+    few CPU tensor ops of the token loop (torch.cat of the ids, greedy_search.py:408) then start a 128-thread team that the quota
+    serialises: measured 0.4 - 39 ms per decode step for a 1 MB cat, against 30 us on one thread.  The reference runs under
+    OMP_NUM_THREADS=40 (README.md:78), which bounds that pool too; this is the same bound from the box's own numbers.  Only ever
+    lowers the setting.  Returns the thread count in force."""
+    import torch
+    n = n or default_host_threads(1)
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def node_cpus(node):
     """CPU ids of a NUMA node (sysfs cpulist), or None"""
     try:

@@ -180,6 +180,8 @@ class LlamaScheduler:
             if self.ctx:
                 self.ctx.close()
             self.ctx = ops.Context(self.device, need)
+            from . import hostinfo
+            hostinfo.cap_torch_threads()      # the token loop's CPU tensor ops: see hostinfo.cap_torch_threads
         if self.pipe is None and n_gpu < sh.layers:
             self.pipe = WeightPipeline(self.ctx, self.model, self.n_slots)
         if self.tables is None or self.tables[0].shape[0] < smax:

@@ -324,6 +324,7 @@ class OffloadScheduler:
             if not getattr(self, "host_threads", None):
                 self.host_threads = hostinfo.default_host_threads(self.dp.world if self.dp else 1)
             self.ctx.set_host_threads(self.host_threads)
+            hostinfo.cap_torch_threads(self.host_threads)     # torch's own CPU ops of the token loop obey the same bound
         if self.pipe is None and n_gpu < sh.layers:
             self.pipe = WeightPipeline(self.ctx, self.model, self.n_slots, self.dp)
         key = (B, T)

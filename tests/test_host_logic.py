@@ -158,3 +158,17 @@ def test_planner_gpu_share_cap_and_model_shape_of_a_packed_directory(tmp_path):
     args = run_generation.build_parser().parse_args(["-m", str(d)])
     sh = run_generation.model_shape(args)
     assert (sh.hidden, sh.heads, sh.ffn, sh.layers, sh.vocab, sh.max_pos) == (512, 4, 2048, 3, 100, 32)
+
+
+def test_cap_torch_threads_only_lowers():
+    """hostinfo.cap_torch_threads: torch's intra-op pool follows the cgroup quota / the caller's bound, never grows"""
+    import torch
+    from lia_amd import hostinfo
+    before = torch.get_num_threads()
+    try:
+        assert hostinfo.cap_torch_threads(before + 7) == before           # a larger bound changes nothing
+        got = hostinfo.cap_torch_threads(1)
+        assert got == 1 and torch.get_num_threads() == 1
+        assert hostinfo.cap_torch_threads(4) == 1                          # and it is never raised again
+    finally:
+        torch.set_num_threads(before)
