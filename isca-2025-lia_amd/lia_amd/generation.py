@@ -78,7 +78,12 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         host_layers = OffloadScheduler.cpu_layer_set(n_gpu, L, lia["cpu_layers"]) if (on_dev and lia.get("cpu_layers")) else ()
         kv = KVState(model, n_gpu, B, T + max_new_tokens, all_on_device=on_dev, host_layers=host_layers)
     unfinished = torch.ones(B, dtype=torch.int64)
+    all_unfinished = True
     latency_list, logits_list = [], []
+    # the ids grow in place (greedy_search.py:408 re-allocates [B, T + t] with torch.cat every step: 1 MB per step at
+    # B 128 x T 1024, on the critical path between two decode steps)
+    ids_buf = torch.empty((B, T + max_new_tokens), dtype=torch.int64)
+    ids_buf[:, :T] = ids
     cur = ids
     step = 0
     while True:
@@ -89,19 +94,23 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         suppress = eos_token_id if (eos_token_id is not None and step < min_new_tokens) else -1
         logits, nxt = sched.forward(cur, kv, max_new_tokens=max_new_tokens, suppress_token=suppress, **lia)
         next_tokens = nxt.cpu()
+        same_as_device = eos_token_id is None or all_unfinished        # no row was replaced by the pad token below
         if eos_token_id is not None:
             next_tokens = next_tokens * unfinished + pad_token_id * (1 - unfinished)   # greedy_search.py:398-405
-        ids = torch.cat([ids, next_tokens[:, None]], dim=-1)                           # :408
+        ids_buf[:, T + step] = next_tokens                                             # :408
         if eos_token_id is not None:
             unfinished = unfinished * (next_tokens != eos_token_id).long()             # :415-421
-        cur = next_tokens[:, None]
+            all_unfinished = bool(unfinished.min() == 1)
+        # the next step's input: the argmax output where it already sits in HBM, unless the EOS bookkeeping changed a row
+        cur = nxt.view(B, 1) if (same_as_device and nxt.is_cuda) else next_tokens[:, None]
         step += 1
         if return_logits:
             logits_list.append(logits.clone())
         latency_list.append(time.time() - tic)                                         # :424
-        if unfinished.max() == 0 or step >= max_new_tokens or (max_steps is not None and step >= max_steps):
+        if (eos_token_id is not None and not all_unfinished and unfinished.max() == 0) or step >= max_new_tokens or \
+                (max_steps is not None and step >= max_steps):
             break
-    out = ids
+    out = ids_buf[:, :T + step].clone() if step < max_new_tokens else ids_buf
     if return_logits:
         return out, latency_list, logits_list
     if token_latency:
