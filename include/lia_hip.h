@@ -162,11 +162,15 @@ int lia_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const
 /* ---- Llama-family layer (BASELINE.json config 4; build-defined: the reference's LlamaDecoderLayer_forward,
  * decoder.py:121-169, has no policy plumbing -- SURVEY.md quirk 3).  Arithmetic = HF transformers' eager bf16 Llama.
  * weights[9]: 0 input_norm.w  1 q.w [h*d,H]  2 k.w [kvh*d,H]  3 v.w  4 o.w [H,h*d]  5 post_norm.w  6 gate.w [F,H]
- * 7 up.w [F,H]  8 down.w [H,F]; k|v and gate|up adjacent in the packed layout.  KV cache on the device, seq-major
- * [smax][batch][kv_heads][head_dim], post-RoPE keys.  cos/sin: [max_pos][head_dim] bf16 tables. */
+ * 7 up.w [F,H]  8 down.w [H,F]; q|k|v and gate|up adjacent in the packed layout.  KV cache on the device, seq-major
+ * [smax][batch][kv_heads][head_dim], post-RoPE keys.  cos/sin: [max_pos][head_dim] bf16 tables.
+ * gu_block: 0 = gate.w and up.w as they are; 32 (and weights[7] == weights[6] + F*H, ffn % 32 == 0) = the 2F rows of the
+ * gate|up block are interleaved, 32 gate rows then the matching 32 up rows -- a 64-column tile of the projection then holds
+ * both factors of 32 outputs and the prefill GEMM's epilogue writes silu(gate) * up itself. */
 typedef struct {
   int hidden, heads, kv_heads, ffn;
   float rms_eps;
+  int gu_block;
 } lia_llama_desc;
 int lia_llama_pack_offsets(const lia_llama_desc* d, size_t offsets[9], size_t* total_bytes);
 size_t lia_llama_workspace_bytes(const lia_llama_desc* d, int max_rows);

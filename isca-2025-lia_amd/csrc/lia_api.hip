@@ -694,7 +694,7 @@ extern "C" void lia_rmsnorm_launch(const bf16_t* x, long ldx, const bf16_t* w, b
                                    hipStream_t st);
 extern "C" void lia_rope_launch(bf16_t* x, long row_stride, const bf16_t* cosb, const bf16_t* sinb, long rows, int heads, int d,
                                 int pos0, int pos_mod, int pos_div, hipStream_t st);
-extern "C" void lia_silu_mul_launch(const bf16_t* gu, bf16_t* out, long M, int F, hipStream_t st);
+extern "C" void lia_silu_mul_launch(const bf16_t* gu, bf16_t* out, long M, int F, int gu_block, hipStream_t st);
 extern "C" void lia_embed_tokens_launch(const int64_t* ids, const bf16_t* tok, bf16_t* y, long rows, int H, hipStream_t st);
 
 static int check_llama_desc(const lia_llama_desc* d) {
@@ -706,6 +706,10 @@ static int check_llama_desc(const lia_llama_desc* d) {
   int hd = d->hidden / d->heads;
   if (!(hd == 32 || hd == 64 || hd == 128) || d->hidden % 128 || d->ffn % 128 || (d->kv_heads * hd) % 16) {
     lia_set_error("llama desc: head_dim %d must be 32/64/128, hidden and ffn multiples of 128", hd);
+    return LIA_ERR_INVALID;
+  }
+  if (d->gu_block != 0 && d->gu_block != LIA_GU_BLOCK) {
+    lia_set_error("llama desc: gu_block %d (0 = gate.w | up.w as they are, %d = interleaved in blocks of %d rows)", d->gu_block, LIA_GU_BLOCK, LIA_GU_BLOCK);
     return LIA_ERR_INVALID;
   }
   return LIA_OK;
@@ -838,7 +842,8 @@ extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, co
   if (fused_gu) {
     LiaOutMap om = plain_out(gu, 2 * F, 2 * F);
     LiaPost post{};
-    post.kind = LIA_POST_SILU_MUL; post.out = act; post.ldo = F;     // decode: act = silu(gate) * up straight from the combine
+    post.kind = LIA_POST_SILU_MUL; post.out = act; post.ldo = F;     // act = silu(gate) * up straight from the combine / the tiled epilogue
+    post.gu_block = d->gu_block;
     rc = gemm_checked(ctx, ln, H, W[6], (int)M, 2 * F, H, none, om, gws, w.gemm_bytes, 0, st, &post, &silu_done);
     if (rc) return rc;
   } else {
@@ -848,7 +853,7 @@ extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, co
       if (rc) return rc;
     }
   }
-  if (!silu_done) lia_silu_mul_launch(gu, act, M, F, st);
+  if (!silu_done) lia_silu_mul_launch(gu, act, M, F, fused_gu ? d->gu_block : 0, st);
   {  // down_proj + residual (+ the next layer's input RMSNorm when the caller chained it)
     LiaEpilogue ep{nullptr, h1, H, 0};
     LiaOutMap om = plain_out(y, H, H);

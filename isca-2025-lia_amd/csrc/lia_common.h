@@ -45,7 +45,10 @@ struct LiaEpilogue {
   const bf16_t* residual;  // [M, ldr] or nullptr
   long ldr;
   int relu;
+  int glu;                 // tiled kernels only: the N columns are blocks of 32 gate | 32 up columns (LIA_GU_BLOCK); the epilogue
+                           // writes silu(gate) * up -- N/2 columns -- to the output map instead of the N raw ones
 };
+#define LIA_GU_BLOCK 32
 
 __device__ __forceinline__ float lia_epilogue_apply(float acc, float bias, bool has_bias, int relu, float res,
                                                     bool has_res) {
@@ -95,8 +98,9 @@ struct LiaPost {
   const bf16_t* g;
   const bf16_t* b;
   float eps;
-  bf16_t* out;          // norm: [M][ldo];  SILU_MUL: act[M][ldo] = silu(y[:, :N/2]) * y[:, N/2:]  (y itself is not written)
+  bf16_t* out;          // norm: [M][ldo];  SILU_MUL: act[M][ldo] = silu(gate) * up  (y itself is not written)
   long ldo;
+  int gu_block;         // SILU_MUL: 0 = columns [gate (N/2) | up (N/2)]; LIA_GU_BLOCK = blocks of 32 gate | 32 up columns
   // ROPE: the first rot_heads heads (width hd) of every output row are rotated at position pos0 + m % T, the rest are plain
   const bf16_t* cos_t;
   const bf16_t* sin_t;

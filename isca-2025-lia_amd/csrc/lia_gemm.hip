@@ -141,8 +141,11 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_silu_kernel(const float
   if (q >= (long)M * (F >> 2)) return;
   const int m = (int)(q / (F >> 2));
   const int c = (int)(q - (long)m * (F >> 2)) * 4;
-  const f32x4 gq = epilogue_quad(splitk_sum(partial, S, M, N, m, c), m, c, ep);
-  const f32x4 uq = epilogue_quad(splitk_sum(partial, S, M, N, m, F + c), m, F + c, ep);
+  // column of gate value c and of its up partner: [gate | up] halves, or blocks of LIA_GU_BLOCK gate | LIA_GU_BLOCK up columns
+  const int ng = post.gu_block ? (c / LIA_GU_BLOCK) * (2 * LIA_GU_BLOCK) + (c % LIA_GU_BLOCK) : c;
+  const int nu = post.gu_block ? ng + LIA_GU_BLOCK : F + c;
+  const f32x4 gq = epilogue_quad(splitk_sum(partial, S, M, N, m, ng), m, ng, ep);
+  const f32x4 uq = epilogue_quad(splitk_sum(partial, S, M, N, m, nu), m, nu, ep);
   uint2 o;
   o.x = lia_silu_mul_pair(pack_bf16x2(gq[0], gq[1]), pack_bf16x2(uq[0], uq[1]));
   o.y = lia_silu_mul_pair(pack_bf16x2(gq[2], gq[3]), pack_bf16x2(uq[2], uq[3]));
@@ -238,6 +241,25 @@ __device__ __forceinline__ void epilogue_via_lds_part(const f32x4 (&acc)[4][MBT]
       const int chunk = (2 * i + (lq >> 1)) ^ (m & 7);
       *(uint2*)(region + m * 128 + chunk * 16 + (lq & 1) * 8) = uint2{o2[0], o2[1]};
     }
+  }
+  if (ep.glu) {
+    // gated-linear-unit output: the wave's 64 columns are 32 gate | 32 up columns of the same 32 outputs (the weight rows are
+    // interleaved in blocks of LIA_GU_BLOCK).  Lanes c < 4 read their gate chunk c and the up chunk c + 4 of a row and store
+    // silu(gate) * up -- the arithmetic of lia_silu_mul_kernel on the same bf16-rounded values -- as 8 of the N / 2 outputs.
+    const int gn_o = (n_base >> 1) + c * 8;
+    int gm = m_base + (lane >> 3);
+#pragma unroll
+    for (int r = 0; r < 2 * MB; ++r) {
+      const int m = r * 8 + (lane >> 3);
+      if (c < 4) {
+        const uint4 gv = *(const uint4*)(region + m * 128 + ((c ^ (m & 7)) << 4));
+        const uint4 uv = *(const uint4*)(region + m * 128 + (((c + 4) ^ (m & 7)) << 4));
+        const uint4 o{lia_silu_mul_pair(gv.x, uv.x), lia_silu_mul_pair(gv.y, uv.y), lia_silu_mul_pair(gv.z, uv.z), lia_silu_mul_pair(gv.w, uv.w)};
+        if (gm < M && gn_o < (N >> 1)) *(uint4*)(om.base[0] + (long)gm * om.ld[0] + gn_o) = o;
+      }
+      gm += 8;
+    }
+    return;
   }
   // where my 8 columns go: segment and column inside it (constant over the rows), cache row of my first tile row
   const int gn = n_base + c * 8;
@@ -1150,7 +1172,7 @@ static bool launch_fused_combine(const float* ws, int split, int M, int N, const
     return true;
   }
   if (post.kind == LIA_POST_SILU_MUL) {
-    if ((N & 7) || (post.ldo & 3) || !post.out) return false;
+    if ((N & 7) || (post.ldo & 3) || !post.out || (post.gu_block && (post.gu_block != LIA_GU_BLOCK || (N % (2 * LIA_GU_BLOCK))))) return false;
     const long nq = (long)M * (N >> 3);
     hipLaunchKernelGGL(lia_splitk_reduce_silu_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, ws, split, M, N, ep, post);
     ++g_fused_combines[post.kind];
@@ -1271,6 +1293,20 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   }
   if ((K % TL_BK) != 0) return -1;
   if (regime) *regime = 2;
+  // the tiled kernels' epilogue writes silu(gate) * up itself when the weight rows are interleaved (LiaEpilogue::glu): the
+  // [M, 2F] intermediate of a prefill (7.5 GB per Llama-3-8B layer at B 128 x T 1024) is never written nor read back
+  LiaEpilogue ep_t = *ep;
+  LiaOutMap om_t = *om;
+  if (post && post_done && g_fuse_combine && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK &&
+      (N % (2 * LIA_GU_BLOCK)) == 0 && post->out && (post->ldo & 7) == 0 && !ep->residual) {
+    ep_t.glu = 1;
+    memset(&om_t, 0, sizeof(om_t));
+    om_t.base[0] = post->out; om_t.ld[0] = post->ldo; om_t.seg_n = N / 2; om_t.T = 1;
+    *post_done = 1;
+    ++g_fused_combines[LIA_POST_SILU_MUL];
+  }
+  ep = &ep_t;
+  om = &om_t;
   if (M >= 1024 && N >= 512 && (g_tiled_variant == 257 || g_tiled_variant == 258)) {
     int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
     static bool attr_set = false;

@@ -177,15 +177,18 @@ extern "C" void lia_rope_launch(bf16_t* x, long row_stride, const bf16_t* cosb, 
 }
 
 // LlamaMLP: act_fn(gate) * up with gate|up side by side in one [M, 2F] buffer: m = bf16( bf16(silu(g)) * u ).
-__global__ __launch_bounds__(256) void lia_silu_mul_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int F) {
+// gu_block = 0: columns [gate (F) | up (F)]; LIA_GU_BLOCK: blocks of 32 gate | 32 up columns (the interleaved weight layout).
+__global__ __launch_bounds__(256) void lia_silu_mul_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int F, int gu_block) {
   const long n8 = M * (F >> 3);
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long stride = (long)gridDim.x * 256;
   for (; i < n8; i += stride) {
     const long m = i / (F >> 3);
     const int c = (int)(i - m * (F >> 3)) * 8;
-    uint4 g = *(const uint4*)(gu + m * 2 * (long)F + c);
-    uint4 u = *(const uint4*)(gu + m * 2 * (long)F + F + c);
+    const int ng = gu_block ? (c / LIA_GU_BLOCK) * (2 * LIA_GU_BLOCK) + (c % LIA_GU_BLOCK) : c;
+    const int nu = gu_block ? ng + LIA_GU_BLOCK : F + c;
+    uint4 g = *(const uint4*)(gu + m * 2 * (long)F + ng);
+    uint4 u = *(const uint4*)(gu + m * 2 * (long)F + nu);
     const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
     uint32_t o[4];
 #pragma unroll
@@ -194,12 +197,12 @@ __global__ __launch_bounds__(256) void lia_silu_mul_kernel(const bf16_t* __restr
   }
 }
 
-extern "C" void lia_silu_mul_launch(const bf16_t* gu, bf16_t* out, long M, int F, hipStream_t st) {
+extern "C" void lia_silu_mul_launch(const bf16_t* gu, bf16_t* out, long M, int F, int gu_block, hipStream_t st) {
   const long n8 = M * (F >> 3);
   if (n8 <= 0) return;
   long blocks = (n8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(lia_silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gu, out, M, F);
+  hipLaunchKernelGGL(lia_silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gu, out, M, F, gu_block);
 }
 
 // token embedding only (Llama has no learned positions): y[row] = embed[ids[row]]

@@ -31,7 +31,7 @@ class ProfResult(ctypes.Structure):
 
 
 class LlamaDesc(ctypes.Structure):
-    _fields_ = [("hidden", c_int), ("heads", c_int), ("kv_heads", c_int), ("ffn", c_int), ("rms_eps", c_float)]
+    _fields_ = [("hidden", c_int), ("heads", c_int), ("kv_heads", c_int), ("ffn", c_int), ("rms_eps", c_float), ("gu_block", c_int)]
 
 
 class KV(ctypes.Structure):

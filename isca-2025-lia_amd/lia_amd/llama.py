@@ -51,6 +51,16 @@ def resolve_llama_shape(name):
     return LLAMA_SHAPES[key]
 
 
+GU_BLOCK = 32      # lia_hip.h, lia_llama_desc.gu_block
+
+
+def interleave_gate_up(gate, up, block=GU_BLOCK):
+    """[F, H] gate.w and up.w -> the [2F, H] block of the layer buffer: `block` gate rows, the matching `block` up rows, ..."""
+    F, H = gate.shape
+    assert up.shape == (F, H) and F % block == 0
+    return np.stack([gate.reshape(F // block, block, H), up.reshape(F // block, block, H)], axis=1).reshape(2 * F, H)
+
+
 def rope_tables(max_pos, d, theta):
     """cos/sin [max_pos, d] in bf16, computed like LlamaRotaryEmbedding.forward: fp32 inv_freq, fp32 angles, cast."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
@@ -64,7 +74,10 @@ class LiaLlamaModel:
 
     def __init__(self, shape):
         self.shape = shape
-        self.desc = N.LlamaDesc(shape.hidden, shape.heads, shape.kv_heads, shape.ffn, shape.rms_eps)
+        # gate.w / up.w live interleaved in the layer buffer, 32 gate rows then the matching 32 up rows (lia_hip.h, gu_block): a
+        # 64-column tile of the gate|up projection then holds both factors of 32 outputs and the prefill GEMM's epilogue
+        # writes silu(gate) * up itself.  The model is the same function of the same weights; only their order in memory differs.
+        self.desc = N.LlamaDesc(shape.hidden, shape.heads, shape.kv_heads, shape.ffn, shape.rms_eps, GU_BLOCK)
         offs = (ctypes.c_size_t * 9)()
         total = ctypes.c_size_t()
         N.check(N.lib().lia_llama_pack_offsets(ctypes.byref(self.desc), ctypes.byref(offs), ctypes.byref(total)), "lia_llama_pack_offsets")
@@ -75,8 +88,16 @@ class LiaLlamaModel:
 
     def _pack_numpy(self, st, tensors):
         flat = np.zeros(self.layer_bytes, np.uint8)
+        F, H = self.shape.ffn, self.shape.hidden
+        gi, ui = LLAMA_TENSORS.index("gate_w"), LLAMA_TENSORS.index("up_w")
+        assert self.offsets[ui] == self.offsets[gi] + F * H * 2, "gate.w and up.w must be adjacent in the layer buffer"
         for i, n in enumerate(LLAMA_TENSORS):
-            a = np.ascontiguousarray(tensors[n], dtype=np.uint16).reshape(-1).view(np.uint8)
+            if n == "up_w":
+                continue                                   # written together with gate_w
+            a = np.ascontiguousarray(tensors[n], dtype=np.uint16)
+            if n == "gate_w":
+                a = interleave_gate_up(a.reshape(F, H), np.ascontiguousarray(tensors["up_w"], dtype=np.uint16).reshape(F, H))
+            a = a.reshape(-1).view(np.uint8)
             flat[self.offsets[i]: self.offsets[i] + a.size] = a
         st._free()
         st._np, st.tier = flat, "pageable"

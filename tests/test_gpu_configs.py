@@ -147,7 +147,7 @@ def llama_big():
     d = LH // LHEADS
 
     def make(kv_heads, kw=None, vw=None):
-        desc = N.LlamaDesc(LH, LHEADS, kv_heads, LF, 1e-5)
+        desc = N.LlamaDesc(LH, LHEADS, kv_heads, LF, 1e-5, 32)     # interleaved gate|up rows (random weights: any order is a model)
         offs = (ctypes.c_size_t * 9)()
         total = ctypes.c_size_t()
         N.check(lib.lia_llama_pack_offsets(ctypes.byref(desc), ctypes.byref(offs), ctypes.byref(total)))

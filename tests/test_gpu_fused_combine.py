@@ -108,15 +108,18 @@ def test_chain_hint_is_ignored_when_the_next_call_takes_another_input():
     ctx.close()
 
 
-@pytest.mark.parametrize("B,H,heads,kvh,F", [(16, 1024, 8, 2, 2816), (128, 2048, 16, 4, 5632), (40, 1024, 8, 8, 3072)])
-def test_llama_decode_layers_fused_equals_unfused(B, H, heads, kvh, F):
+@pytest.mark.parametrize("B,H,heads,kvh,F,T", [(16, 1024, 8, 2, 2816, 6), (128, 2048, 16, 4, 5632, 6), (40, 1024, 8, 8, 3072, 6),
+                                                (128, 1024, 8, 2, 2816, 9)])
+def test_llama_layers_fused_equals_unfused(B, H, heads, kvh, F, T):
     """q|k|v in one GEMM with RoPE in its combine, RMSNorm in the o-proj combine, SiLU*up in the gate|up combine, the next
-    layer's input RMSNorm chained into down-proj's: ids of the outputs and the post-RoPE K cache, bit for bit."""
+    layer's input RMSNorm chained into down-proj's -- and in the prefill SiLU*up in the tiled GEMM's epilogue (B x T = 96 rows:
+    skinny; 240 / 768 rows: the 128 x 128 tiles; 1152 rows: the 256 x 256 tiles): the hidden states of the prefill and of every
+    decode step and the post-RoPE K cache, bit for bit against the route with one kernel per op."""
     import torch
     from lia_amd import _native as N, ops
     from lia_amd.llama import LiaLlamaModel, LlamaShape, rope_tables
     lib = _knobs()
-    T, new, L = 6, 3, 2
+    new, L = 3, 2
     m = synth.make_llama_model(7, 64, H, heads, kvh, F, L, 0.05)
     shape = LlamaShape("t", H, heads, kvh, F, L, 64, max_pos=T + new + 4, rope_theta=10000.0)
     model = LiaLlamaModel.from_numpy(shape, m)
@@ -144,7 +147,8 @@ def test_llama_decode_layers_fused_equals_unfused(B, H, heads, kvh, F):
         for w, kv in zip(ws, kvs):
             call(w, a, b, kv, T, 0)
             a, b = b, a
-        outs = []
+        ctx.synchronize()
+        outs = [to_bits(a).copy()]                       # the prefill's hidden states
         for s in range(new):
             a = to_dev(torch, synth.make_hidden(100 + s, B, 1, H))
             b = torch.empty_like(a)
@@ -164,8 +168,10 @@ def test_llama_decode_layers_fused_equals_unfused(B, H, heads, kvh, F):
     lib.lia_gemm_set_fuse_combine(1)
     ran = [a - b for a, b in zip(after, before)]
     assert ran[0] >= 3 * new and ran[1] >= 2 * new and ran[2] >= 2 * new, f"fused combines that ran (rmsnorm, silu, rope): {ran}"
+    if B * T > 256:
+        assert ran[1] >= 2 * new + L, f"the tiled gate|up epilogue did not write silu(gate) * up itself: {ran}"
     for s, (f, p) in enumerate(zip(fused, plain)):
-        assert (f == p).all(), f"decode step {s}: {(f != p).sum()} of {f.size} values differ"
+        assert (f == p).all(), f"{'prefill' if s == 0 else 'decode step %d' % (s - 1)}: {(f != p).sum()} of {f.size} values differ"
     for (fk, fv), (pk, pv) in zip(fkv, pkv):
         assert (fk == pk).all() and (fv == pv).all()
     ctx.close()
