@@ -265,21 +265,56 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
       v_rd[u][d] = 256 * key + 16 * (ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) + 8 * (tp & 1);
     }
 
-#define P2_SCORES(kt32, sb, sacc)                                                                                     \
+  // q.k of one 32-key block: eight dependent MFMAs
+#define P2_QK(sb, sacc)                                                                                               \
   do {                                                                                                                \
     sacc = f32x16{0};                                                                                                 \
     _Pragma("unroll") for (int ss_ = 0; ss_ < 8; ++ss_) {                                                             \
       uint4 kv_ = *(const uint4*)(k_lds + (sb) * 8192 + k_rd + (((2 * ss_ + h) ^ (r & 15)) << 4));                    \
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv_), qf[ss_], sacc, 0, 0, 0);        \
     }                                                                                                                 \
-    const bool inside_ = (kt32) * 32 + 31 <= q_wave && (kt32) * 32 + 31 < T;   /* wave-uniform: nothing to mask */     \
+  } while (0)
+  // the reference's rounding points on the scores, then the causal mask (inside_: wave-uniform, nothing to mask)
+#define P2_ROUND_MASK(kt32, sacc, inside_)                                                                            \
+  do {                                                                                                                \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                  \
       int key_ = (kt32) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;                                                        \
       float sv_ = rbf(sacc[i]);                                                                                       \
       if (post_scale) sv_ = rbf(sv_ * scaling);                                                                       \
-      sacc[i] = (inside_ || (key_ <= my_q && key_ < T)) ? sv_ : -INFINITY;                                            \
+      sacc[i] = ((inside_) || (key_ <= my_q && key_ < T)) ? sv_ : -INFINITY;                                          \
     }                                                                                                                 \
   } while (0)
+#define P2_SCORES(kt32, sb, sacc)                                                                                     \
+  do {                                                                                                                \
+    P2_QK(sb, sacc);                                                                                                  \
+    const bool in_ = (kt32) * 32 + 31 <= q_wave && (kt32) * 32 + 31 < T;                                              \
+    P2_ROUND_MASK(kt32, sacc, in_);                                                                                   \
+  } while (0)
+  // running row max / sum of exp with the block's scores (sweep 1)
+#define P2_STATS(s)                                                                                                   \
+  do {                                                                                                                \
+    float tm = s[0];                                                                                                  \
+    _Pragma("unroll") for (int i = 1; i < 16; ++i) tm = fmaxf(tm, s[i]);                                              \
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                                                                           \
+    float mn = fmaxf(m, tm);                                                                                          \
+    if (mn > -INFINITY) {                                                                                             \
+      float ts = 0.f;                                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) ts += __expf(s[i] - mn);                                         \
+      ts += __shfl_xor(ts, 32, 64);                                                                                   \
+      l = l * __expf(m - mn) + ts;                                                                                    \
+      m = mn;                                                                                                         \
+    }                                                                                                                 \
+  } while (0)
+  // A 64-key tile that lies entirely at or below the wave's diagonal (all but the last one or two tiles of a wave) runs both
+  // blocks' q.k chains FIRST and only then the VALU work on block 0, which overlaps the matrix pipe still busy with block 1
+  // (then P.V of block 0 under the VALU work of block 1): same operations, same order within a block and between the
+  // blocks' updates of (m, l) and of the output accumulators -- the bits do not change.  PMC before: matrix pipe 10 % busy,
+  // VALU 30 %, two waves per SIMD (222 of 512 registers each) stalled on one another's latencies; B 128 x T 1024 x 32 heads
+  // 7.25 -> 5.65 ms, OPT-30B's B 64 x T 256 x 56 heads 0.478 -> 0.409 ms.  (The same interleave for the partly masked tiles,
+  // with the mask flags as run-time values, needs 294 registers -- one wave per SIMD, 12.7 ms -- or spills at 256: 7.9 ms.)
+#define P2_TILE_INSIDE(t) ((2 * (t) + 1) * 32 + 31 <= q_wave && (2 * (t) + 1) * 32 + 31 < T)
+  // (A second such path for the diagonal tile -- block 0 visible, block 1 masked, flags still compile-time -- takes the kernel to
+  // 314 registers: one wave per SIMD, 8.6 ms; capped at 256 it spills 20 bytes: 6.2 ms.  The diagonal tiles keep the plain path.)
 
   // (named registers and unconditional loads: an array filled under `if (t + 1 < n64)` is kept in scratch by hipcc)
   uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
@@ -297,25 +332,23 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
     P2_STORE_K()
     __syncthreads();
     P2_LOAD_K(t + 1)      // (clamped: the last iteration re-reads its own tile)
+    if (P2_TILE_INSIDE(t)) {
+      f32x16 s0, s1;
+      P2_QK(0, s0);
+      P2_QK(1, s1);
+      P2_ROUND_MASK(2 * t, s0, true);
+      P2_STATS(s0);
+      P2_ROUND_MASK(2 * t + 1, s1, true);
+      P2_STATS(s1);
+      continue;
+    }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int kt = 2 * t + sb;
       if (kt < n32 && kt * 32 <= q_wave + 31) {  // wave-uniform: block exists and is not entirely above the diagonal
         f32x16 s;
         P2_SCORES(kt, sb, s);
-        float tm = s[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) tm = fmaxf(tm, s[i]);
-        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-        float mn = fmaxf(m, tm);
-        if (mn > -INFINITY) {
-          float ts = 0.f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) ts += __expf(s[i] - mn);
-          ts += __shfl_xor(ts, 32, 64);
-          l = l * __expf(m - mn) + ts;
-          m = mn;
-        }
+        P2_STATS(s);
       }
     }
   }
@@ -346,37 +379,61 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
     __syncthreads();
     P2_LOAD_K(t + 1)
     P2_LOAD_V(t + 1)
+#define P2_PROBS(s, pk)                                                                                               \
+  do {                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
+      float p0, p1;                                                                                                   \
+      P2_DIV(__expf(s[2 * i] - m), p0);                                                                               \
+      P2_DIV(__expf(s[2 * i + 1] - m), p1);                                                                           \
+      pk[i] = pack_bf16x2(p0, p1);                                                                                    \
+    }                                                                                                                 \
+  } while (0)
+    // keys 32 sb + 16 ks + 4 h + (0..3) -> elements 0..3, the same + 8 -> elements 4..7 (the k order of an
+    // accumulator tile used as an operand)
+#define P2_PV(sb, pk)                                                                                                 \
+  do {                                                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
+      bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[4 * ks], pk[4 * ks + 1], pk[4 * ks + 2], pk[4 * ks + 3]});      \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                                 \
+        const char* vb = v_lds + (32 * (sb) + 16 * ks) * 256;                                                         \
+        lia_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[0][d])); \
+        lia_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[1][d])); \
+        bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));              \
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);                                  \
+      }                                                                                                               \
+    }                                                                                                                 \
+  } while (0)
+    if (P2_TILE_INSIDE(t)) {
+      f32x16 s0, s1;
+      uint32_t pk0[8], pk1[8];
+      P2_QK(0, s0);
+      P2_QK(1, s1);
+      P2_ROUND_MASK(2 * t, s0, true);
+      P2_PROBS(s0, pk0);
+      P2_PV(0, pk0);
+      P2_ROUND_MASK(2 * t + 1, s1, true);
+      P2_PROBS(s1, pk1);
+      P2_PV(1, pk1);
+      continue;
+    }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int kt = 2 * t + sb;
       if (kt < n32 && kt * 32 <= q_wave + 31) {
         f32x16 s;
-        P2_SCORES(kt, sb, s);
         uint32_t pk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float p0, p1;
-          P2_DIV(__expf(s[2 * i] - m), p0);
-          P2_DIV(__expf(s[2 * i + 1] - m), p1);
-          pk[i] = pack_bf16x2(p0, p1);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[4 * ks], pk[4 * ks + 1], pk[4 * ks + 2], pk[4 * ks + 3]});
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            // keys 32 sb + 16 ks + 4 h + (0..3) -> elements 0..3, the same + 8 -> elements 4..7 (the k order of an
-            // accumulator tile used as an operand)
-            const char* vb = v_lds + (32 * sb + 16 * ks) * 256;
-            lia_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[0][d]));
-            lia_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[1][d]));
-            bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
-          }
-        }
+        P2_SCORES(kt, sb, s);
+        P2_PROBS(s, pk);
+        P2_PV(sb, pk);
       }
     }
   }
+#undef P2_PROBS
+#undef P2_PV
+#undef P2_QK
+#undef P2_ROUND_MASK
+#undef P2_STATS
+#undef P2_TILE_INSIDE
 #undef P2_SCORES
 #undef P2_DIV
 #undef P2_LOAD_K
