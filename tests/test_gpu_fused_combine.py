@@ -24,7 +24,7 @@ def _knobs():
     return lib
 
 
-@pytest.mark.parametrize("B,H,heads,F", [(8, 1024, 8, 4096), (64, 2048, 16, 8192), (33, 1536, 12, 6144)])
+@pytest.mark.parametrize("B,H,heads,F", [(8, 1024, 8, 4096), (64, 2048, 16, 8192), (33, 1536, 12, 6144), (1, 768, 12, 3072), (256, 1024, 8, 4096)])
 def test_opt_decode_layers_fused_equals_unfused(B, H, heads, F):
     """two resident layers, three decode steps: LN2 in the out-proj combine, the next layer's LN1 chained into fc2's."""
     import torch
@@ -67,7 +67,9 @@ def test_opt_decode_layers_fused_equals_unfused(B, H, heads, F):
     plain, pk = run(False)
     assert lib.lia_gemm_fused_combine_count(LN) == n1, "the switch did not turn the fused combines off"
     lib.lia_gemm_set_fuse_combine(1)
-    assert n1 - n0 >= 3 * new, f"only {n1 - n0} fused LayerNorm combines ran (expected LN2 x2 + one chained LN1 per step)"
+    # (H = 768: the out-proj GEMM has 12 K-chunks and is not split -- its LN2 stays a kernel of its own; fc2's chained LN1 rides)
+    want = 3 * new if H >= 1024 else new
+    assert n1 - n0 >= want, f"only {n1 - n0} fused LayerNorm combines ran (expected LN2 x2 + one chained LN1 per step)"
     for s, (f, p) in enumerate(zip(fused, plain)):
         assert (f == p).all(), f"decode step {s}: {(f != p).sum()} of {f.size} values differ between the fused and the per-op route"
     for f, p in zip(fk, pk):
@@ -109,7 +111,7 @@ def test_chain_hint_is_ignored_when_the_next_call_takes_another_input():
 
 
 @pytest.mark.parametrize("B,H,heads,kvh,F,T", [(16, 1024, 8, 2, 2816, 6), (128, 2048, 16, 4, 5632, 6), (40, 1024, 8, 8, 3072, 6),
-                                                (128, 1024, 8, 2, 2816, 9)])
+                                                (128, 1024, 8, 2, 2816, 9), (1, 1024, 8, 2, 2816, 6)])
 def test_llama_layers_fused_equals_unfused(B, H, heads, kvh, F, T):
     """q|k|v in one GEMM with RoPE in its combine, RMSNorm in the o-proj combine, SiLU*up in the gate|up combine, the next
     layer's input RMSNorm chained into down-proj's -- and in the prefill SiLU*up in the tiled GEMM's epilogue (B x T = 96 rows:
