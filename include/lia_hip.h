@@ -51,6 +51,11 @@ void* lia_ctx_compute_stream(lia_ctx* ctx); /* hipStream_t created by the contex
 int lia_ctx_synchronize(lia_ctx* ctx);          /* compute AND K/V delivery streams */
 int lia_ctx_synchronize_compute(lia_ctx* ctx);  /* the compute stream only (deferred K/V deliveries keep running) */
 int lia_ctx_set_host_threads(lia_ctx* ctx, int n); /* OpenMP threads of the policy-2 host attention */
+/* 1 when the context was created under LIA_SERIALIZE=1 (debug): the K/V delivery stream, and the copy / wire-decode streams of
+ * every streamer created on it, ARE the compute stream, so no ordering depends on an event.  The reference serialises with
+ * torch.cuda.synchronize() after every minibatch / layer (modeling_opt.py:1298,1339,1506,1528); a result that differs between
+ * the two modes is a missing cross-stream dependency. */
+int lia_ctx_serialized(lia_ctx* ctx);
 /* Cross-layer chaining for decode (build-defined; the reference launches every LayerNorm as its own kernel, decoder.py:199-206).
  * One-shot promise about the NEXT lia_layer_forward / lia_llama_layer_forward call on this context: its output y will be the
  * input x of the call after it, unchanged, and that layer's first norm has weights g (and b; NULL for RMSNorm).  The layer then
@@ -130,7 +135,7 @@ int lia_ctx_kv_store_wait(lia_ctx* ctx); /* host-blocks until every policy-0 K/V
  * of the prefill (H2D runs 8 % slower beside them); the first decode step waits per layer with lia_kv_deliver_wait(ticket)
  * right before that layer's host attention.  row_elems = heads * head_dim. */
 int lia_kv_deliver(lia_ctx* ctx, const lia_kv* dev, lia_kv* host, int T, int row_elems, int* ticket);
-int lia_kv_deliver_wait(lia_ctx* ctx, int ticket);
+int lia_kv_deliver_wait(lia_ctx* ctx, int ticket); /* host-blocks until that delivery has landed; frees the ticket */
 
 /* ---- individual sub-layer ops (same kernels the layer call uses; exposed for parity tests) ------ */
 /* F.layer_norm, decoder.py:107-119 */
@@ -260,6 +265,9 @@ int lia_numa_available(void);
 /* make a host range DMA-able by the copy engine (hipHostRegister); the reference leaves CXL tensors
  * pageable (numa_alloc.py:49) so its copies degrade to staged synchronous ones */
 int lia_numa_register(void* ptr, size_t size);
+/* the same for a read-only mapping (PROT_READ, MAP_SHARED mmap of a checkpoint file): pinned without write intent, so the
+ * page-cache pages are used in place */
+int lia_numa_register_readonly(void* ptr, size_t size);
 int lia_numa_unregister(void* ptr);
 /* pinned host memory (Tensor.pin_memory(), modeling_opt.py:207-227) */
 void* lia_host_alloc_pinned(size_t size);

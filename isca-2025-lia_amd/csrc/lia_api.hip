@@ -3,6 +3,7 @@
 // lia_elementwise.hip, host-side cooperative code in lia_host.cpp.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -93,6 +94,10 @@ struct lia_ctx {
   const void* normed_buf;
   long normed_rows;                 // ... for this many rows of this width
   int normed_h;
+  // LIA_SERIALIZE=1 (debug): ONE stream for everything -- the K/V delivery stream IS the compute stream, and a streamer created
+  // on this context copies and decodes on it too, so every event handshake is trivially ordered.  Results must not change; if
+  // they do, a cross-stream ordering is missing (the role torch.cuda.synchronize() plays at lia/modeling_opt.py:1339,1528).
+  bool serialized;
 };
 
 extern "C" int lia_ctx_chain_next_norm(lia_ctx* c, const lia_bf16* g, const lia_bf16* b) {
@@ -118,6 +123,12 @@ extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out)
   c->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
   {
+    const char* ser = getenv("LIA_SERIALIZE");
+    c->serialized = ser && ser[0] == '1';
+  }
+  if (c->serialized) {
+    c->d2h = c->compute;
+  } else {
     // K/V delivery must not starve behind back-to-back GEMMs when it falls back to a blit kernel (strided case)
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -157,12 +168,13 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
     delete c->prof_events;
     delete c->prof_recs;
   }
+  if (c->d2h != c->compute) (void)hipStreamDestroy(c->d2h);
   (void)hipStreamDestroy(c->compute);
-  (void)hipStreamDestroy(c->d2h);
   delete c;
 }
 
 extern "C" void* lia_ctx_compute_stream(lia_ctx* c) { return c ? (void*)c->compute : nullptr; }
+extern "C" int lia_ctx_serialized(lia_ctx* c) { return c && c->serialized ? 1 : 0; }
 
 extern "C" int lia_ctx_synchronize(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
@@ -254,13 +266,11 @@ extern "C" int lia_kv_deliver(lia_ctx* c, const lia_kv* dev, lia_kv* host, int T
     return LIA_ERR_INVALID;
   }
   if (!c->deliver_events) { c->deliver_events = new std::vector<hipEvent_t>(); c->deliver_pending = new std::vector<char>(); }
+  // A ticket is freed by lia_kv_deliver_wait and by nothing else: recycling one whose copy merely happened to be complete
+  // (r02) handed the same id to a later layer of the SAME prefill, and waiting for layer i then meant waiting for layer j > i.
   int id = -1;
-  for (size_t i = 0; i < c->deliver_pending->size(); ++i) {
-    // a ticket nobody waited for (a generation that ended with its prefill) is free again once its copy has completed
-    if ((*c->deliver_pending)[i] && hipEventQuery((*c->deliver_events)[i]) == hipSuccess) (*c->deliver_pending)[i] = 0;
+  for (size_t i = 0; i < c->deliver_pending->size(); ++i)
     if (!(*c->deliver_pending)[i]) { id = (int)i; break; }
-  }
-  (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is an answer, not an error to report later
   if (id < 0) {
     hipEvent_t e;
     HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -906,6 +916,9 @@ extern "C" size_t lia_pack11_bound(size_t n_values);
 extern "C" size_t lia_pack10_bound(size_t n_values);
 extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st);
 
+#ifndef LIA_DECODE_CUS_DEFAULT
+#define LIA_DECODE_CUS_DEFAULT 0
+#endif
 struct lia_streamer {
   lia_ctx* ctx;
   int n_slots;
@@ -943,7 +956,8 @@ extern "C" int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, l
   s->ctx = ctx; s->n_slots = n_slots; s->slot_bytes = align_up(slot_bytes, 256);
   s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr; s->staging = nullptr; s->staging_bytes = 0;
   HIP_TRY(hipMalloc((void**)&s->slots, s->slot_bytes * n_slots));
-  HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+  if (ctx->serialized) s->copy = ctx->compute;
+  else HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
   s->copied.resize(n_slots); s->released.resize(n_slots); s->t0.resize(n_slots); s->t1.resize(n_slots);
   s->has_release.assign(n_slots, 0); s->timing_pending.assign(n_slots, 0); s->pending_bytes.assign(n_slots, 0);
   s->was_marked.assign(n_slots, 0);
@@ -969,10 +983,10 @@ extern "C" void lia_stream_destroy(lia_streamer* s) {
   if (s->staging) {
     (void)hipStreamSynchronize(s->decode);
     for (hipEvent_t e : s->landed) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(s->decode);
+    if (s->decode != s->ctx->compute) (void)hipStreamDestroy(s->decode);
     (void)hipFree(s->staging);
   }
-  (void)hipStreamDestroy(s->copy);
+  if (s->copy != s->ctx->compute) (void)hipStreamDestroy(s->copy);
   delete s;
 }
 
@@ -1023,7 +1037,27 @@ static int ensure_staging(lia_streamer* s) {
   s->staging_bytes = std::max({lia_pack12_bound(s->slot_bytes / 2), lia_pack11_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024),
                                lia_pack10_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024)});
   HIP_TRY(hipMalloc((void**)&s->staging, s->staging_bytes * s->n_slots));
-  HIP_TRY(hipStreamCreateWithFlags(&s->decode, hipStreamNonBlocking));
+  // The wire-format decode has a whole layer's link time (~14 ms for OPT-30B) to rebuild a layer and needs ~1/30 of the chip for
+  // that, but launched on a plain stream its thousands of workgroups take every CU and whatever the compute stream launches
+  // next queues behind them (a prefill LayerNorm: 88 -> 600 us, 44 times per prefill).  LIA_DECODE_CUS=n (default
+  // LIA_DECODE_CUS_DEFAULT) confines the decode stream to n compute units with a CU mask; 0 = the whole chip (r02).
+  int decode_cus = LIA_DECODE_CUS_DEFAULT;
+  if (const char* e = getenv("LIA_DECODE_CUS")) decode_cus = atoi(e);
+  if (s->ctx->serialized) {
+    s->decode = s->ctx->compute;
+  } else if (decode_cus > 0) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->ctx->device));
+    const int total = prop.multiProcessorCount;
+    decode_cus = std::min(decode_cus, total);
+    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+    // low bits first: the driver deals consecutive mask bits round-robin over the XCDs (and their shader engines), so n bits are
+    // n / 8 CUs on each of the 8 XCDs
+    for (int i = 0; i < decode_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    HIP_TRY(hipExtStreamCreateWithCUMask(&s->decode, (uint32_t)mask.size(), mask.data()));
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&s->decode, hipStreamNonBlocking));
+  }
   s->landed.resize(s->n_slots);
   s->decoded_on_side.assign(s->n_slots, 0);
   for (int i = 0; i < s->n_slots; ++i) HIP_TRY(hipEventCreateWithFlags(&s->landed[i], hipEventDisableTiming));
@@ -1182,6 +1216,18 @@ extern "C" int lia_numa_register(void* ptr, size_t size) {
   hipError_t e = hipHostRegister(ptr, size, hipHostRegisterDefault);
   if (e != hipSuccess) {
     lia_set_error("hipHostRegister(%p, %zu) failed: %s", ptr, size, hipGetErrorString(e));
+    return LIA_ERR_MEMORY;
+  }
+  return LIA_OK;
+}
+// Register a READ-ONLY mapping (a shared, PROT_READ mmap of a checkpoint file): the pages are pinned without write intent, so
+// they stay the page-cache pages -- no private copy of the file appears in anonymous memory.
+extern "C" int lia_numa_register_readonly(void* ptr, size_t size) {
+  if (!ptr || !size) return LIA_ERR_INVALID;
+  hipError_t e = hipHostRegister(ptr, size, hipHostRegisterReadOnly);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    lia_set_error("hipHostRegister(%p, %zu, read-only) failed: %s", ptr, size, hipGetErrorString(e));
     return LIA_ERR_MEMORY;
   }
   return LIA_OK;

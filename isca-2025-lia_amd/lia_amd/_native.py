@@ -49,6 +49,7 @@ SIGNATURES = {
     "lia_ctx_synchronize": (c_int, [c_void_p]),
     "lia_ctx_synchronize_compute": (c_int, [c_void_p]),
     "lia_ctx_set_host_threads": (c_int, [c_void_p, c_int]),
+    "lia_ctx_serialized": (c_int, [c_void_p]),
     "lia_ctx_chain_next_norm": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lia_prof_start": (c_int, [c_void_p, c_int]),
     "lia_prof_set_stride": (c_int, [c_void_p, c_int]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "lia_numa_set_interleave_nodes": (c_int, [ctypes.POINTER(c_int), c_int]),
     "lia_numa_available": (c_int, []),
     "lia_numa_register": (c_int, [c_void_p, c_size_t]),
+    "lia_numa_register_readonly": (c_int, [c_void_p, c_size_t]),
     "lia_numa_unregister": (c_int, [c_void_p]),
     "lia_host_alloc_pinned": (c_void_p, [c_size_t]),
     "lia_host_free_pinned": (None, [c_void_p]),

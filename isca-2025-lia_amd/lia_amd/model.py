@@ -252,31 +252,36 @@ class LayerStore:
             return
         src = self._raw_on_device()
         self._free()                                   # the host copy goes first: never two generations of a layer in host memory
-        enc = self._encode_packed(fmt, src)
         from . import hostinfo
-        raw_ptr = None
-        if enc and keep_raw:
-            try:
-                hostinfo.guard_host_allocation(self.nbytes + enc[1], "raw + packed pinned copies of a host-computed layer", ceiling=0.85)
-                raw_ptr = self._lib.lia_host_alloc_pinned(self.nbytes)
-            except MemoryError:
-                raw_ptr = None
-            if raw_ptr:
-                self._fill_host(raw_ptr, src)
+        raw_ptr = ptr = None
+        try:
+            enc = self._encode_packed(fmt, src)
+            if enc and keep_raw:
+                try:
+                    hostinfo.guard_host_allocation(self.nbytes + enc[1], "raw + packed pinned copies of a host-computed layer", ceiling=0.85)
+                    raw_ptr = self._lib.lia_host_alloc_pinned(self.nbytes)
+                except MemoryError:
+                    raw_ptr = None
+                if raw_ptr:
+                    self._fill_host(raw_ptr, src)
+                else:
+                    enc = None               # no room for two copies: keep the raw one only (it also streams, just more bytes)
+            nbytes = enc[1] if enc else self.nbytes
+            hostinfo.guard_host_allocation(nbytes, "pinning a streamed layer")
+            ptr = self._lib.lia_host_alloc_pinned(nbytes)
+            if not ptr:
+                raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
+            if enc:
+                N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
             else:
-                enc = None               # no room for two copies: keep the raw one only (it also streams, just more bytes)
-        nbytes = enc[1] if enc else self.nbytes
-        hostinfo.guard_host_allocation(nbytes, "pinning a streamed layer")
-        ptr = self._lib.lia_host_alloc_pinned(nbytes)
-        if not ptr:
-            if raw_ptr:
-                self._lib.lia_host_free_pinned(raw_ptr)
-            self._dev, self.tier = src, "device"       # nothing is lost: the layer stays where it could be rebuilt
-            raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
-        if enc:
-            N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
-        else:
-            self._fill_host(ptr, src)
+                self._fill_host(ptr, src)
+        except BaseException:
+            # nothing is lost: whatever failed (the guard, the allocation, the copy), the layer stays where it can be rebuilt from
+            for p_ in (raw_ptr, ptr):
+                if p_:
+                    self._lib.lia_host_free_pinned(p_)
+            self._dev, self.tier = src, "device"
+            raise
         self._ptr, self.tier, self._raw_ptr = ptr, "pinned", raw_ptr
         self.packed, self.stream_bytes, self.want_fmt = (fmt if enc else 0), nbytes, fmt
 
@@ -287,23 +292,30 @@ class LayerStore:
 
     def _to_pinned_shard(self, fmt, shard):
         r, G = shard
-        src = self._raw_on_device()
+        src0 = self._raw_on_device()
         self._free()
-        enc = self._encode_packed(fmt, src)
-        if enc:
-            src, total = enc
-        else:
-            total = self.nbytes
-        sh = self.shard_bytes(total, G)
-        lo, hi = min(r * sh, total), min((r + 1) * sh, total)
-        from . import hostinfo
-        hostinfo.guard_host_allocation(sh, "pinning a slice of a streamed layer")
-        ptr = self._lib.lia_host_alloc_pinned(sh)
-        if not ptr:
-            raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
-        ctypes.memset(ptr, 0, sh)
-        if hi > lo:
-            N.check(self._lib.lia_memcpy_d2h(ptr, src.data_ptr() + lo, hi - lo), "lia_memcpy_d2h")
+        ptr = None
+        try:
+            enc = self._encode_packed(fmt, src0)
+            if enc:
+                src, total = enc
+            else:
+                src, total = src0, self.nbytes
+            sh = self.shard_bytes(total, G)
+            lo, hi = min(r * sh, total), min((r + 1) * sh, total)
+            from . import hostinfo
+            hostinfo.guard_host_allocation(sh, "pinning a slice of a streamed layer")
+            ptr = self._lib.lia_host_alloc_pinned(sh)
+            if not ptr:
+                raise MemoryError("Fail to allocate pinned memory: " + self._lib.lia_last_error().decode())
+            ctypes.memset(ptr, 0, sh)
+            if hi > lo:
+                N.check(self._lib.lia_memcpy_d2h(ptr, src.data_ptr() + lo, hi - lo), "lia_memcpy_d2h")
+        except BaseException:
+            if ptr:
+                self._lib.lia_host_free_pinned(ptr)
+            self._dev, self.tier = src0, "device"      # the whole raw layer is still here: nothing is lost
+            raise
         self._ptr, self.tier = ptr, "pinned"
         self.packed, self.stream_bytes, self.shard, self.want_fmt = (fmt if enc else 0), total, (r, G, sh), fmt
 
@@ -316,49 +328,85 @@ class LayerStore:
             return
         src = self._raw_on_device()
         self._free()
-        enc = self._encode_packed(fmt, src)
-        nbytes = enc[1] if enc else self.nbytes
-        from . import hostinfo
-        hostinfo.guard_host_allocation(nbytes, "CXL-tier copy of a streamed layer")
-        ptr = self._lib.numa_alloc_interleave(nbytes)
-        if not ptr:
+        ptr, registered, nbytes = None, False, self.nbytes
+        try:
+            enc = self._encode_packed(fmt, src)
+            nbytes = enc[1] if enc else self.nbytes
+            from . import hostinfo
+            hostinfo.guard_host_allocation(nbytes, "CXL-tier copy of a streamed layer")
+            ptr = self._lib.numa_alloc_interleave(nbytes)
+            if not ptr:
+                raise MemoryError("Fail to allocate CXL memory!")  # same text as lia/modeling_opt.py:175
+            N.check(self._lib.lia_numa_register(ptr, nbytes), "lia_numa_register")   # register first: the fill below then runs at DMA speed
+            registered = True
+            if enc:
+                N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
+            else:
+                self._fill_host(ptr, src)
+        except BaseException:
+            if registered:
+                self._lib.lia_numa_unregister(ptr)
+            if ptr:
+                self._lib.numa_free_node(ptr, nbytes)
             self._dev, self.tier = src, "device"
-            raise MemoryError("Fail to allocate CXL memory!")  # same text as lia/modeling_opt.py:175
-        rc = self._lib.lia_numa_register(ptr, nbytes)           # register first: the fill below then runs at DMA speed
-        if rc != 0:
-            self._lib.numa_free_node(ptr, nbytes)
-            self._dev, self.tier = src, "device"
-            N.check(rc, "lia_numa_register")
-        if enc:
-            N.check(self._lib.lia_memcpy_d2h(ptr, enc[0].data_ptr(), nbytes), "lia_memcpy_d2h")
-        else:
-            self._fill_host(ptr, src)
+            raise
         self._ptr, self.tier = ptr, "cxl"
         self.packed, self.stream_bytes, self.want_fmt = (fmt if enc else 0), nbytes, fmt
 
     def set_from_mapped_file(self, path, offset, nbytes, fmt):
         """The layer's wire bytes straight from a checkpoint file of the build's on-disk format (lia_amd.packed_checkpoint):
-        a private mmap of the file range, registered with the driver (hipHostRegister) so the copy engine DMAs from the page
-        cache copy -- no second host copy of the model.  fmt = 0 (raw bf16) or the packed format the file holds."""
+        an mmap of the file range registered with the driver (hipHostRegister) so the copy engine DMAs from the page cache.
+        First choice is a READ-ONLY SHARED mapping registered read-only (lia_numa_register_readonly): pinning without write
+        intent leaves the page-cache pages where they are -- no second host copy.  A driver that refuses that gets a private
+        writable mapping (r02's form; pinning it with write intent may copy the pages into anonymous memory, so the guard
+        below counts the layer as a full allocation either way).  fmt = 0 (raw bf16) or the packed format the file holds."""
         import mmap
         if fmt == 0 and nbytes != self.nbytes:
             raise ValueError(f"{path}: raw layer of {nbytes} bytes, expected {self.nbytes}")
+        from . import hostinfo
+        hostinfo.guard_host_allocation(nbytes, f"mapping + registering {path}")
         self._free()
         gran = mmap.ALLOCATIONGRANULARITY
         start = offset // gran * gran
-        f = open(path, "rb")
-        try:
-            mm = mmap.mmap(f.fileno(), nbytes + (offset - start), access=mmap.ACCESS_COPY, offset=start)
-        finally:
-            f.close()
-        base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
-        rc = self._lib.lia_numa_register(base, len(mm))
-        if rc != 0:
-            mm.close()
+        length = nbytes + (offset - start)
+        mm = base = mode = None
+        with open(path, "rb") as f:
+            for mode, access, register in (("shared-readonly", mmap.ACCESS_READ, self._lib.lia_numa_register_readonly),
+                                           ("private", mmap.ACCESS_COPY, self._lib.lia_numa_register)):
+                mm = mmap.mmap(f.fileno(), length, access=access, offset=start)
+                base = np.frombuffer(mm, dtype=np.uint8).ctypes.data          # (works for read-only buffers, unlike ctypes.from_buffer)
+                rc = register(base, length)
+                if rc == 0:
+                    break
+                try:
+                    mm.close()
+                except BufferError:
+                    pass
+                mm = None
+        if mm is None:
             N.check(rc, f"hipHostRegister of {path}")
-        self._mm, self._mm_base = mm, base
+        self._mm, self._mm_base, self.map_mode = mm, base, mode
         self._ptr, self.tier = base + (offset - start), "mapped"
         self.packed, self.stream_bytes, self.want_fmt = int(fmt), nbytes, int(fmt)
+
+    def set_from_file_to_device(self, path, offset, nbytes, fmt):
+        """A RESIDENT layer of a packed checkpoint directory: plain read of the wire bytes, one H2D copy, decoded on the device when
+        the file holds a packed format.  (r02 mapped + registered + freed every resident layer on its way to HBM.)"""
+        if fmt == 0 and nbytes != self.nbytes:
+            raise ValueError(f"{path}: raw layer of {nbytes} bytes, expected {self.nbytes}")
+        host = np.fromfile(path, dtype=np.uint8, count=nbytes, offset=offset)
+        if host.size != nbytes:
+            raise ValueError(f"{path}: short read ({host.size} of {nbytes} bytes)")
+        dev = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
+        if fmt:
+            enc = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            N.check(self._lib.lia_memcpy_h2d(enc.data_ptr(), host.ctypes.data, nbytes), "lia_memcpy_h2d")
+            N.check(self._lib.lia_pack_decode(ctypes.c_void_p(enc.data_ptr()), ctypes.c_void_p(dev.data_ptr()), self.nbytes // 2, int(fmt),
+                                              None), "lia_pack_decode")
+            torch.cuda.synchronize()
+        else:
+            N.check(self._lib.lia_memcpy_h2d(dev.data_ptr(), host.ctypes.data, nbytes), "lia_memcpy_h2d")
+        self.set_from_device(dev)
 
     def is_dma_able(self):
         return self.tier in ("pinned", "cxl", "mapped")

@@ -10,8 +10,9 @@ Here a model is written ONCE as a directory of per-layer wire buffers, exactly t
     <dir>/head.bin           embed_tokens | embed_positions | final_ln_w | final_ln_b, raw bf16
     <dir>/layer_NNN.bin      one packed layer: raw bf16 (lia_layer_pack_offsets layout) or its lossless pack10 encoding
 
-and loaded without a second host copy: resident layers are read into HBM, streamed layers are `mmap`ed and the mapping is
-registered with the driver (hipHostRegister), so the copy engine DMAs out of the page cache in the wire format on disk.
+and loaded without a second host copy: resident layers are read straight into HBM, streamed layers are `mmap`ed (read-only,
+shared) and the mapping is registered with the driver (hipHostRegister, read-only), so the copy engine DMAs out of the page
+cache in the wire format on disk.  Every mapping is checked against the container's memory limit first (hostinfo).
 """
 import json
 import os
@@ -120,13 +121,19 @@ def load_packed(dirpath, n_gpu_layers=0):
 
     model.embed_tokens, model.embed_positions = dev(head[cuts[0]:cuts[1]], shape.vocab, H), dev(head[cuts[1]:cuts[2]], shape.max_pos + 2, H)
     model.final_ln_w, model.final_ln_b = dev(head[cuts[2]:cuts[3]], H), dev(head[cuts[3]:cuts[4]], H)
+    # the streamed layers stay registered (pinned) for the life of the model: judge the whole plan before the first mapping,
+    # LayerStore.set_from_mapped_file guards every single one again (an opt-175b directory is ~220 GB of them)
+    from . import hostinfo
+    hostinfo.check_host_allocation(sum(int(e["bytes"]) for e in man["layers"][n_gpu_layers:]),
+                                   f"{dirpath}: registering {len(man['layers']) - n_gpu_layers} streamed layers")
     for i, (st, ent) in enumerate(zip(model.layers, man["layers"])):
         path = os.path.join(dirpath, ent["file"])
         if os.path.getsize(path) != ent["bytes"]:
             raise ValueError(f"{path}: {os.path.getsize(path)} bytes on disk, manifest says {ent['bytes']}")
-        st.set_from_mapped_file(path, 0, ent["bytes"], ent["wire"])
         if i < n_gpu_layers:
-            st.to_device()
+            st.set_from_file_to_device(path, 0, ent["bytes"], ent["wire"])       # plain read -> HBM: never mapped, never registered
+        else:
+            st.set_from_mapped_file(path, 0, ent["bytes"], ent["wire"])
     torch.cuda.synchronize()
     return model
 

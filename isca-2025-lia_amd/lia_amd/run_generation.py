@@ -31,6 +31,9 @@ def build_parser():
     p.add_argument("--num-warmup", default=10, type=int)
     p.add_argument("--batch-size", default=1, type=int)
     p.add_argument("--token-latency", action="store_true")
+    p.add_argument("--profile", action="store_true",
+                   help="one profiled generate() before the timed loop (run_generation.py:103,290-307 runs torch.profiler over five "
+                        "there); here the library's own HIP-event brackets: GEMM time / rates per phase, host attention, link traffic")
     # the seven LIA flags, same names / types / defaults as run.py:195-215 and run_generation.py:111-117
     p.add_argument("--prefill-policy", default=1, type=int)
     p.add_argument("--decoding-policy", default=1, type=int)
@@ -144,6 +147,50 @@ def summarize(total_time, num_iter, num_warmup, total_list, batch_size, out=prin
     return res
 
 
+def profile_once(model, input_ids, generate_kwargs, out=print):
+    """--profile (run_generation.py:290-307): one generate() with every GEMM launch bracketed by HIP events on its own stream
+    (lia_prof_*), the host-attention wall clock and the weight stream's copy-engine time; prints the table and returns it."""
+    sched = model._lia_scheduler
+    generate(model, input_ids, **dict(generate_kwargs, max_steps=2))       # untimed: allocations, placement, page-in
+    st = {}
+
+    def hook(step):
+        if step == 0:
+            sched.stream_stats(reset=True)
+            sched.ctx.prof_start(65536)
+        elif step == 1:
+            st["prefill"], st["prefill_h2d"] = sched.ctx.prof_stop(), sched.stream_stats(reset=True)
+            sched.ctx.prof_start(65536)
+
+    res = generate(model, input_ids, step_hook=hook, **dict(generate_kwargs, token_latency=True))
+    lat = res[1]
+    st["decode"], st["decode_h2d"] = sched.ctx.prof_stop(), sched.stream_stats()
+    if "prefill" not in st:          # a one-token generation: everything is the prefill
+        st["prefill"], st["prefill_h2d"], st["decode"], st["decode_h2d"] = st["decode"], st["decode_h2d"], None, (0.0, 0.0)
+    rows = []
+    for phase, wall in (("prefill", lat[0]), ("decode", sum(lat[1:]))):
+        pr = st[phase]
+        if pr is None:
+            continue
+        b, ms = st[phase + "_h2d"]
+        for regime in ("tiled", "skinny"):
+            n = pr[regime + "_launches"]
+            if n:
+                t = pr[regime + "_ms"]
+                rows.append((phase, f"GEMM {regime} (M {'> 256' if regime == 'tiled' else '<= 256'})", n, t, f"{pr[regime + '_flops'] / t / 1e9:.1f} TFLOP/s",
+                             f"{pr[regime + '_bytes'] / t / 1e6:.0f} GB/s"))
+        if pr["host_attention_calls"]:
+            rows.append((phase, "host attention (policy 2)", pr["host_attention_calls"], pr["host_attention_ms"], "", ""))
+        if b:
+            rows.append((phase, "weight stream H2D (copy engine busy)", "", ms, "", f"{b / max(ms, 1e-9) / 1e6:.1f} GB/s"))
+        rows.append((phase, "wall clock", "", 1e3 * wall, "", ""))
+    out("\n" + "-" * 10 + " Profile (one generate; HIP-event brackets per launch) " + "-" * 10)
+    out("%-8s %-40s %8s %12s %16s %12s" % ("phase", "what", "calls", "ms", "compute", "memory"))
+    for r in rows:
+        out("%-8s %-40s %8s %12.3f %16s %12s" % r)
+    return rows
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print(args)
@@ -172,6 +219,8 @@ def main(argv=None):
     if args.cpu_layers:
         generate_kwargs["cpu_layers"] = args.cpu_layers
     input_ids = synthetic_prompt(model.shape.vocab, int(args.input_tokens), args.batch_size)
+    if args.profile:
+        profile_once(model, input_ids, generate_kwargs)
     total_time, total_list = 0.0, []
     for i in range(args.num_iter):
         tic = time.time()

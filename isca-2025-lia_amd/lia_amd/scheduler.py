@@ -304,6 +304,11 @@ class OffloadScheduler:
         # them to the host caches then (lia_kv_deliver), instead of beside the prefill's weight stream.  LIA_DEFER_KV=0: deliver at once.
         self.defer_kv = os.environ.get("LIA_DEFER_KV", "1") != "0"
         self._kv_hold = None        # ((B, T, first streamed layer), [(k, v, KV struct) per streamed layer])
+        # every delivery ticket not yet waited for, whichever KVState it belongs to: ticket -> (weakref(KVState), layer).  The
+        # holding caches are shared by all generations of this scheduler, so a new prefill may only write them once ALL of these
+        # have landed (a generation that ended at its prefill, a second live KVState, a KVState reused with len reset)
+        self._outstanding = {}
+        self.kv_delivery = {"bytes": 0, "issue_to_landed_ms": None, "host_wait_ms": 0.0}   # of the last deferred delivery
 
     # -- resources -----------------------------------------------------------------------------------
     def _ensure(self, rows, B, T, n_gpu):
@@ -316,6 +321,7 @@ class OffloadScheduler:
                 self.pipe.close()
                 self.pipe = None
             if self.ctx is not None:
+                self._await_all_deliveries()      # their tickets die with the context
                 self.ctx.close()
             self.ctx = ops.Context(self.device, need)
             # the policy-2 host attention team: usable CPUs (affinity mask AND cgroup quota) split over the ranks, never
@@ -360,10 +366,26 @@ class OffloadScheduler:
         pend = getattr(kv_state, "pending", None)
         if not pend:
             return
+        import time
+        t0 = time.time()
         for i in ([idx] if idx is not None else sorted(pend)):
             t = pend.pop(i, None)
             if t is not None:
                 N.check(self.ctx.lib.lia_kv_deliver_wait(self.ctx.handle, t), "lia_kv_deliver_wait")
+                self._outstanding.pop(t, None)
+        self.kv_delivery["host_wait_ms"] += 1e3 * (time.time() - t0)
+        if not pend and self.kv_delivery.get("_issued_at") is not None:
+            self.kv_delivery["issue_to_landed_ms"] = 1e3 * (time.time() - self.kv_delivery.pop("_issued_at"))
+
+    def _await_all_deliveries(self):
+        """every outstanding delivery of this scheduler, whichever generation issued it: their copies read the shared holding
+        caches on the D2H stream, which the compute stream is about to overwrite"""
+        for t, (ref, idx) in list(self._outstanding.items()):
+            N.check(self.ctx.lib.lia_kv_deliver_wait(self.ctx.handle, t), "lia_kv_deliver_wait")
+            owner = ref()
+            if owner is not None and getattr(owner, "pending", None):
+                owner.pending.pop(idx, None)
+        self._outstanding.clear()
 
     def _resident(self, idx):
         if idx not in self.resident_ptrs:
@@ -426,6 +448,7 @@ class OffloadScheduler:
         first_streamed = n_gpu
         hold = None
         if is_prefill and policy == 0 and n_gpu < L and self.defer_kv and pos0 == 0:
+            self._await_all_deliveries()          # (host-blocking: afterwards nothing on the D2H stream reads the holding caches)
             hold = self._hold_caches(B, T, n_gpu)
         if policy == 1 and n_gpu < L:
             self._await_kv(kv_state)
@@ -454,8 +477,8 @@ class OffloadScheduler:
                 ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
                 x, y = y, x
                 continue
-            if not is_prefill:
-                self._await_kv(kv_state, idx)                      # a deferred K/V delivery of the prefill: the host cache must be complete
+            if hold is None:
+                self._await_kv(kv_state, idx)                      # a deferred K/V delivery of an earlier prefill: the host cache must be complete
             if idx in host_now:
                 x, y = self._host_decode_layer(idx, x, y, kv_state, B, T, pos0)
                 continue
@@ -494,7 +517,11 @@ class OffloadScheduler:
         logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
         if hold is not None:
             # the deferred deliveries, in the order the first decode step will need them; tickets are awaited per layer there
+            import time
+            import weakref
+            self._await_kv(kv_state)              # (a KVState reused for a second prefill: never drop a ticket unawaited)
             kv_state.pending = {}
+            self.kv_delivery = {"bytes": 0, "issue_to_landed_ms": None, "host_wait_ms": 0.0, "_issued_at": time.time()}
             for idx in range(n_gpu, L):
                 if kv_state.kv[idx].on_device:
                     continue
@@ -502,6 +529,8 @@ class OffloadScheduler:
                 N.check(ctx.lib.lia_kv_deliver(ctx.handle, ctypes.byref(hold[idx - n_gpu][2]), ctypes.byref(kv_state.kv[idx]), T,
                                                sh.hidden, ctypes.byref(t)), "lia_kv_deliver")
                 kv_state.pending[idx] = t.value
+                self._outstanding[t.value] = (weakref.ref(kv_state), idx)
+                self.kv_delivery["bytes"] += 2 * T * B * sh.hidden * 2
             N.check(ctx.lib.lia_ctx_synchronize_compute(ctx.handle), "lia_ctx_synchronize_compute")
         else:
             ctx.synchronize()
@@ -583,5 +612,6 @@ class OffloadScheduler:
             self.pipe.close()
             self.pipe = None
         if self.ctx:
+            self._await_all_deliveries()
             self.ctx.close()
             self.ctx = None

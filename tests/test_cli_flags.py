@@ -14,6 +14,7 @@ def test_flag_surface_and_defaults():
                                   "--decoding-policy 2 --gpu-percentage 10 --num-minibatch 2 --pin-weight --enable-cxl --no-overlap".split())
     assert (b.prefill_policy, b.decoding_policy, b.gpu_percentage, b.num_minibatch) == (0, 2, 10, 2)
     assert b.pin_weight and b.enable_cxl and b.no_overlap and b.token_latency and b.greedy and b.ipex and b.benchmark
+    assert not a.profile and build_parser().parse_args(["--profile"]).profile        # run_generation.py:103
     with pytest.raises(SystemExit):
         build_parser().parse_args(["--prefill-policy", "x"])
 

@@ -23,14 +23,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode):
+def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode, backend="gloo"):
     for p in (ROOT, os.path.join(ROOT, "isca-2025-lia_amd"), GOLD):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIA_DP_CHUNK_BYTES=str(96 * 1024), LIA_DP_STREAM=mode)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":          # RCCL: one rank per device, so world size 1 on the test box
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import synth
         from lia_amd import dp
@@ -61,7 +65,11 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode):
         assert (full.numpy() == z["ids_bf16"]).all()
         if g.is_root or mode == "allgather":       # the host copies really are in the wire format that was asked for
             assert all(st.packed == {"raw": 0, "pack10": 10}[fmt] for st in model.layers[n_gpu:]), [st.packed for st in model.layers]
-        if mode == "allgather":       # every rank pinned exactly its slice of every streamed layer's wire bytes
+        if backend == "nccl":
+            assert dist.get_backend() == "nccl" and model._lia_scheduler.pipe.copy_stream is not None
+            b, ms = model._lia_scheduler.stream_stats()
+            assert b > 0 and ms > 0          # the chunked copies really went through the streamer's copy stream
+        if mode == "allgather" and world > 1:       # every rank pinned exactly its slice of every streamed layer's wire bytes
             assert all(st.shard is not None and st.shard[:2] == (rank, world) for st in model.layers[n_gpu:])
         elif not g.is_root:
             assert all(st.tier == "remote" for st in model.layers[n_gpu:])
@@ -80,3 +88,16 @@ def test_two_ranks_one_gpu_match_golden(tmp_path, fmt, gpu_percentage, mode):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), fmt, "generate_h256", gpu_percentage, mode), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+@pytest.mark.parametrize("mode", ["broadcast", "allgather"])
+@pytest.mark.parametrize("fmt", ["raw", "pack10"])
+def test_rccl_backend_world1_streamer_matches_golden(tmp_path, fmt, mode):
+    """The code path the first multi-GPU run executes, with the REAL backend (torch.distributed "nccl" = RCCL) at the only world
+    size one GPU allows: meta broadcast, per-chunk lia_stream_copy_chunk + dist.broadcast(async_op=True) issued under
+    torch.cuda.stream(ExternalStream(copy stream)), work.wait() ordering, packed staging -> lia_stream_decode_packed ->
+    lia_stream_mark_ready, both LIA_DP_STREAM modes.  (r02 only ever ran it by hand with LIA_FORCE_DP=1.)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(1, port, str(tmp_path), fmt, "generate_h256", 25, mode, "nccl"), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()

@@ -1,0 +1,333 @@
+"""-m gpu: the PRODUCTION shapes against the CPU oracle (checker mode: fp32 FMA inner loops), through the C ABI.
+
+r02's full-size tests were self-consistency properties (tests/test_gpu_fullsize_properties.py); the oracle and the reference
+goldens stopped at H <= 512.  Here the kernels that only exist at the real sizes -- split-K slice counts at K = 7168 / 28672 /
+49152, RT = 2 workgroups, the 256 x 256 phased prefill GEMM, the fused norm combines, lm_head at vocab 50272 / 128256 -- are
+compared with `oracle/lia_oracle.c` (which restates decoder.py:172-335, attentions.py:312-557, models.py:424-431) on the same
+seeded inputs:
+
+  * one decode step of an OPT-30B-shaped layer (7168 / 56 / 28672, B = 64, S = 257) and of an OPT-175B-shaped layer
+    (12288 / 96 / 49152, B = 32), policies 3 (GPU attention over a device cache) and 2 (host attention over a host cache);
+  * the prefill of the same OPT-30B layer: B = 1 x T = 256 (M = 256, skinny regime + prefill attention) and B = 4 x T = 256
+    (M = 1024: the tiled 256 x 256 GEMM), whole layer vs oracle incl. the K/V rows;
+  * the M = 16384 prefill GEMMs of the headline (B 64 x T 256) for all four N / K pairs with their epilogues, checked on a
+    64-row sample of x (rows of a linear are independent);
+  * lm_head + argmax at the full vocabularies, reporting the smallest top-2 gap and the first disagreeing row (if any);
+  * one Llama-3-8B-shaped layer (4096 / 32 / 8 / 14336): decode B = 128 at S = 1025, prefill B = 2 x T = 1024.
+Tolerances are those of tests/test_gpu_ops.py::test_layer_forward_matches_reference_golden.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import synth
+from test_gpu_ops import assert_close, to_bits
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=0.07, rtol=0.016)
+OPT = {"opt-30b": (7168, 56, 28672, 64), "opt-175b": (12288, 96, 49152, 32)}       # H, heads, F, decode batch of the config
+
+
+def _bits(t):
+    import torch
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def _checker(oracle):
+    from lia_amd import hostinfo
+    oracle.lib().lia_oracle_set_threads(hostinfo.usable_cpus())
+    oracle.lib().lia_oracle_set_fast(0)          # fp32 FMA: the oracle as checker, not as the fast CPU baseline
+    return oracle
+
+
+def _randn(torch, shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    t = (scale * torch.randn(shape, generator=g, device="cuda")).to(torch.bfloat16).contiguous()
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.fixture(scope="module", params=sorted(OPT))
+def opt_layer(request):
+    """a seeded random layer of the shape, once on the device (packed flat buffer) and once as the oracle's dict of tensors"""
+    import torch
+    from lia_amd import ops
+    from lia_amd.model import OPTShape, draw_layer
+    H, heads, F, B = OPT[request.param]
+    desc = ops.make_desc(H, heads, F)
+    offs, total = ops.pack_offsets(desc)
+    flat = draw_layer(OPTShape(request.param, H, heads, F, 1), offs, total, li=0, seed=11)
+    g = torch.Generator(device="cuda").manual_seed(12)          # biases / LN: non-trivial values (draw_layer leaves them at 0 / 1)
+    for i, n in enumerate(ops.LAYER_TENSORS):
+        if n.endswith("_b") or n in ("ln1_w", "ln2_w"):
+            k = F if n == "fc1_b" else H
+            base = 1.0 if n.endswith("_w") else 0.0
+            flat[offs[i] // 2: offs[i] // 2 + k] = (base + 0.1 * torch.randn(k, generator=g, device="cuda")).to(torch.bfloat16)
+    torch.cuda.synchronize()
+    host = _bits(flat)
+    dims = {"q_w": (H, H), "k_w": (H, H), "v_w": (H, H), "out_w": (H, H), "fc1_w": (F, H), "fc2_w": (H, F)}
+    W = {}
+    for i, n in enumerate(ops.LAYER_TENSORS):
+        shp = dims.get(n, (F,) if n == "fc1_b" else (H,))
+        W[n] = host[offs[i] // 2: offs[i] // 2 + int(np.prod(shp))].reshape(shp)
+    ctx = ops.Context(0, ops.workspace_bytes(desc, 1024))
+    from lia_amd import hostinfo
+    ctx.set_host_threads(hostinfo.usable_cpus())          # the policy-2 host attention team (never omp_get_max_threads())
+    yield dict(name=request.param, H=H, heads=heads, F=F, B=B, desc=desc, flat=flat, W=W, ctx=ctx,
+               wptrs=ops.weight_ptr_array(flat.data_ptr(), offs))
+    ctx.close()
+    del flat
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("policy", [3, 2])
+def test_opt_decode_layer_vs_oracle(opt_layer, oracle, policy):
+    import torch
+    from lia_amd import _native as N
+    orc = _checker(oracle)
+    L = opt_layer
+    H, heads, B, T = L["H"], L["heads"], L["B"], 256
+    d = H // heads
+    kc = _randn(torch, (T + 2, B, heads, d), 21)
+    vc = _randn(torch, (T + 2, B, heads, d), 22)
+    okc, ovc = _bits(kc).copy(), _bits(vc).copy()
+    x = _randn(torch, (B, 1, H), 23)
+    if policy == 2:
+        hk, hv = kc.cpu().pin_memory(), vc.cpu().pin_memory()
+        kv = N.KV(hk.data_ptr(), hv.data_ptr(), T + 2, B, 0)
+    else:
+        hk, hv = kc, vc
+        kv = N.KV(kc.data_ptr(), vc.data_ptr(), T + 2, B, 1)
+    y = torch.empty_like(x)
+    L["ctx"].layer_forward(L["desc"], policy, L["wptrs"], x, y, kv, B, 1, T)
+    L["ctx"].synchronize()
+    ref = orc.layer_forward(policy, L["W"], _bits(x), okc, ovc, T, heads)
+    got = to_bits(y)
+    print(f"\n{L['name']} decode policy {policy}: {100 * (got == ref).mean():.2f} % bit-identical, "
+          f"max |err| {np.abs(synth.bf16_bits_to_f32(got) - synth.bf16_bits_to_f32(ref)).max():.4g}")
+    assert_close(got, ref, min_exact=0.75, what=f"{L['name']} decode policy {policy}", **TOL)
+    # the new K/V row (position T) landed in the cache the policy owns
+    assert_close(to_bits(hk)[T], okc[T], 0.03, 0.008, 0.95, "new K row")
+    assert_close(to_bits(hv)[T], ovc[T], 0.03, 0.008, 0.95, "new V row")
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_opt30b_prefill_layer_vs_oracle(opt_layer, oracle, B):
+    """B = 1: M = 256 rows (skinny GEMMs, prefill attention); B = 4: M = 1024 rows -> lia_gemm_tiled256p_kernel, the headline's
+    prefill GEMM.  Different rows (not the harness's identical rows): every row is checked on its own data."""
+    import torch
+    from lia_amd import _native as N
+    L = opt_layer
+    if L["name"] != "opt-30b":
+        pytest.skip("prefill case is the headline shape")
+    orc = _checker(oracle)
+    H, heads, T = L["H"], L["heads"], 256
+    d = H // heads
+    kc = torch.zeros((T, B, heads, d), dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    kv = N.KV(kc.data_ptr(), vc.data_ptr(), T, B, 1)
+    x = _randn(torch, (B, T, H), 31 + B)
+    y = torch.empty_like(x)
+    L["ctx"].layer_forward(L["desc"], 3, L["wptrs"], x, y, kv, B, T, 0)
+    L["ctx"].synchronize()
+    okc, ovc = np.zeros((T, B, heads, d), np.uint16), np.zeros((T, B, heads, d), np.uint16)
+    ref = orc.layer_forward(3, L["W"], _bits(x), okc, ovc, 0, heads)
+    got = to_bits(y)
+    print(f"\nopt-30b prefill B={B} T={T}: {100 * (got == ref).mean():.2f} % bit-identical")
+    assert_close(got, ref, min_exact=0.75, what=f"prefill B={B}", **TOL)
+    assert_close(to_bits(kc), okc, 0.03, 0.008, 0.95, "K rows")
+    assert_close(to_bits(vc), ovc, 0.03, 0.008, 0.95, "V rows")
+
+
+@pytest.mark.parametrize("which", ["qkv", "out", "fc1", "fc2"])
+def test_opt30b_m16384_gemm_on_sampled_rows(opt_layer, oracle, which):
+    """The headline's prefill GEMMs at M = 64 x 256 = 16384 with their real epilogues (bias; bias + residual; bias + ReLU),
+    oracle-checked on 64 sampled rows."""
+    import torch
+    L = opt_layer
+    if L["name"] != "opt-30b":
+        pytest.skip("M = 16384 is the headline's prefill")
+    orc = _checker(oracle)
+    H, F, W = L["H"], L["F"], L["W"]
+    M = 16384
+    from lia_amd import ops
+    offs = {n: i for i, n in enumerate(ops.LAYER_TENSORS)}
+    po, _ = ops.pack_offsets(L["desc"])
+    dev = lambda n, shape: L["flat"][po[offs[n]] // 2: po[offs[n]] // 2 + int(np.prod(shape))].view(*shape)  # noqa: E731
+    if which == "qkv":      # one [3H, H] GEMM over the adjacent q | k | v weights and biases
+        w, b, res, relu, K = dev("q_w", (3 * H, H)), dev("q_b", (3 * H,)), None, False, H
+        wo, bo = np.concatenate([W["q_w"], W["k_w"], W["v_w"]]), np.concatenate([W["q_b"], W["k_b"], W["v_b"]])
+    elif which == "out":
+        w, b, relu, K = dev("out_w", (H, H)), dev("out_b", (H,)), False, H
+        wo, bo = W["out_w"], W["out_b"]
+        res = _randn(torch, (M, H), 41)
+    elif which == "fc1":
+        w, b, res, relu, K = dev("fc1_w", (F, H)), dev("fc1_b", (F,)), None, True, H
+        wo, bo = W["fc1_w"], W["fc1_b"]
+    else:
+        w, b, relu, K = dev("fc2_w", (H, F)), dev("fc2_b", (H,)), False, F
+        wo, bo = W["fc2_w"], W["fc2_b"]
+        res = _randn(torch, (M, H), 42)
+    x = _randn(torch, (M, K), 43, 0.5 if which == "fc2" else 1.0)
+    y = L["ctx"].linear(x, w, b, res, relu=relu)
+    L["ctx"].synchronize()
+    rows = np.random.RandomState(7).choice(M, 64, replace=False)
+    rows.sort()
+    ridx = torch.from_numpy(rows).cuda()
+    ref = orc.linear(_bits(x[ridx]), wo, bo, None if res is None else _bits(res[ridx]), relu=relu)
+    got = to_bits(y[ridx])
+    print(f"\nM=16384 {which}: {100 * (got == ref).mean():.2f} % bit-identical on {len(rows)} sampled rows")
+    assert_close(got, ref, atol=0.035 if res is not None else 0.02, rtol=0.008, min_exact=0.97, what=f"tiled {which}")
+
+
+def _report_argmax(name, logits_bits, nxt, ref_logits, ref_next):
+    rl = synth.bf16_bits_to_f32(ref_logits)
+    top2 = np.sort(rl, -1)[:, -2:]
+    gaps = top2[:, 1] - top2[:, 0]
+    bad = np.nonzero(nxt != ref_next)[0]
+    first = None if bad.size == 0 else int(bad[0])
+    print(f"\n{name}: argmax rows equal {int((nxt == ref_next).sum())}/{len(nxt)}, smallest top-2 gap {gaps.min():.4g}, "
+          f"first disagreeing row {first}" + ("" if first is None else f" (its gap {gaps[first]:.4g})"))
+    return gaps, bad
+
+
+def test_opt_lm_head_full_vocab(oracle):
+    """final LN + tied lm_head + argmax at vocab 50272 x H 7168 (models.py:424-431, greedy_search.py:367)."""
+    import torch
+    from lia_amd import ops
+    orc = _checker(oracle)
+    B, T, H, vocab = 4, 3, 7168, 50272
+    hid, emb = _randn(torch, (B, T, H), 51, 2.0), _randn(torch, (vocab, H), 52, 0.02)
+    lnw, lnb = (1.0 + 0.1 * _randn(torch, (H,), 53).float()).to(torch.bfloat16), _randn(torch, (H,), 54, 0.1)
+    ctx = ops.Context(0, 2 * 256 * H + 8 * B * vocab * 4 + (1 << 20))
+    logits, nxt = ctx.lm_head(hid, lnw, lnb, emb)
+    ctx.synchronize()
+    ref_logits, ref_next = orc.lm_head(_bits(hid), _bits(lnw), _bits(lnb), _bits(emb))
+    got = to_bits(logits)
+    assert_close(got, ref_logits, 0.03, 0.01, 0.95, "logits at vocab 50272")
+    nx = nxt.cpu().numpy()
+    assert (nx == synth.bf16_bits_to_f32(got).argmax(-1)).all()          # first maximal index of the GPU's own logits
+    gaps, bad = _report_argmax("opt lm_head 50272", got, nx, ref_logits, ref_next)
+    # a disagreement is legitimate only on a near-tie of the ORACLE's logits (one bf16 ulp at the logit's magnitude)
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(synth.bf16_bits_to_f32(ref_logits)).max(-1))) - 7)
+    assert all(gaps[r] <= 2 * ulp[r] for r in bad), (bad, gaps[bad], ulp[bad])
+    ctx.close()
+
+
+def test_llama_lm_head_full_vocab(oracle):
+    """final RMSNorm + untied lm_head + argmax at vocab 128256 x H 4096 (Llama-3-8B)."""
+    import torch
+    from lia_amd import _native as N, ops
+    orc = _checker(oracle)
+    lib = N.lib()
+    B, T, H, vocab = 4, 2, 4096, 128256
+    hid, lm = _randn(torch, (B, T, H), 61, 2.0), _randn(torch, (vocab, H), 62, 0.02)
+    nw = (1.0 + 0.1 * _randn(torch, (H,), 63).float()).to(torch.bfloat16)
+    ctx = ops.Context(0, 2 * 256 * H + 8 * B * vocab * 4 + (1 << 20))
+    logits = torch.empty((B, vocab), dtype=torch.bfloat16, device="cuda")
+    nxt = torch.empty((B,), dtype=torch.int64, device="cuda")
+    N.check(lib.lia_llama_lm_head(ctx.handle, ctypes.c_void_p(hid.data_ptr()), B, T, H, ctypes.c_void_p(nw.data_ptr()),
+                                  ctypes.c_void_p(lm.data_ptr()), vocab, 1e-5, -1, ctypes.c_void_p(logits.data_ptr()),
+                                  ctypes.c_void_p(nxt.data_ptr()), ctypes.c_void_p(ctx.stream)), "lia_llama_lm_head")
+    ctx.synchronize()
+    L = orc._llama_lib()
+    ref_logits, ref_next = np.empty((B, vocab), np.uint16), np.empty((B,), np.int64)
+    hb, nb, lb = _bits(hid), _bits(nw), _bits(lm)
+    L.lia_oracle_llama_lm_head(orc._p(hb), orc._p(nb), orc._p(lb), orc._p(ref_logits), orc._p(ref_next), B, T, H, vocab, 1e-5)
+    got = to_bits(logits)
+    assert_close(got, ref_logits, 0.03, 0.01, 0.95, "logits at vocab 128256")
+    nx = nxt.cpu().numpy()
+    assert (nx == synth.bf16_bits_to_f32(got).argmax(-1)).all()
+    gaps, bad = _report_argmax("llama lm_head 128256", got, nx, ref_logits, ref_next)
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(synth.bf16_bits_to_f32(ref_logits)).max(-1))) - 7)
+    assert all(gaps[r] <= 2 * ulp[r] for r in bad), (bad, gaps[bad], ulp[bad])
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def llama_layer():
+    import torch
+    from lia_amd import ops
+    from lia_amd.llama import LiaLlamaModel, LlamaShape, rope_tables
+    H, heads, kvh, F = 4096, 32, 8, 14336
+    shape = LlamaShape("llama-3-8b-1layer", H, heads, kvh, F, 1, 64, max_pos=2048)
+    model = LiaLlamaModel(shape)
+    KD = kvh * (H // heads)
+    dims = {"in_norm_w": (H,), "q_w": (H, H), "k_w": (KD, H), "v_w": (KD, H), "o_w": (H, H), "post_norm_w": (H,), "gate_w": (F, H),
+            "up_w": (F, H), "down_w": (H, F)}
+    W = {}
+    for j, (n, shp) in enumerate(dims.items()):
+        t = _randn(torch, shp, 70 + j, 0.02)
+        if n.endswith("norm_w"):
+            t = (1.0 + 5.0 * t.float()).to(torch.bfloat16)
+        W[n] = _bits(t)
+    model._pack_numpy(model.layers[0], W)
+    model.layers[0].to_device()
+    from lia_amd import _native as N
+    ctx = ops.Context(0, N.lib().lia_llama_workspace_bytes(ctypes.byref(model.desc), 2048))
+    cos, sin = rope_tables(2048, H // heads, shape.rope_theta)
+    w = (ctypes.c_void_p * 9)(*[model.layers[0].device_ptr() + o for o in model.offsets])
+    yield dict(model=model, W=W, ctx=ctx, cos=cos, sin=sin, w=w, H=H, heads=heads, kvh=kvh, F=F, theta=shape.rope_theta)
+    ctx.close()
+    model.close()
+    torch.cuda.empty_cache()
+
+
+def _llama_run(L, x, kv, B, T, pos0):
+    import torch
+    from lia_amd import _native as N
+    y = torch.empty_like(x)
+    N.check(N.lib().lia_llama_layer_forward(L["ctx"].handle, ctypes.byref(L["model"].desc), ctypes.byref(L["w"]), ctypes.c_void_p(x.data_ptr()),
+                                            ctypes.c_void_p(y.data_ptr()), ctypes.byref(kv), ctypes.c_void_p(L["cos"].data_ptr()),
+                                            ctypes.c_void_p(L["sin"].data_ptr()), B, T, pos0, 0, ctypes.c_void_p(L["ctx"].stream)),
+            "lia_llama_layer_forward")
+    L["ctx"].synchronize()
+    return y
+
+
+def test_llama3_8b_decode_layer_vs_oracle(llama_layer, oracle):
+    """BASELINE config 4's decode step: B = 128, S = 1025, grouped-query attention over a device cache, fused RoPE / RMSNorm /
+    SiLU combines, against the oracle's restatement of HF's eager bf16 Llama."""
+    import torch
+    from lia_amd import _native as N
+    orc = _checker(oracle)
+    L = llama_layer
+    H, heads, kvh, B, S0 = L["H"], L["heads"], L["kvh"], 128, 1024
+    d = H // heads
+    kc, vc = _randn(torch, (S0 + 2, B, kvh, d), 81), _randn(torch, (S0 + 2, B, kvh, d), 82)
+    okc, ovc = _bits(kc).copy(), _bits(vc).copy()
+    x = _randn(torch, (B, 1, H), 83)
+    kv = N.KV(kc.data_ptr(), vc.data_ptr(), S0 + 2, B, 1)
+    y = _llama_run(L, x, kv, B, 1, S0)
+    ocos, osin = orc.rope_tables(2048, d, L["theta"])
+    ref = orc.llama_layer_forward(L["W"], _bits(x), okc, ovc, ocos, osin, S0, heads, kvh)
+    got = to_bits(y)
+    print(f"\nllama-3-8b decode B={B} S={S0 + 1}: {100 * (got == ref).mean():.2f} % bit-identical")
+    assert_close(got, ref, 0.07, 0.016, 0.7, "llama-3-8b decode layer")
+    assert_close(to_bits(kc)[S0], okc[S0], 0.03, 0.008, 0.95, "new post-RoPE K row")
+    assert_close(to_bits(vc)[S0], ovc[S0], 0.03, 0.008, 0.95, "new V row")
+
+
+def test_llama3_8b_prefill_layer_vs_oracle(llama_layer, oracle):
+    """B = 2 x T = 1024 (M = 2048: the tiled GEMM with the SiLU.up epilogue over interleaved gate | up rows, the d = 128 prefill
+    attention with 4 query heads per K/V head) against the oracle."""
+    import torch
+    from lia_amd import _native as N
+    orc = _checker(oracle)
+    L = llama_layer
+    H, heads, kvh, B, T = L["H"], L["heads"], L["kvh"], 2, 1024
+    d = H // heads
+    kc = torch.zeros((T, B, kvh, d), dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    kv = N.KV(kc.data_ptr(), vc.data_ptr(), T, B, 1)
+    x = _randn(torch, (B, T, H), 84)
+    y = _llama_run(L, x, kv, B, T, 0)
+    okc, ovc = np.zeros((T, B, kvh, d), np.uint16), np.zeros((T, B, kvh, d), np.uint16)
+    ocos, osin = orc.rope_tables(2048, d, L["theta"])
+    ref = orc.llama_layer_forward(L["W"], _bits(x), okc, ovc, ocos, osin, 0, heads, kvh)
+    got = to_bits(y)
+    print(f"\nllama-3-8b prefill B={B} T={T}: {100 * (got == ref).mean():.2f} % bit-identical")
+    assert_close(got, ref, 0.07, 0.016, 0.7, "llama-3-8b prefill layer")
+    assert_close(to_bits(kc), okc, 0.03, 0.008, 0.95, "post-RoPE K rows")
+    assert_close(to_bits(vc), ovc, 0.03, 0.008, 0.95, "V rows")
