@@ -60,6 +60,10 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raw-leg", action="store_true", help="skip the second, shorter leg with raw bf16 on the wire")
     ap.add_argument("--raw-steps", type=int, default=6)
+    ap.add_argument("--no-cooperative-leg", action="store_true", help="skip the build-defined cooperative-split leg (value_cooperative)")
+    ap.add_argument("--coop-steps", type=int, default=16, help="decode steps of the cooperative leg (the controller settles in the first half)")
+    ap.add_argument("--no-dp-extra-legs", action="store_true", help="N > 1: skip the KV-in-HBM and all-gather legs")
+    ap.add_argument("--dp-extra-steps", type=int, default=6)
     ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the policy-1 CPU baseline leg")
     ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
     ap.add_argument("--cxl-nodes", default=None, help="NUMA nodes of the CXL tier, e.g. 2,3 (default LIA_CXL_NODES or 2,3)")
@@ -169,6 +173,71 @@ def cpu_oracle_sample(shape, B, T, threads):
                       f"scaled x{L} layers (x{B // Bp} batch for prefill); embeddings / lm_head excluded"}
 
 
+def parity_sample(sched, model, shape, B, T, threads):
+    """The oracle as CHECKER at the benchmark's own shape: one decode step (S = T + 1) of ONE layer of the model's shape through
+    lia_layer_forward (policy 2: GPU linears, host attention over a host cache -- the headline's decode policy) and through
+    oracle.layer_forward (fp32 FMA mode) on the SAME tensors.  Reported, not asserted (tests/test_gpu_fullsize_oracle.py asserts)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch
+    import lia_oracle as orc
+    from lia_amd import _native as N, ops
+    from lia_amd.model import draw_layer
+    orc.lib().lia_oracle_set_threads(threads)
+    orc.lib().lia_oracle_set_fast(0)
+    H, F, heads = shape.hidden, shape.ffn, shape.heads
+    d = H // heads
+    bits = lambda t: t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    flat = draw_layer(shape, model.offsets, model.layer_bytes, li=7, seed=123)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *shp: torch.randn(*shp, generator=g, device="cuda").to(torch.bfloat16)  # noqa: E731
+    x, kc, vc = rnd(B, 1, H), rnd(T + 2, B, heads, d), rnd(T + 2, B, heads, d)
+    torch.cuda.synchronize()
+    host = bits(flat)
+    dims = {"q_w": (H, H), "k_w": (H, H), "v_w": (H, H), "out_w": (H, H), "fc1_w": (F, H), "fc2_w": (H, F)}
+    W = {}
+    for i, n in enumerate(ops.LAYER_TENSORS):
+        shp = dims.get(n, (F,) if n == "fc1_b" else (H,))
+        W[n] = host[model.offsets[i] // 2: model.offsets[i] // 2 + int(np.prod(shp))].reshape(shp)
+    hk, hv = kc.cpu().pin_memory(), vc.cpu().pin_memory()
+    okc, ovc = bits(hk).copy(), bits(hv).copy()
+    kv = N.KV(hk.data_ptr(), hv.data_ptr(), T + 2, B, 0)
+    y = torch.empty_like(x)
+    sched.ctx.layer_forward(model.desc, 2, ops.weight_ptr_array(flat.data_ptr(), model.offsets), x, y, kv, B, 1, T)
+    sched.ctx.synchronize()
+    t0 = time.time()
+    ref = orc.layer_forward(2, W, bits(x), okc, ovc, T, heads)
+    oracle_s = time.time() - t0
+    got = bits(y)
+    f32 = lambda b: (b.astype(np.uint32) << 16).view(np.float32)  # noqa: E731
+    a, b = f32(got), f32(ref)
+    err = np.abs(a - b)
+    q = 2.0 ** (np.floor(np.log2(float(np.abs(b).max()))) - 7)
+    return {"what": f"one {shape.name}-shaped layer, decode step B={B} S={T + 1}, policy 2: lia_layer_forward vs oracle.layer_forward (fp32 FMA) on the same tensors",
+            "max_abs": float(err.max()), "frac_bit_identical": float((got == ref).mean()), "max_abs_ref": float(np.abs(b).max()),
+            "bf16_quantum_at_max_ref": q, "max_err_in_quanta": float(err.max() / q), "frac_within_one_quantum": float((err <= q).mean()),
+            "new_kv_row_frac_bit_identical": float(((bits(hk)[T] == okc[T]).mean() + (bits(hv)[T] == ovc[T]).mean()) / 2),
+            "oracle_layer_s": oracle_s,
+            "note": "per-op identity is >= 99.9 % (tests/test_gpu_fullsize_oracle.py); a whole layer amplifies each op's one-ulp flips "
+                    "by ~2*sqrt(p) per GEMM at K >= 7168, hence the lower whole-layer identity rate with a bounded error"}
+
+
+def first_divergence(ids_a, ids_b, T, logits_b=None):
+    """compare the generated tokens of two legs over their common length -> {"ids_equal", "steps_compared", "first_divergent_step",
+    "top2_logit_gap_at_divergence"} (the gap from leg b's logits of that step, row 0)"""
+    import numpy as np
+    n = min(ids_a.shape[1], ids_b.shape[1]) - T
+    a, b = ids_a[:, T:T + n].numpy(), ids_b[:, T:T + n].numpy()
+    diff = np.nonzero((a != b).any(axis=0))[0]
+    out = {"ids_equal": bool(diff.size == 0), "steps_compared": int(n), "first_divergent_step": None if diff.size == 0 else int(diff[0])}
+    if diff.size and logits_b is not None and int(diff[0]) < len(logits_b):
+        import torch
+        lg = logits_b[int(diff[0])][0].float()
+        top = torch.topk(lg, 2).values
+        out["top2_logit_gap_at_divergence"] = float(top[0] - top[1])
+    return out
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
     (profiles/r02_opt30b_bench_pmc_hbm.json, tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).
@@ -187,6 +256,59 @@ def pmc_traffic(kernel_substr):
     except (OSError, ValueError, KeyError):
         pass
     return None, None
+
+
+def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index):
+    """N > 1 (every rank calls this): value_kv_in_hbm -- the same broadcast stream with policy 3/3 (KV cache in HBM, no host
+    attention: what removes the per-rank host-thread bottleneck) -- and value_allgather -- every rank pins 1/N of each streamed
+    layer and reads it over ITS OWN host link, one all-gather per layer over xGMI.  Short legs (--dp-extra-steps)."""
+    import torch
+    from lia_amd.generation import generate
+    from lia_amd.model import LiaOPTModel
+    from lia_amd.scheduler import OffloadScheduler
+    dev = "cuda" if backend == "nccl" else "cpu"
+    res = {}
+
+    def leg(name, mdl, kwargs):
+        t0 = time.time()
+        try:
+            generate(mdl, ids, max_steps=2, **kwargs)                          # placement / allocations of this leg, untimed
+            sc = mdl._lia_scheduler
+            sc.stream_stats(reset=True)
+            dist.barrier()
+            torch.cuda.synchronize()
+            _, lat = generate(mdl, ids, max_steps=2 + a.dp_extra_steps, **kwargs)
+            dec = sum(lat[2:]) / len(lat[2:])
+            h2d_b, _ = sc.stream_stats()
+            v = torch.tensor([dec, lat[0], h2d_b / max(sum(lat), 1e-9) / 1e9], dtype=torch.float64, device=dev)
+            allv = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(allv, v)
+            worst = max(float(x[0]) for x in allv)
+            res["value_" + name] = B * world / worst
+            res[name + "_leg"] = {"decode_steps_timed": len(lat[2:]), "ms_per_step": 1e3 * worst, "prefill_ms": 1e3 * max(float(x[1]) for x in allv),
+                                  "per_rank_h2d_gbs": [float(x[2]) for x in allv], "leg_s": time.time() - t0}
+        except Exception as e:                                                  # (every rank takes the same branch: same shapes, same flags)
+            res[name + "_leg"] = {"error": f"{type(e).__name__}: {e}"}
+
+    leg("kv_in_hbm", model, dict(gen_kwargs, prefill_policy=3, decoding_policy=3))
+    if group.mode != "allgather" and world > 1:
+        # every rank needs its own slice of every streamed layer: the root gives its copies up, all ranks draw the (seeded) layers
+        # again and pin slice r of G.  The resident layers and the head stay as they are.
+        sched.close()
+        for st in model.layers[n_gpu:]:
+            st.close()
+        group.mode = "allgather"
+        try:
+            m2 = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, host_owner=True, pack12=fmt,
+                                         shard=(rank, world))
+            m2._lia_scheduler = OffloadScheduler(m2, device=dev_index, dp_group=group, pack12=fmt)
+            m2._lia_scheduler.host_threads = host_threads
+            leg("allgather", m2, gen_kwargs)
+            m2._lia_scheduler.close()
+            m2.close()
+        except Exception as e:
+            res["allgather_leg"] = {"error": f"{type(e).__name__}: {e}"}
+    return res
 
 
 def main(argv=None):
@@ -247,16 +369,20 @@ def main(argv=None):
         raise SystemExit("prompt + steps exceeds max positions")
     n_gpu = shape.layers if (is_llama and a.gpu_percentage >= 100) else int(shape.layers * a.gpu_percentage / 100)
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
+    coop_start = None
     if a.cpu_layers < 0 and not is_llama:
+        # -1: the scheduler's online controller picks the count from the measured decode steps; the planner only seeds it
         from lia_amd import planner
-        a.cpu_layers, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
-                                                  planner.Box(host_threads=host_threads,
-                                                              wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
-                                                  kv_in_hbm=(a.prefill_policy == 3 and a.decoding_policy == 3))
+        coop_start, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
+                                                planner.Box(host_threads=host_threads,
+                                                            wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
+                                                kv_in_hbm=(a.prefill_policy == 3 and a.decoding_policy == 3))
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
                  gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=a.enable_cxl, no_overlap=False)
     if a.cpu_layers:
         flags["cpu_layers"] = a.cpu_layers
+        if coop_start is not None:
+            flags["cpu_layers_start"] = coop_start
     if a.cxl_nodes:
         from lia_amd.cxl.numa_alloc import set_cxl_nodes
         set_cxl_nodes([int(v) for v in a.cxl_nodes.split(",")])
@@ -274,7 +400,7 @@ def main(argv=None):
                                         host_owner=(group is None or group.is_root or group.mode == "allgather"), pack12=fmt,
                                         shard=((rank, world) if (group is not None and world > 1 and group.mode == "allgather") else None),
                                         raw_layers=(OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, a.cpu_layers)
-                                                    if (a.cpu_layers and a.decoding_policy in (2, 3) and group is None) else ()))
+                                                    if (a.cpu_layers > 0 and a.decoding_policy in (2, 3) and group is None) else ()))
         sched = OffloadScheduler(model, device=dev_index, dp_group=group, pack12=fmt)
         sched.host_threads = host_threads
     model._lia_scheduler = sched                         # generate() drives this scheduler
@@ -323,17 +449,20 @@ def main(argv=None):
     timed = sorted(lat[1 + a.warmup:])
     host_attn_ms_step = prof.get("host_attention_ms", 0.0) / max(1, a.steps)
 
-    rccl_ranks, per_rank = 1, [{"rank": 0, "host_attention_threads": host_threads, "host_attention_ms_per_step": host_attn_ms_step}]
+    my_h2d_gbs = h2d_bytes / (elapsed * 1e9)
+    rccl_ranks, per_rank = 1, [{"rank": 0, "host_attention_threads": host_threads, "host_attention_ms_per_step": host_attn_ms_step,
+                                "h2d_gbs": my_h2d_gbs}]
     if dist is not None:
         dev = "cuda" if backend == "nccl" else "cpu"
         tmax = torch.tensor([elapsed, prefill_ms, dec_mean_s], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, prefill_ms, dec_mean_s = float(tmax[0]), float(tmax[1]), float(tmax[2])
-        mine = torch.tensor([float(rank), float(host_threads), host_attn_ms_step], dtype=torch.float64, device=dev)
+        mine = torch.tensor([float(rank), float(host_threads), host_attn_ms_step, my_h2d_gbs], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)                      # a real collective over the communicator the run used
         rccl_ranks = dist.get_world_size()
-        per_rank = [{"rank": int(v[0]), "host_attention_threads": int(v[1]), "host_attention_ms_per_step": float(v[2])} for v in allr]
+        per_rank = [{"rank": int(v[0]), "host_attention_threads": int(v[1]), "host_attention_ms_per_step": float(v[2]),
+                     "h2d_gbs": float(v[3])} for v in allr]
 
     out = None
     if rank == 0:
@@ -346,32 +475,55 @@ def main(argv=None):
         achieved = prof["skinny_bytes"] / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
         traffic, traffic_src = (pmc_traffic("lia_gemm_skinny2_kernel<4") if (a.model == "opt-30b" and B == 64) else (None, None))
         headline = (a.model == "opt-30b" and B * world == 64 and T == 256 and a.gpu_percentage == 10 and not a.cpu_layers)
+        config5 = (a.model == "opt-30b" and a.global_batch == 256 and T == 256 and a.gpu_percentage == 10 and world > 1)
+        streamed = (not is_llama) and n_gpu < shape.layers
+        link_gbs = h2d_bytes / (elapsed * 1e9)
+        kvd = dict(getattr(sched, "kv_delivery", None) or {})
+        kvd.pop("_issued_at", None)
         wire_bytes = float(sum(s.stream_bytes for s in model.layers[n_gpu:] if s.tier not in ("device", "remote", None))) if not is_llama else 0.0
         raw_bytes = float(sum(s.nbytes for s in model.layers[n_gpu:] if s.tier not in ("device", "remote", None))) if not is_llama else 0.0
         out = {
             "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if headline
-                      else f"decode tokens/s (+ prefill ms), {a.model} bs={B * world} in{T} gpu%={a.gpu_percentage}",
+                      else ("decode tokens/s (+ prefill ms), OPT-30B bs=256 in256/out32 gpu%=10 batch-sharded (BASELINE config 5)" if config5
+                            else f"decode tokens/s (+ prefill ms), {a.model} bs={B * world} in{T} gpu%={a.gpu_percentage}"),
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{shape.name} shape (random-init {'U[0,1)' if a.init == 'uniform01' else 'N(0,0.02)'}), batch {B}/GPU identical rows, "
                                    f"prompt {T}, {new} new tokens, gpu%={a.gpu_percentage} ({n_gpu} resident + {shape.layers - n_gpu} streamed layers), "
                                    f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
-                                   f"num-minibatch {a.num_minibatch}{', ' + str(a.cpu_layers) + ' decode layers on the host cores' if a.cpu_layers else ''}",
-                       "global_batch": B * world, "prompt_len": T, "new_tokens": new,
+                                   f"num-minibatch {a.num_minibatch}{(', ' + (str(a.cpu_layers) if a.cpu_layers > 0 else 'an online-chosen number of') + ' decode layers on the host cores') if a.cpu_layers else ''}",
+                       "global_batch": B * world, "prompt_len": T, "new_tokens": new, "new_tokens_requested": 32 if not is_llama else 128,
+                       "new_tokens_note": f"the configuration asks for {32 if not is_llama else 128} new tokens; this run generated 1 + warmup + steps = {new} "
+                                          f"(cache sized for {T + new} positions), so the timed decode steps run at S = {T + 1 + a.warmup}..{T + new - 1}",
+                       "baseline_config": ("configs[1]" if headline else "configs[4]" if config5 else None),
                        "parallelism": (f"dp{world} batch-shard, {group.mode} weight stream" if world > 1 else "single GPU"),
                        "host_attention_threads": host_threads, "host_numa_node": pin_node if pinned_cpus else None},
             "prefill_ms": prefill_ms,
+            "prefill_ms_note": ("first-token latency = latency_list[0] (run_generation.py:345).  With the policy-0 prefill the K/V rows of the streamed "
+                                "layers are parked in HBM and delivered to the host caches AFTER the first token (kv_delivery below; LIA_DEFER_KV=0 "
+                                "delivers beside the prefill as the reference's store_cache does, modeling_opt.py:334-345), so unlike the reference's "
+                                "number this one does not contain the D2H of the cache; prefill_ms_incl_kv_delivery does") if (streamed and kvd.get("bytes")) else None,
+            "kv_delivery": ({"deferred": True, "bytes": kvd.get("bytes"), "issue_to_landed_ms": kvd.get("issue_to_landed_ms"),
+                             "host_wait_ms_in_first_decode_step": kvd.get("host_wait_ms"), "first_decode_step_ms": 1e3 * lat[1] if len(lat) > 1 else None}
+                            if (streamed and kvd.get("bytes")) else {"deferred": False}),
+            "prefill_ms_incl_kv_delivery": (prefill_ms + (kvd.get("issue_to_landed_ms") or 0.0)) if (streamed and kvd.get("bytes")) else prefill_ms,
             "protocol": {"entry_point": "lia_amd.generation.generate(token_latency=True)", "max_new_tokens": new,
                          "prefill_ms": prefill_ms, "decode_tokens_per_s": B * world / dec_mean_s,
                          "definition": "prefill = latency_list[0]; decode = batch / mean(latency_list[1:]) (run_generation.py:345-354); "
                                        "`value` brackets the last --steps decode steps with barrier + synchronize"},
             "decode_latency_ms": {"mean": 1e3 * sum(timed) / len(timed), "p90": 1e3 * timed[int(0.9 * (len(timed) - 1))], "max": 1e3 * timed[-1]},
-            "roofline": {"bound": "hbm", "kernel": "lia_gemm_skinny2_kernel<4,3,1,8,RT> (RT = 1 and 2; decode linears + lm_head)",
+            "roofline": ({"bound": "pcie", "what": "the timed decode step is bound by the host link: every streamed layer crosses it once per step",
+                          "achieved": link_gbs, "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": link_gbs / PCIE_PEAK_GBS,
+                          "traffic": h2d_bytes / a.steps, "traffic_what": "wire bytes per decode step counted by the streamer (lia_stream_stats)",
+                          "copy_engine_busy_frac": (h2d_ms * 1e-3) / elapsed, "dominant_kernel": None} if streamed else
+                         {"bound": "hbm", "dominant_kernel": None}),
+            "dominant_kernel_roofline": {"bound": "hbm", "kernel": "lia_gemm_skinny2_kernel<MT,3,NT,8,RT> (decode linears + lm_head)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "launches": prof["skinny_launches"], "bracket_stride": a.bracket_stride, "avg_launch_us": 1e3 * sk_ms / sk_n,
                          "avg_bracket_us_raw": 1e3 * sk_raw_ms / sk_n, "empty_bracket_us": 1e3 * prof.get("empty_bracket_ms", 0.0),
-                         "algorithmic_bytes_per_launch": prof["skinny_bytes"] / sk_n},
+                         "algorithmic_bytes_per_launch": prof["skinny_bytes"] / sk_n,
+                         "share_of_step": (sk_ms * a.bracket_stride / a.steps) / (1e3 * elapsed / a.steps)},
             "host_link": {"bound": "pcie", "stream_format": a.stream_format if not is_llama else "raw",
                           "bits_per_value": (16.0 * wire_bytes / raw_bytes) if raw_bytes else None,
                           "weight_bytes_per_step": raw_bytes if not is_llama else None,
@@ -387,17 +539,48 @@ def main(argv=None):
                                   "note": "cgroup CFS quota stalls during the timed decode steps (cpu.stat)"},
             "build_s": build_s,
         }
+        if a.cpu_layers < 0 and not is_llama:
+            out["cooperative_controller"] = sched.coop_report()
+        dk = out.pop("dominant_kernel_roofline")
+        if streamed:
+            out["roofline"]["dominant_kernel"] = dk
+        else:                       # all-resident: the decode GEMM IS the binding roofline
+            out["roofline"] = dict(dk, dominant_kernel=None)
 
     # ---- second leg: the same streamed layers as RAW bf16 (what the reference ships), same model object, re-tiered ----------
+    ids_check = {}
     if rank == 0 and world == 1 and not is_llama and fmt and not a.no_raw_leg and n_gpu < shape.layers:
         sched.pack12 = 0
         t0 = time.time()
-        _, lat_raw = generate(model, ids, max_steps=2 + a.raw_steps, **gen_kwargs)
+        ids_raw, lat_raw, logits_raw = generate(model, ids, max_steps=2 + a.raw_steps, return_logits=True, **gen_kwargs)
         out["value_raw_format"] = B / (sum(lat_raw[2:]) / len(lat_raw[2:]))
         out["raw_format_leg"] = {"stream_format": "raw", "decode_steps_timed": len(lat_raw[2:]), "prefill_ms": 1e3 * lat_raw[0],
                                  "ms_per_step": 1e3 * sum(lat_raw[2:]) / len(lat_raw[2:]), "retier_and_run_s": time.time() - t0,
                                  "note": "same model object re-placed from the packed wire format to raw bf16; first decode step untimed"}
+        ids_check[f"{a.stream_format}_vs_raw_wire"] = first_divergence(out_ids, ids_raw, T, logits_raw)
+        del logits_raw
         sched.pack12 = fmt
+
+    # ---- build-defined cooperative split, beside (never instead of) the headline: the planner's host-computed layer count ------
+    if rank == 0 and world == 1 and not is_llama and not a.no_cooperative_leg and not a.cpu_layers and a.decoding_policy == 2 \
+            and n_gpu < shape.layers:
+        try:
+            from lia_amd import planner
+            t0 = time.time()
+            c0, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
+                                            planner.Box(host_threads=host_threads,
+                                                        wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]))
+            coop_kwargs = dict(gen_kwargs, cpu_layers=-1, cpu_layers_start=c0)      # -1: the scheduler's online controller, seeded by the plan
+            ids_coop, lat_coop = generate(model, ids, max_steps=2 + a.coop_steps, **coop_kwargs)
+            tail = lat_coop[-max(1, a.coop_steps // 2):]                             # after the controller has settled
+            out["value_cooperative"] = B / (sum(tail) / len(tail))
+            out["cooperative_leg"] = {"planned_host_layers": c0, "controller": sched.coop_report(), "decode_steps": len(lat_coop) - 1,
+                                      "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail), "leg_s": time.time() - t0,
+                                      "note": "decode layers computed on the host cores never cross the link (build-defined, SURVEY 8 f-3); "
+                                              "the count is adjusted online from the measured copy-engine idle time"}
+            ids_check["cooperative_vs_headline"] = first_divergence(out_ids, ids_coop, T)
+        except Exception as e:
+            out["cooperative_leg"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline: the reference's policy 1 ("compute everything on CPU", IPEX/AMX there) on this box's host cores ----------
     if rank == 0 and world == 1 and not is_llama and not a.no_cpu_baseline:
@@ -406,12 +589,14 @@ def main(argv=None):
         product = None
         try:
             t0 = time.time()
-            _, lat_cpu = generate(model, ids, max_steps=2 + a.cpu_steps, **cpu_kwargs)
+            ids_cpu, lat_cpu, logits_cpu = generate(model, ids, max_steps=2 + a.cpu_steps, return_logits=True, **cpu_kwargs)
             product = {"decode_tokens_per_s": B / (sum(lat_cpu[2:]) / len(lat_cpu[2:])), "decode_steps_timed": len(lat_cpu[2:]),
                        "ms_per_step": 1e3 * sum(lat_cpu[2:]) / len(lat_cpu[2:]), "leg_s": time.time() - t0,
                        "sample": f"generate(prefill_policy=0, decoding_policy=1, gpu_percentage=0): {len(lat_cpu[2:])} full decode steps, every one of the "
                                  f"{shape.layers} layers on the host cores (lia_host_layer_forward: AVX-512-BF16 linears + fp32 attention over the host "
                                  "KV cache, weights read raw from pinned memory); embeddings / final LN / lm_head stay on the GPU; the prefill is the GPU's"}
+            ids_check["host_policy1_vs_headline"] = first_divergence(out_ids, ids_cpu, T, logits_cpu)
+            del logits_cpu
         except Exception as e:          # the oracle sample below still gives a baseline
             product = {"error": f"{type(e).__name__}: {e}"}
         orc = cpu_oracle_sample(shape, B, T, host_threads)
@@ -421,6 +606,18 @@ def main(argv=None):
                                "sample": product.get("sample", orc["sample"]),
                                "product_host_path": product, "oracle_port": orc, "prefill_ms": orc["prefill_ms"],
                                "cpu": hostinfo.cpu_model(), "isa": hostinfo.isa_flags(), "cpus_usable": hostinfo.usable_cpus()}
+        try:
+            out["parity"] = parity_sample(sched, model, shape, B, T, host_threads)
+        except Exception as e:
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and ids_check:
+        out["ids_check"] = ids_check
+
+    # ---- N > 1: two short extra legs so that ONE line shows why the curve bends (same model, same ranks) -------------------
+    if dist is not None and (world > 1 or force_dp) and not is_llama and not a.no_dp_extra_legs and n_gpu < shape.layers:
+        extra = dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index)
+        if rank == 0:
+            out.update(extra)
     if rank == 0:
         out["host_memory_gib"] = {k: (None if v is None else round(v / 2**30, 2)) for k, v in hostinfo.cgroup_memory().items()}
 

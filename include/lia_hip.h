@@ -250,6 +250,9 @@ int lia_stream_wait(lia_streamer* s, int slot, void* compute_stream);    /* comp
 int lia_stream_release(lia_streamer* s, int slot, void* compute_stream); /* slot reusable after this    */
 /* bytes copied and copy-engine busy milliseconds since the last reset (hipEvent timing on the copy stream) */
 int lia_stream_stats(lia_streamer* s, double* bytes, double* busy_ms, int reset);
+/* the same totals without ever blocking: copies still in flight are left for a later call (used inside the token loop by the
+ * online cooperative-split controller, which must not wait for the prefetched layers) */
+int lia_stream_poll_stats(lia_streamer* s, double* bytes, double* busy_ms);
 void* lia_stream_copy_stream(lia_streamer* s);
 
 /* ---- host memory tiers ------------------------------------------------------------------------------

@@ -1176,6 +1176,18 @@ extern "C" int lia_stream_stats(lia_streamer* s, double* bytes, double* busy_ms,
   return LIA_OK;
 }
 
+// The non-blocking form: only copies whose end event has already completed are counted (a queued copy stays pending and is
+// counted by a later call).  For callers inside the token loop, which must never wait for the prefetched layers.
+extern "C" int lia_stream_poll_stats(lia_streamer* s, double* bytes, double* busy_ms) {
+  if (!s) return LIA_ERR_INVALID;
+  for (int i = 0; i < s->n_slots; ++i)
+    if (s->timing_pending[i] && hipEventQuery(s->t1[i]) == hipSuccess) streamer_collect(s, i);
+  (void)hipGetLastError();   // hipErrorNotReady from the query is an answer, not an error
+  if (bytes) *bytes = s->bytes;
+  if (busy_ms) *busy_ms = s->busy_ms;
+  return LIA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pinned / registered host memory
 // ------------------------------------------------------------------------------------------------

@@ -49,7 +49,10 @@ def generate(model, input_ids, max_new_tokens=None, min_new_tokens=None, do_samp
            "gpu_percentage": lia["gpu_percentage"] or 0, "num_minibatch": lia["num_minibatch"] or 1,
            "enable_cxl": bool(lia["enable_cxl"])}
     if model_kwargs.get("cpu_layers"):           # build-defined extension (scheduler.forward): host-computed decode layers
-        lia["cpu_layers"] = int(model_kwargs.pop("cpu_layers"))
+        lia["cpu_layers"] = int(model_kwargs.pop("cpu_layers"))          # -1: chosen online (scheduler.CoopController)
+        if model_kwargs.get("cpu_layers_start") is not None:
+            lia["cpu_layers_start"] = int(model_kwargs.pop("cpu_layers_start"))
+    model_kwargs.pop("cpu_layers_start", None)
     # build-defined, for bench.py: step_hook(i) runs before greedy iteration i (barriers / profiler brackets around exactly the
     # timed steps); max_steps ends the loop early while the caches stay sized for max_new_tokens (a short warm-up call)
     hooks = {"step_hook": model_kwargs.pop("step_hook", None), "max_steps": model_kwargs.pop("max_steps", None)}
@@ -75,7 +78,12 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
     else:
         # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278; in HBM for every layer when both policies are 3
         on_dev = lia["prefill_policy"] == 3 and lia["decoding_policy"] == 3
-        host_layers = OffloadScheduler.cpu_layer_set(n_gpu, L, lia["cpu_layers"]) if (on_dev and lia.get("cpu_layers")) else ()
+        host_layers = ()
+        if on_dev and lia.get("cpu_layers", 0) > 0:
+            host_layers = OffloadScheduler.cpu_layer_set(n_gpu, L, lia["cpu_layers"])
+        elif on_dev and lia.get("cpu_layers", 0) < 0 and getattr(sched, "dp", None) is None and n_gpu < L - 1:
+            # online count: every CANDIDATE host layer keeps its cache on the host (the GPU serves it with policy 2 when it is not chosen)
+            host_layers = sched._coop_controller(n_gpu, L, B, T, max_new_tokens, lia["gpu_percentage"], 3, lia.get("cpu_layers_start")).superset()
         kv = KVState(model, n_gpu, B, T + max_new_tokens, all_on_device=on_dev, host_layers=host_layers)
     unfinished = torch.ones(B, dtype=torch.int64)
     all_unfinished = True

@@ -50,7 +50,9 @@ def build_parser():
                    help="measure this box (lia_amd.planner.calibrate, a few seconds) and let the planner choose --gpu-percentage, "
                         "the policies and --cpu-layers instead of the hand-picked values of llm/scripts/lia_*.sh")
     p.add_argument("--cpu-layers", default=0, type=int,
-                   help="with --decoding-policy 2: this many streamed layers take their decode step on the host cores (policy 1 per layer)")
+                   help="with --decoding-policy 2: this many streamed layers take their decode step on the host cores (policy 1 per layer); "
+                        "-1 = chosen online from the measured decode steps (scheduler.CoopController), seeded by the planner")
+    p.add_argument("--cpu-layers-start", default=None, type=int, help=argparse.SUPPRESS)
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--init", default="normal", choices=["normal", "uniform01"],
                    help="uniform01 = the reference's dummy-weight recipe (utils/opt-weight-gen.py:61-62)")
@@ -93,10 +95,12 @@ def auto_plan(args, out=print):
     args.gpu_percentage, args.prefill_policy, args.decoding_policy = pl.gpu_percentage, pl.prefill_policy, pl.decoding_policy
     args.num_minibatch, args.pin_weight, args.stream_format = pl.num_minibatch, True, fmt
     if pl.n_gpu_layers < shape.layers and pl.decoding_policy == 2:
-        args.cpu_layers, _ = planner.plan_cpu_layers(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, pl.gpu_percentage, box)
+        # the plan SEEDS the count; the scheduler's online controller (cpu_layers = -1) moves it with the measured decode steps
+        args.cpu_layers_start, _ = planner.plan_cpu_layers(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, pl.gpu_percentage, box)
+        args.cpu_layers = -1 if args.cpu_layers_start > 0 else 0
     out(f"auto-plan: calibrated {box.calibrated}")
     out(f"auto-plan: gpu%={pl.gpu_percentage} ({pl.n_gpu_layers} resident layers) prefill policy {pl.prefill_policy} decode policy "
-        f"{pl.decoding_policy} cpu-layers {args.cpu_layers} wire {fmt}; predicted prefill {pl.prefill_ms:.0f} ms, "
+        f"{pl.decoding_policy} cpu-layers {'online from ' + str(args.cpu_layers_start) if args.cpu_layers < 0 else args.cpu_layers} wire {fmt}; predicted prefill {pl.prefill_ms:.0f} ms, "
         f"{pl.decode_tokens_per_s:.1f} tokens/s ({pl.note})")
     return pl
 
@@ -218,6 +222,8 @@ def main(argv=None):
                            gpu_percentage=args.gpu_percentage, num_minibatch=args.num_minibatch, enable_cxl=args.enable_cxl)
     if args.cpu_layers:
         generate_kwargs["cpu_layers"] = args.cpu_layers
+        if args.cpu_layers < 0 and args.cpu_layers_start is not None:
+            generate_kwargs["cpu_layers_start"] = args.cpu_layers_start
     input_ids = synthetic_prompt(model.shape.vocab, int(args.input_tokens), args.batch_size)
     if args.profile:
         profile_once(model, input_ids, generate_kwargs)

@@ -23,6 +23,7 @@ run the phase's policy: prefill 0 (minibatched, K/V delivered to the host cache)
 and is not scheduled here.
 """
 import ctypes
+import os
 
 import torch
 
@@ -179,6 +180,22 @@ class WeightPipeline:
         N.check(self.lib.lia_stream_release(self.handle, slot, ctypes.c_void_p(self.ctx.stream)), "lia_stream_release")
         self.free_slots.append(slot)
 
+    def forget(self, layer_idx):
+        """Give up a queued copy of layer_idx (it will not be used: the layer's decode step moved to the host cores).  The slot is
+        free again at once; lia_stream_begin orders its next copy behind the abandoned one."""
+        for j, (li, slot) in enumerate(self.inflight):
+            if li == layer_idx:
+                self.inflight.pop(j)
+                self.free_slots.append(slot)
+                return True
+        return False
+
+    def poll_stats(self):
+        """(bytes, busy ms) of the copies that have COMPLETED so far -- never blocks (stats() waits for the queued copies)"""
+        b, ms = ctypes.c_double(), ctypes.c_double()
+        N.check(self.lib.lia_stream_poll_stats(self.handle, ctypes.byref(b), ctypes.byref(ms)))
+        return b.value, ms.value
+
     def drain(self):
         """Forget every queued copy and wait for the copy engine: called before the model re-tiers its layers."""
         for _, slot in self.inflight:
@@ -283,6 +300,79 @@ class KVState:
             pass
 
 
+class CoopController:
+    """Online choice of the number of host-computed decode layers (`cpu_layers=-1`, build-defined cooperative split).
+
+    r02 picked the count once from a 4-second calibration (planner.plan_cpu_layers) and landed 129 ... 177 tok/s depending on
+    which socket the GPU hangs off.  Here the count follows the MEASURED decode steps: the host set of size c is the first c
+    layers of a fixed nested order (`order`: farthest-point spread over the streamed layers, so every prefix is evenly
+    spread and raw host copies are kept for the first c_max only); a step is max(link time of the streamed layers, host +
+    GPU time), so the controller hill-climbs on the step time, exploring first in the direction the copy engine's idle share
+    points to (link >= 97 % busy: one more host layer shortens the link time; less: the host is the bottleneck, one fewer).
+    One settle step after every change (queued copies still reflect the old set), `measure` steps per setting."""
+
+    def __init__(self, order, start, c_max, measure=2, expire=40):
+        self.order, self.c_max = list(order), min(int(c_max), len(order))
+        self.c = max(0, min(int(start), self.c_max))
+        self.measure, self.expire = measure, expire
+        self.rec = {}                 # c -> [mean step ms, samples, step index of the last sample]
+        self.acc, self.settle, self.step, self.moves = [], 1, 0, 0
+        self.trace = []               # (step, c, ms, link busy share)
+
+    def host_set(self, c=None):
+        return frozenset(self.order[:self.c if c is None else c])
+
+    def superset(self):
+        return frozenset(self.order[:self.c_max])
+
+    def observe(self, step_ms, busy_share):
+        """one finished decode step at the current c -> the c of the next step"""
+        self.step += 1
+        self.trace.append((self.step, self.c, round(step_ms, 2), round(busy_share, 3)))
+        if self.settle > 0:
+            self.settle -= 1
+            return self.c
+        self.acc.append((step_ms, busy_share))
+        if len(self.acc) < self.measure:
+            return self.c
+        ms = sum(a for a, _ in self.acc) / len(self.acc)
+        busy = sum(b for _, b in self.acc) / len(self.acc)
+        self.acc = []
+        self.rec[self.c] = [ms, self.measure, self.step]
+        for k in [k for k, v in self.rec.items() if self.step - v[2] > self.expire and k != self.c]:
+            del self.rec[k]           # old measurements age out: the box may have changed (another tenant, clocks)
+        # far from the optimum (the previous move gained > 2 %) the stride is 2 layers, else 1
+        prev = getattr(self, "_prev", None)
+        stride = 2 if (prev is not None and prev[0] in self.rec and ms < 0.98 * self.rec[prev[0]][0]) else 1
+        want = None
+        if stride == 2:
+            d = 1 if self.c > prev[0] else -1
+            cand = self.c + 2 * d
+            if 0 <= cand <= self.c_max and cand not in self.rec and (self.c + d) not in self.rec:
+                want = cand
+        up, down = self.c + 1, self.c - 1
+        first, second = (up, down) if busy >= 0.97 else (down, up)
+        if want is None:
+            for cand in (first, second):
+                if 0 <= cand <= self.c_max and cand not in self.rec:
+                    # explore the side the link points to; the other side only when this setting is not already the better one
+                    if cand == first or (first in self.rec and self.rec[first][0] >= ms):
+                        want = cand
+                        break
+        if want is None:
+            near = [k for k in self.rec if abs(k - self.c) <= 2]
+            best = min(near, key=lambda k: self.rec[k][0])
+            want = best if self.rec[best][0] < 0.995 * ms else self.c        # hysteresis: move only for > 0.5 %
+        self._prev = (self.c, ms)
+        if want != self.c:
+            self.c, self.settle, self.moves = want, 1, self.moves + 1
+        return self.c
+
+    def report(self):
+        return {"host_layers": self.c, "max_host_layers": self.c_max, "moves": self.moves, "steps_observed": self.step,
+                "ms_by_count": {str(k): round(v[0], 2) for k, v in sorted(self.rec.items())}, "trace_tail": self.trace[-12:]}
+
+
 class OffloadScheduler:
     """forward(input_ids, kv_state, **lia flags) -> (logits [B,vocab], next_ids [B]) on the device."""
 
@@ -308,6 +398,8 @@ class OffloadScheduler:
         # holding caches are shared by all generations of this scheduler, so a new prefill may only write them once ALL of these
         # have landed (a generation that ended at its prefill, a second live KVState, a KVState reused with len reset)
         self._outstanding = {}
+        self._coop = None           # CoopController of the cooperative split (cpu_layers=-1), kept across generations
+        self._coop_key = None
         self.kv_delivery = {"bytes": 0, "issue_to_landed_ms": None, "host_wait_ms": 0.0}   # of the last deferred delivery
 
     # -- resources -----------------------------------------------------------------------------------
@@ -394,10 +486,13 @@ class OffloadScheduler:
 
     # -- one forward -----------------------------------------------------------------------------------
     def forward(self, input_ids, kv_state, prefill_policy=1, decoding_policy=1, no_overlap=False, pin_weight=False,
-                gpu_percentage=0, num_minibatch=1, enable_cxl=False, max_new_tokens=None, suppress_token=-1, cpu_layers=0):
+                gpu_percentage=0, num_minibatch=1, enable_cxl=False, max_new_tokens=None, suppress_token=-1, cpu_layers=0,
+                cpu_layers_start=None):
         """cpu_layers (build-defined): with decoding policy 2, that many of the streamed layers run
         their decode step entirely on the host cores (policy 1, weights read in place) instead of crossing the link --
-        the cooperative split of the reference taken per layer.  Prefill is unaffected (policy 0 for every layer)."""
+        the cooperative split of the reference taken per layer.  Prefill is unaffected (policy 0 for every layer).
+        cpu_layers=-1: the count is chosen ONLINE (CoopController) from the measured decode steps, starting at cpu_layers_start
+        (default: planner.plan_cpu_layers for this shape and box defaults)."""
         m, sh = self.model, self.model.shape
         B, T = input_ids.shape
         L = sh.layers
@@ -418,7 +513,12 @@ class OffloadScheduler:
 
         # move_gpu_layer / pin_memory, idempotent.  The policy-1 host path reads the host copy directly, so the pack12
         # wire format is only used when neither phase runs on the CPU.
-        cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and decoding_policy in (2, 3) and self.dp is None) else frozenset()
+        coop = None
+        if cpu_layers and cpu_layers < 0 and decoding_policy in (2, 3) and self.dp is None and n_gpu < L - 1:
+            coop = self._coop_controller(n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, cpu_layers_start)
+            cpu_set = coop.superset()                                # layers that keep a raw host copy (and a host KV cache)
+        else:
+            cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and cpu_layers > 0 and decoding_policy in (2, 3) and self.dp is None) else frozenset()
         if cpu_set and decoding_policy == 3 and any(kv_state.kv[i].on_device for i in cpu_set):
             raise ValueError("cpu_layers with the KV cache in HBM: the host-computed layers need a host cache "
                              "(KVState(..., all_on_device=True, host_layers=OffloadScheduler.cpu_layer_set(...)))")
@@ -432,7 +532,12 @@ class OffloadScheduler:
                 self.pipe.drain()
             self.resident_ptrs.clear()
         m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=cpu_set, shard=shard)
-        host_now = cpu_set if not is_prefill else frozenset()     # layers this forward computes on the host
+        host_act = coop.host_set() if coop is not None else cpu_set   # the layers whose DECODE step runs on the host cores
+        host_now = host_act if not is_prefill else frozenset()    # layers this forward computes on the host
+        t_fwd0 = None
+        if coop is not None and not is_prefill:
+            import time
+            t_fwd0, busy0 = time.time(), (self.pipe.poll_stats()[1] if self.pipe else 0.0)
         rows = B * T if n_gpu > 0 else mini * T                    # resident layers take the whole batch
         if policy == 0 and n_gpu < L:
             rows = max(rows, mini * kv_state.smax)                 # policy-0 decode parks the cached prefix in a slab
@@ -463,7 +568,7 @@ class OffloadScheduler:
                 i += 1
                 if i >= L:
                     i, wrapped = first_streamed, True
-                if not ((wrapped or not is_prefill) and i in cpu_set):
+                if not ((wrapped or not is_prefill) and i in host_act):
                     return i, wrapped
 
         if n_gpu < L and overlap:
@@ -502,6 +607,8 @@ class OffloadScheduler:
                 # other streamed layers keep theirs in HBM (policy 3)
                 pol = 0 if (policy == 3 and idx in cpu_set) else policy
                 kvl = kv_state.kv[idx]
+                if pol == 0 and not is_prefill and policy == 3:
+                    pol = 2            # a candidate host layer that the GPU computes this step: its cache lives on the host
                 if hold is not None and pol == 0:
                     pol, kvl = 3, hold[idx - n_gpu][2]             # same arithmetic, rows land in the HBM holding cache
                 for i in range(B // mini):
@@ -537,7 +644,48 @@ class OffloadScheduler:
             if policy == 0 or (is_prefill and cpu_set):
                 ctx.kv_store_wait()                                # host cache complete before the next step reads it
         kv_state.len = pos0 + T
+        if t_fwd0 is not None:
+            import time
+            step_ms = 1e3 * (time.time() - t_fwd0)
+            busy = (self.pipe.poll_stats()[1] - busy0) / max(step_ms, 1e-6) if self.pipe else 0.0
+            before = coop.host_set()
+            coop.observe(step_ms, min(busy, 1.0))
+            for li in coop.host_set() - before:                   # newly host-computed: a queued copy of it will never be used
+                pipe.forget(li)
         return logits, nxt
+
+    def _coop_controller(self, n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, start):
+        key = (n_gpu, L, B, decoding_policy)
+        if self._coop is None or self._coop_key != key:
+            if start is None:
+                from . import hostinfo, planner
+                start, _ = planner.plan_cpu_layers(self.model.shape, B, T, max_new_tokens or 32, gpu_percentage,
+                                                   planner.Box(host_threads=self.host_threads or hostinfo.default_host_threads(1),
+                                                               wire_ratio={0: 1.0, 12: 0.751, 11: 0.696, 10: 0.675}[self.pack12]),
+                                                   kv_in_hbm=(decoding_policy == 3))
+            order = self.cpu_layer_order(n_gpu, L)
+            self._coop = CoopController(order, start, min(len(order), int(start) + int(os.environ.get("LIA_COOP_HEADROOM", "8"))))
+            self._coop_key = key
+        return self._coop
+
+    def coop_report(self):
+        return self._coop.report() if self._coop is not None else None
+
+    @staticmethod
+    def cpu_layer_order(n_gpu, L):
+        """A fixed NESTED order of the streamed layers (never the first one, which the wrap-around prefetch targets): layer k of
+        the order is the one farthest (circularly: the forward wraps into the next step) from the k before it, so every prefix
+        is evenly spread -- the host set can grow or shrink by one layer without moving the others."""
+        cand = list(range(n_gpu + 1, L))
+        if not cand:
+            return []
+        span = L - n_gpu
+        order = [cand[len(cand) // 2]]
+        while len(order) < len(cand):
+            def gap(x):
+                return min(min((x - y) % span, (y - x) % span) for y in order + [n_gpu])
+            order.append(max((c for c in cand if c not in order), key=lambda x: (gap(x), -x)))
+        return order
 
     @staticmethod
     def cpu_layer_set(n_gpu, L, count):

@@ -14,7 +14,21 @@ seeded inputs:
     64-row sample of x (rows of a linear are independent);
   * lm_head + argmax at the full vocabularies, reporting the smallest top-2 gap and the first disagreeing row (if any);
   * one Llama-3-8B-shaped layer (4096 / 32 / 8 / 14336): decode B = 128 at S = 1025, prefill B = 2 x T = 1024.
-Tolerances are those of tests/test_gpu_ops.py::test_layer_forward_matches_reference_golden.
+
+Two kinds of comparison, because a whole layer at H >= 7168 cannot be bit-compared the way a H = 512 golden can:
+
+  * PER OP (same inputs on both sides): the GEMMs with their epilogues, the decode attention and LayerNorm at the production
+    sizes are >= 99.9 % bit-identical to the oracle and never further than one bf16 quantum of the op's largest output -- the
+    kernels are the oracle's arithmetic up to the fp32 summation order (measured: 99.93-100 %);
+  * WHOLE LAYER: each op's rare one-ulp flips are AMPLIFIED by the next GEMM.  A fraction p of inputs off by one ulp u moves
+    every accumulator of the next linear by about w * u * sqrt(p * K); with the N(0, 0.02) weights of the random-init model and
+    K = 7168 ... 49152, sqrt(K) * w is 1.7 ... 4.4, so the flip rate after a GEMM is ~ 2 * sqrt(p): 0.04 % -> 4 % -> 45 %
+    across the layer's three GEMM stages (at the goldens' H = 512 the factor is 0.45 and 80 % stay identical).  The whole-layer
+    check is therefore an ERROR BOUND, not an identity rate: every element within three bf16 quanta of the layer's largest
+    output (the fc2 result is rounded three times at that magnitude: after the GEMM, after the bias, after the residual) plus
+    2 ulp of its own value, 99.5 % within one such quantum, and the early-stage K/V rows (one GEMM deep) >= 95 % identical.
+    Measured identity rates (printed by the tests): OPT-30B decode 58-62 %, prefill 40 %; OPT-175B decode 43-48 %; Llama-3-8B
+    decode 72 %, prefill 46 %.
 """
 import ctypes
 
@@ -25,7 +39,37 @@ import synth
 from test_gpu_ops import assert_close, to_bits
 
 pytestmark = pytest.mark.gpu
-TOL = dict(atol=0.07, rtol=0.016)
+
+
+def _quantum(v):
+    """the bf16 quantum (ulp) at magnitude v"""
+    return 2.0 ** (np.floor(np.log2(max(float(v), 2.0 ** -120))) - 7)
+
+
+def layer_close(got, ref, what, min_exact=0.3):
+    """whole-layer bound (module docstring): 3 quanta of the largest output + 2 ulp of the value; 99.5 % within one quantum"""
+    a, b = synth.bf16_bits_to_f32(got), synth.bf16_bits_to_f32(ref)
+    q = _quantum(np.abs(b).max())
+    err = np.abs(a - b)
+    frac = float((got == ref).mean())
+    print(f"\n{what}: {100 * frac:.2f} % bit-identical, max |err| {err.max():.4g} = {err.max() / q:.2f} quanta of max |ref| {np.abs(b).max():.3g}, "
+          f"{100 * (err <= q).mean():.3f} % within one quantum")
+    bad = err > 3 * q + 2.0 ** -6 * np.abs(b)
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} outside 3 quanta ({3 * q:.3g}) + 2 ulp, max err {err.max():.4g}"
+    assert (err <= q).mean() >= 0.995, f"{what}: only {100 * (err <= q).mean():.2f} % within one quantum ({q:.3g})"
+    assert frac >= min_exact, f"{what}: only {frac:.4f} bit-identical"
+
+
+def op_close(got, ref, what, min_exact=0.999):
+    """per-op bound: same inputs on both sides -> (almost) every output bit-identical, none further than one quantum of the
+    op's largest output"""
+    a, b = synth.bf16_bits_to_f32(got), synth.bf16_bits_to_f32(ref)
+    q = _quantum(np.abs(b).max())
+    err = np.abs(a - b)
+    frac = float((got == ref).mean())
+    print(f"\n{what}: {100 * frac:.3f} % bit-identical, max |err| {err.max():.4g} (quantum at max |ref| {np.abs(b).max():.3g}: {q:.3g})")
+    assert err.max() <= q, f"{what}: max err {err.max():.4g} > one quantum {q:.3g}"
+    assert frac >= min_exact, f"{what}: only {frac:.5f} bit-identical"
 OPT = {"opt-30b": (7168, 56, 28672, 64), "opt-175b": (12288, 96, 49152, 32)}       # H, heads, F, decode batch of the config
 
 
@@ -103,13 +147,61 @@ def test_opt_decode_layer_vs_oracle(opt_layer, oracle, policy):
     L["ctx"].layer_forward(L["desc"], policy, L["wptrs"], x, y, kv, B, 1, T)
     L["ctx"].synchronize()
     ref = orc.layer_forward(policy, L["W"], _bits(x), okc, ovc, T, heads)
-    got = to_bits(y)
-    print(f"\n{L['name']} decode policy {policy}: {100 * (got == ref).mean():.2f} % bit-identical, "
-          f"max |err| {np.abs(synth.bf16_bits_to_f32(got) - synth.bf16_bits_to_f32(ref)).max():.4g}")
-    assert_close(got, ref, min_exact=0.75, what=f"{L['name']} decode policy {policy}", **TOL)
+    layer_close(to_bits(y), ref, f"{L['name']} decode policy {policy}")
     # the new K/V row (position T) landed in the cache the policy owns
     assert_close(to_bits(hk)[T], okc[T], 0.03, 0.008, 0.95, "new K row")
     assert_close(to_bits(hv)[T], ovc[T], 0.03, 0.008, 0.95, "new V row")
+
+
+@pytest.mark.parametrize("which", ["qkv", "out", "fc1", "fc2"])
+@pytest.mark.parametrize("split", [0, 1], ids=["heuristic-splitk", "one-slice"])
+def test_opt_decode_gemms_per_op_vs_oracle(opt_layer, oracle, which, split):
+    """The four decode GEMMs of the layer at the config's batch (M = 64 / 32) on the layer's own weights, same inputs on both sides:
+    the production split-K slice counts (heuristic) and the single-slice form."""
+    import torch
+    from lia_amd import ops
+    orc = _checker(oracle)
+    L = opt_layer
+    H, F, W, M = L["H"], L["F"], L["W"], L["B"]
+    offs = {n: i for i, n in enumerate(ops.LAYER_TENSORS)}
+    po, _ = ops.pack_offsets(L["desc"])
+    dev = lambda n, shape: L["flat"][po[offs[n]] // 2: po[offs[n]] // 2 + int(np.prod(shape))].view(*shape)  # noqa: E731
+    res, relu = None, False
+    if which == "qkv":
+        w, b, K = dev("q_w", (3 * H, H)), dev("q_b", (3 * H,)), H
+        wo, bo = np.concatenate([W["q_w"], W["k_w"], W["v_w"]]), np.concatenate([W["q_b"], W["k_b"], W["v_b"]])
+    elif which == "out":
+        w, b, K, wo, bo, res = dev("out_w", (H, H)), dev("out_b", (H,)), H, W["out_w"], W["out_b"], _randn(torch, (M, H), 91)
+    elif which == "fc1":
+        w, b, K, wo, bo, relu = dev("fc1_w", (F, H)), dev("fc1_b", (F,)), H, W["fc1_w"], W["fc1_b"], True
+    else:
+        w, b, K, wo, bo, res = dev("fc2_w", (H, F)), dev("fc2_b", (H,)), F, W["fc2_w"], W["fc2_b"], _randn(torch, (M, H), 92)
+    x = _randn(torch, (M, K), 93, 0.3 if which == "out" else 1.0)
+    if which == "fc2":
+        x = torch.relu(1.5 * x)
+        torch.cuda.synchronize()
+    y = L["ctx"].linear(x, w, b, res, relu=relu, split_k=split)
+    L["ctx"].synchronize()
+    ref = orc.linear(_bits(x), wo, bo, None if res is None else _bits(res), relu=relu)
+    op_close(to_bits(y), ref, f"{L['name']} decode GEMM {which} M={M} split_k={split}")
+
+
+def test_opt_decode_attention_and_layernorm_per_op_vs_oracle(opt_layer, oracle):
+    import torch
+    orc = _checker(oracle)
+    L = opt_layer
+    H, heads, B, T = L["H"], L["heads"], L["B"], 256
+    d = H // heads
+    kc, vc = _randn(torch, (T + 2, B, heads, d), 21), _randn(torch, (T + 2, B, heads, d), 22)
+    q = _randn(torch, (B, 1, H), 94, 2.2)
+    out = L["ctx"].attention(q, kc, vc, T + 1, heads)
+    L["ctx"].synchronize()
+    # the attention output is a convex combination of V rows: its quantum is that of |v| ~ 1, values near 0 are common
+    op_close(to_bits(out), orc.attention(_bits(q), _bits(kc), _bits(vc), T + 1, heads, True), f"{L['name']} decode attention S={T + 1}",
+             min_exact=0.998)
+    x = _randn(torch, (B, H), 95, 3.0)
+    op_close(to_bits(L["ctx"].layernorm(x, L["flat"][:H].clone() + 1, L["flat"][H:2 * H].clone())),
+             orc.layernorm(_bits(x), _bits(L["flat"][:H] + 1), _bits(L["flat"][H:2 * H])), f"{L['name']} layernorm")
 
 
 @pytest.mark.parametrize("B", [1, 4])
@@ -133,9 +225,7 @@ def test_opt30b_prefill_layer_vs_oracle(opt_layer, oracle, B):
     L["ctx"].synchronize()
     okc, ovc = np.zeros((T, B, heads, d), np.uint16), np.zeros((T, B, heads, d), np.uint16)
     ref = orc.layer_forward(3, L["W"], _bits(x), okc, ovc, 0, heads)
-    got = to_bits(y)
-    print(f"\nopt-30b prefill B={B} T={T}: {100 * (got == ref).mean():.2f} % bit-identical")
-    assert_close(got, ref, min_exact=0.75, what=f"prefill B={B}", **TOL)
+    layer_close(to_bits(y), ref, f"opt-30b prefill B={B} T={T}")
     assert_close(to_bits(kc), okc, 0.03, 0.008, 0.95, "K rows")
     assert_close(to_bits(vc), ovc, 0.03, 0.008, 0.95, "V rows")
 
@@ -176,9 +266,7 @@ def test_opt30b_m16384_gemm_on_sampled_rows(opt_layer, oracle, which):
     rows.sort()
     ridx = torch.from_numpy(rows).cuda()
     ref = orc.linear(_bits(x[ridx]), wo, bo, None if res is None else _bits(res[ridx]), relu=relu)
-    got = to_bits(y[ridx])
-    print(f"\nM=16384 {which}: {100 * (got == ref).mean():.2f} % bit-identical on {len(rows)} sampled rows")
-    assert_close(got, ref, atol=0.035 if res is not None else 0.02, rtol=0.008, min_exact=0.97, what=f"tiled {which}")
+    op_close(to_bits(y[ridx]), ref, f"M=16384 {which} ({len(rows)} sampled rows)")
 
 
 def _report_argmax(name, logits_bits, nxt, ref_logits, ref_next):
@@ -302,9 +390,7 @@ def test_llama3_8b_decode_layer_vs_oracle(llama_layer, oracle):
     y = _llama_run(L, x, kv, B, 1, S0)
     ocos, osin = orc.rope_tables(2048, d, L["theta"])
     ref = orc.llama_layer_forward(L["W"], _bits(x), okc, ovc, ocos, osin, S0, heads, kvh)
-    got = to_bits(y)
-    print(f"\nllama-3-8b decode B={B} S={S0 + 1}: {100 * (got == ref).mean():.2f} % bit-identical")
-    assert_close(got, ref, 0.07, 0.016, 0.7, "llama-3-8b decode layer")
+    layer_close(to_bits(y), ref, f"llama-3-8b decode B={B} S={S0 + 1}")
     assert_close(to_bits(kc)[S0], okc[S0], 0.03, 0.008, 0.95, "new post-RoPE K row")
     assert_close(to_bits(vc)[S0], ovc[S0], 0.03, 0.008, 0.95, "new V row")
 
@@ -326,8 +412,6 @@ def test_llama3_8b_prefill_layer_vs_oracle(llama_layer, oracle):
     okc, ovc = np.zeros((T, B, kvh, d), np.uint16), np.zeros((T, B, kvh, d), np.uint16)
     ocos, osin = orc.rope_tables(2048, d, L["theta"])
     ref = orc.llama_layer_forward(L["W"], _bits(x), okc, ovc, ocos, osin, 0, heads, kvh)
-    got = to_bits(y)
-    print(f"\nllama-3-8b prefill B={B} T={T}: {100 * (got == ref).mean():.2f} % bit-identical")
-    assert_close(got, ref, 0.07, 0.016, 0.7, "llama-3-8b prefill layer")
+    layer_close(to_bits(y), ref, f"llama-3-8b prefill B={B} T={T}")
     assert_close(to_bits(kc), okc, 0.03, 0.008, 0.95, "post-RoPE K rows")
     assert_close(to_bits(vc), ovc, 0.03, 0.008, 0.95, "V rows")

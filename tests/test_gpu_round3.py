@@ -152,3 +152,40 @@ def test_run_generation_profile_flag(capsys):
     out = capsys.readouterr().out
     assert "Profile (one generate" in out and "GEMM skinny" in out and "host attention (policy 2)" in out and "weight stream H2D" in out
     assert "First token average latency" in out and res["decode_tokens_per_s"] > 0
+
+
+@pytest.mark.parametrize("fmt", ["raw", "pack10"])
+@pytest.mark.parametrize("pol", [(0, 2), (3, 3)], ids=["kv-on-host", "kv-in-hbm"])
+def test_online_cooperative_split_changes_host_set_mid_generation(fmt, pol, monkeypatch):
+    """cpu_layers = -1: the scheduler's CoopController moves the number of host-computed decode layers BETWEEN decode steps.  The
+    controller is scripted here to jump around (3 -> 1 -> 2 -> 0 -> 3 ...), which exercises every transition the real one can
+    make: layers leaving the host set are streamed again (on demand, then prefetched), layers entering it have their queued
+    copies forgotten; with the cache in HBM (3/3) a candidate layer the GPU computes runs policy 2 over its host cache.
+    Greedy ids must equal the HF golden run."""
+    import torch
+    from lia_amd import scheduler as S
+    from lia_amd.generation import generate
+    monkeypatch.setenv("LIA_STREAM_FORMAT", fmt)
+    script = [3, 1, 2, 0, 3, 2, 1, 3]
+    seen = []
+
+    def scripted(self, step_ms, busy_share):
+        assert step_ms > 0 and 0.0 <= busy_share <= 1.0
+        self.step += 1
+        seen.append(self.c)
+        self.c = min(script[self.step % len(script)], self.c_max)
+        return self.c
+
+    monkeypatch.setattr(S.CoopController, "observe", scripted)
+    z, m, ids, c = _load("generate_h256")
+    model = _model(m, c)
+    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], prefill_policy=pol[0], decoding_policy=pol[1],
+                   gpu_percentage=0, pin_weight=True, cpu_layers=-1, cpu_layers_start=2)
+    assert (out.numpy() == z["ids_bf16"]).all(), (out[0, c["T"]:].tolist(), z["ids_bf16"][0, c["T"]:].tolist())
+    sched = model._lia_scheduler
+    assert len(seen) == c["new"] - 1 and len(set(seen)) >= 3, seen           # every decode step observed, the count really moved
+    assert sched.coop_report()["max_host_layers"] == 3
+    sup = sched._coop.superset()
+    assert all(model.layers[i].raw_host_ptr() is not None for i in sup)      # every candidate keeps a raw copy for the host cores
+    sched.close()
+    model.close()

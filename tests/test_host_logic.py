@@ -172,3 +172,21 @@ def test_cap_torch_threads_only_lowers():
         assert hostinfo.cap_torch_threads(4) == 1                          # and it is never raised again
     finally:
         torch.set_num_threads(before)
+
+
+def test_coop_controller_converges_on_a_synthetic_box():
+    """the controller alone (no GPU work): step = max(link time of the streamed layers, host time) with 1 % noise"""
+    import random
+    from lia_amd.scheduler import CoopController, OffloadScheduler
+    order = OffloadScheduler.cpu_layer_order(4, 48)
+    assert len(order) == 43 and len(set(order)) == 43 and 4 not in order
+    for k in (4, 8, 14):                                  # every prefix is spread: no two chosen layers adjacent while there is room
+        assert min(b - a for a, b in zip(sorted(order[:k]), sorted(order[:k])[1:])) >= 2
+    for start in (10, 14, 18, 22):
+        random.seed(start)
+        ctl = CoopController(order, start, start + 8)
+        for _ in range(31):
+            link, host = (44 - ctl.c) * 14.7, 110 + ctl.c * 15.5
+            ms = max(link, host) * (1 + random.uniform(-0.01, 0.01))
+            ctl.observe(ms, min(1.0, link / ms))
+        assert ctl.c == 18, (start, ctl.report())            # argmin of max(link, host) for these rates
