@@ -23,6 +23,7 @@ N > 1: batch-sharded data parallel, one rank per GPU over RCCL; started as-is it
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -235,6 +236,9 @@ def first_divergence(ids_a, ids_b, T, logits_b=None):
         lg = logits_b[int(diff[0])][0].float()
         top = torch.topk(lg, 2).values
         out["top2_logit_gap_at_divergence"] = float(top[0] - top[1])
+        out["bf16_quantum_at_top_logit"] = 2.0 ** (math.floor(math.log2(max(abs(float(top[0])), 1e-30))) - 7)
+        out["note"] = ("the legs run different arithmetic on purpose (host-computed layers use the CPU policy's fused-bias linears and fp32 attention, "
+                       "decoder.py / Krnl.cpp); they may part only where the top two logits are within a few bf16 quanta")
     return out
 
 
@@ -508,6 +512,8 @@ def main(argv=None):
                              "host_wait_ms_in_first_decode_step": kvd.get("host_wait_ms"), "first_decode_step_ms": 1e3 * lat[1] if len(lat) > 1 else None}
                             if (streamed and kvd.get("bytes")) else {"deferred": False}),
             "prefill_ms_incl_kv_delivery": (prefill_ms + (kvd.get("issue_to_landed_ms") or 0.0)) if (streamed and kvd.get("bytes")) else prefill_ms,
+            "prefill_ms_incl_kv_delivery_note": "time until the HOST caches hold the prompt's K/V (what the reference's first-token latency contains); here the "
+                                                "delivery runs under decode step 1, which it does not slow down (kv_delivery.first_decode_step_ms vs decode_latency_ms.mean)",
             "protocol": {"entry_point": "lia_amd.generation.generate(token_latency=True)", "max_new_tokens": new,
                          "prefill_ms": prefill_ms, "decode_tokens_per_s": B * world / dec_mean_s,
                          "definition": "prefill = latency_list[0]; decode = batch / mean(latency_list[1:]) (run_generation.py:345-354); "
@@ -571,14 +577,15 @@ def main(argv=None):
                                             planner.Box(host_threads=host_threads,
                                                         wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]))
             coop_kwargs = dict(gen_kwargs, cpu_layers=-1, cpu_layers_start=c0)      # -1: the scheduler's online controller, seeded by the plan
-            ids_coop, lat_coop = generate(model, ids, max_steps=2 + a.coop_steps, **coop_kwargs)
+            ids_coop, lat_coop, logits_coop = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **coop_kwargs)
             tail = lat_coop[-max(1, a.coop_steps // 2):]                             # after the controller has settled
             out["value_cooperative"] = B / (sum(tail) / len(tail))
             out["cooperative_leg"] = {"planned_host_layers": c0, "controller": sched.coop_report(), "decode_steps": len(lat_coop) - 1,
                                       "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail), "leg_s": time.time() - t0,
                                       "note": "decode layers computed on the host cores never cross the link (build-defined, SURVEY 8 f-3); "
                                               "the count is adjusted online from the measured copy-engine idle time"}
-            ids_check["cooperative_vs_headline"] = first_divergence(out_ids, ids_coop, T)
+            ids_check["cooperative_vs_headline"] = first_divergence(out_ids, ids_coop, T, logits_coop)
+            del logits_coop
         except Exception as e:
             out["cooperative_leg"] = {"error": f"{type(e).__name__}: {e}"}
 
