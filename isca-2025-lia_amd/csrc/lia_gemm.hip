@@ -18,7 +18,6 @@
 #include <cstring>
 #include "lia_common.h"
 
-#include <type_traits>
 #define GL_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -460,6 +459,14 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
         int m = m_base + 16 * p + l15;
         if (m < M) *(f32x4*)(pp + (long)m * N + nn) = acc[t][p];
       }
+    } else if (ep.glu) {
+      // gate | up projection, one slice: park the finished bf16 tile in the (dead) ring, pair the columns below
+#pragma unroll
+      for (int p = 0; p < MT; ++p) {
+        const int ml = 16 * p + l15;
+        const f32x4 q = epilogue_quad(acc[t][p], min(m_base + ml, M - 1), nn, ep);
+        *(uint2*)(smem + ((long)ml * BN + (nn - n_tile)) * 2) = uint2{pack_bf16x2(q[0], q[1]), pack_bf16x2(q[2], q[3])};
+      }
     } else {
 #pragma unroll
       for (int p = 0; p < MT; ++p) {
@@ -467,6 +474,23 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
         if (m < M) store_quad(acc[t][p], m, nn, ep, om);
       }
     }
+  }
+  if (partial == nullptr && ep.glu) {
+    // LlamaMLP act_fn(gate) * up inside the GEMM launch (r03): the N columns are blocks of LIA_GU_BLOCK gate | LIA_GU_BLOCK up
+    // columns (lia_llama_desc.gu_block), a 128-column tile holds both factors of 64 outputs.  Same device function as the
+    // stand-alone kernel and the split-K combine (lia_silu_mul_pair): the three routes give the same bits for the same sums.
+    __syncthreads();
+    constexpr int OQ = BN / 8;                        // output quads per tile row (BN / 2 columns)
+    for (int q = tid; q < XR * OQ; q += 64 * WAVES) {
+      const int ml = q / OQ, c4 = (q % OQ) * 4;
+      const int ng = (c4 / LIA_GU_BLOCK) * (2 * LIA_GU_BLOCK) + (c4 % LIA_GU_BLOCK);
+      const int m = m_base + ml;
+      if (m >= M || n_tile + ng + LIA_GU_BLOCK >= N) continue;        // (a ragged last tile: N is a multiple of 64 here)
+      const uint2 g = *(const uint2*)(smem + ((long)ml * BN + ng) * 2);
+      const uint2 u = *(const uint2*)(smem + ((long)ml * BN + ng + LIA_GU_BLOCK) * 2);
+      *(uint2*)lia_out_ptr(om, m, n_tile / 2 + c4) = uint2{lia_silu_mul_pair(g.x, u.x), lia_silu_mul_pair(g.y, u.y)};
+    }
+    return;
   }
 #ifdef LIA_GEMM_STAMPS
   S2_STAMP(3);
@@ -510,165 +534,6 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
     store_quad(a, m, n, ep, om);
   }
 }
-
-// ---------------------------------------------------------------------------------------------
-// skinny regime, r03: the x operand never touches LDS ("skinny3", 32 < M <= 128).
-// In lia_gemm_skinny2_kernel every wave owns 16 RT weight rows and needs ALL x rows, so the x chunk is staged through LDS beside
-// the weights: at M = 128 a ring stage is half x, three stages fill 96 KB, and ONE workgroup per CU keeps 32 KB of weight bytes
-// in flight -- 8 MB on the chip, which at ~2 us of loaded HBM latency is ~4 TB/s (Llama-3-8B decode, B = 128: 2.1-4.4 TB/s per
-// GEMM, r02 verdict).  Here the waves are cut the OTHER way: wave w owns m-block (w % MB) -- 16 x rows -- and 1 / NS of the
-// workgroup's weight rows (NS = 8 / MB).  Its B operand is then 16 bytes per lane per k-step of ITS OWN rows, loaded straight
-// from global memory (L2: x is read by every workgroup) into a REGISTER ring, and LDS holds weights only: a stage of a 128-row
-// tile is 16 KB, four stages fit twice per CU, and 96 KB of weight bytes per CU are in flight.  Every wave reads the whole weight
-// chunk from LDS (the 8x read fan-out moved from x to W; LDS bandwidth is not the limit at either).
-// Same fragment convention, same MFMA, same k order per accumulator, same slab layout: for a given split the output is
-// BIT-IDENTICAL to lia_gemm_skinny2_kernel's (tests/test_gpu_ops.py::test_skinny3_*).
-//
-// The register ring is hand-allocated: v[96:127] (four slots of two 16-byte fragments), outside the compiler's budget
-// (amdgpu_num_vgpr(96)); the loads and the counted wait are inline asm that name those registers literally, and the wait asm
-// MOVES the landed slot into ordinary values.  Two forms the compiler could not be trusted with: x loads it can see make it add
-// its own vmcnt(0) once or twice per unrolled trip (the ring collapses), and asm loads into values it allocates let it copy a
-// slot register BEFORE the wait (phi / tied-operand copies: stale data; both seen in the ISA).
-// vmcnt: a chunk's group = WL LDS-DMA + 2 x loads per thread, retired in issue order by ONE counted wait per chunk.  The loop body
-// is branch-free: every iteration issues a group (chunk index clamped to the slice's last chunk; the S - 1 redundant groups hit
-// L2) and the padding iterations of the last trip multiply by a zeroed B operand.
-// ---------------------------------------------------------------------------------------------
-#define S3_STR2(x) #x
-#define S3_STR(x) S3_STR2(x)
-#define S3_CLOB(a) "v" S3_STR(a)
-// the 8 registers of ring slot u: v[96 + 8u .. 96 + 8u + 7]
-#define S3_SLOT_LOAD(A0, A1, A2, A3, A4, A5, A6, A7, ptr)                                                                          \
-  asm volatile("global_load_dwordx4 v[" S3_STR(A0) ":" S3_STR(A3) "], %0, off\n\t"                                                \
-               "global_load_dwordx4 v[" S3_STR(A4) ":" S3_STR(A7) "], %0, off offset:64"                                          \
-               :: "v"(ptr) : "memory", S3_CLOB(A0), S3_CLOB(A1), S3_CLOB(A2), S3_CLOB(A3), S3_CLOB(A4), S3_CLOB(A5), S3_CLOB(A6), S3_CLOB(A7))
-#define S3_SLOT_TAKE(A0, A1, A2, A3, A4, A5, A6, A7, CNT, x0, x1)                                                                  \
-  asm volatile("s_waitcnt vmcnt(%8)\n\t"                                                                                          \
-               "v_mov_b32 %0, v" S3_STR(A0) "\n\tv_mov_b32 %1, v" S3_STR(A1) "\n\tv_mov_b32 %2, v" S3_STR(A2) "\n\tv_mov_b32 %3, v" S3_STR(A3) "\n\t" \
-               "v_mov_b32 %4, v" S3_STR(A4) "\n\tv_mov_b32 %5, v" S3_STR(A5) "\n\tv_mov_b32 %6, v" S3_STR(A6) "\n\tv_mov_b32 %7, v" S3_STR(A7)        \
-               : "=v"(x0.x), "=v"(x0.y), "=v"(x0.z), "=v"(x0.w), "=v"(x1.x), "=v"(x1.y), "=v"(x1.z), "=v"(x1.w)                  \
-               : "n"(CNT)                                                                                                          \
-               : "memory", S3_CLOB(A0), S3_CLOB(A1), S3_CLOB(A2), S3_CLOB(A3), S3_CLOB(A4), S3_CLOB(A5), S3_CLOB(A6), S3_CLOB(A7))
-
-template <int SLOT> __device__ __forceinline__ void s3_slot_load(const bf16_t* ptr) {
-  if constexpr (SLOT == 0) S3_SLOT_LOAD(96, 97, 98, 99, 100, 101, 102, 103, ptr);
-  else if constexpr (SLOT == 1) S3_SLOT_LOAD(104, 105, 106, 107, 108, 109, 110, 111, ptr);
-  else if constexpr (SLOT == 2) S3_SLOT_LOAD(112, 113, 114, 115, 116, 117, 118, 119, ptr);
-  else S3_SLOT_LOAD(120, 121, 122, 123, 124, 125, 126, 127, ptr);
-}
-template <int SLOT, int CNT> __device__ __forceinline__ void s3_slot_take(u32x4& x0, u32x4& x1) {
-  if constexpr (SLOT == 0) S3_SLOT_TAKE(96, 97, 98, 99, 100, 101, 102, 103, CNT, x0, x1);
-  else if constexpr (SLOT == 1) S3_SLOT_TAKE(104, 105, 106, 107, 108, 109, 110, 111, CNT, x0, x1);
-  else if constexpr (SLOT == 2) S3_SLOT_TAKE(112, 113, 114, 115, 116, 117, 118, 119, CNT, x0, x1);
-  else S3_SLOT_TAKE(120, 121, 122, 123, 124, 125, 126, 127, CNT, x0, x1);
-}
-
-template <int MB, int BN, int S, int NT>
-__device__ __forceinline__ void lia_gemm_skinny3_body(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ W, long ldw, int M, int N,
-                                                      int K, int chunks_per_split, float* __restrict__ partial, const LiaEpilogue& ep,
-                                                      const LiaOutMap& om) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WAVES = 8, NS = WAVES / MB;         // NS waves share an m-block, each takes 1/NS of the tile's weight rows
-  constexpr int TW = BN / 16 / NS;                  // 16-row weight tiles per wave
-  constexpr int RR = 8 * WAVES, RB = RR * 128;      // rows / bytes one LDS-DMA round of the workgroup covers
-  constexpr int WL = BN / RR;                       // LDS-DMA instructions per thread per chunk
-  constexpr int NL = WL + 2;                        // vector-memory operations per thread per chunk (W rounds + 2 x loads)
-  constexpr int STAGE = BN * 128;
-  static_assert(MB * NS == WAVES && TW * NS * 16 == BN && WL * RR == BN && S >= 3 && S <= 4, "tile shape");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int p = wave % MB, h = wave / MB;           // my m-block, my share of the weight rows
-  const int n_tile = blockIdx.x * BN;
-  const int nchunks = K / S2_BK;
-  const int c_begin = blockIdx.y * chunks_per_split;
-  const int c_end = min(nchunks, c_begin + chunks_per_split);
-  const int n = c_end - c_begin;
-
-  const int srow = tid >> 3, sc = tid & 7;
-  const bf16_t* wsrc[WL];
-#pragma unroll
-  for (int r = 0; r < WL; ++r) {
-    const int row = srow + RR * r;
-    wsrc[r] = W + (long)min(n_tile + row, N - 1) * ldw + ((sc ^ tl_swz(row)) << 3);
-  }
-  // my B fragment: row 16 p + l15 (clamped; rows >= M are never stored), elements [32 ks + 8 lq, + 8) of the chunk
-  const bf16_t* xsrc = x + (long)min(16 * p + l15, M - 1) * ldx + 8 * lq;
-
-  auto issue_w = [&](int c, int stage) {
-    char* st = smem + stage * STAGE;
-    const long koff = (long)c * S2_BK;
-#pragma unroll
-    for (int r = 0; r < WL; ++r) {
-      if constexpr (NT) __builtin_amdgcn_global_load_lds(GL_AS1(wsrc[r] + koff), LDS_AS3(st + r * RB + wave * 1024), 16, 0, 2);
-      else __builtin_amdgcn_global_load_lds(GL_AS1(wsrc[r] + koff), LDS_AS3(st + r * RB + wave * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[TW];
-#pragma unroll
-  for (int t = 0; t < TW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (n > 0) {
-    const int c_last = c_end - 1;
-    // prologue: groups 0 .. S-2 (a group = the W rounds, then the two x loads, in that order)
-    { const int c = min(c_begin, c_last); issue_w(c, 0); s3_slot_load<0>(xsrc + (long)c * S2_BK); }
-    { const int c = min(c_begin + 1, c_last); issue_w(c, 1); s3_slot_load<1>(xsrc + (long)c * S2_BK); }
-    if constexpr (S > 3) { const int c = min(c_begin + 2, c_last); issue_w(c, 2); s3_slot_load<2>(xsrc + (long)c * S2_BK); }
-    const int trips = (n + S - 1) / S;
-    auto step = [&](int i, auto u_tag) {
-      constexpr int u = decltype(u_tag)::value;
-      u32x4 x0, x1;
-      s3_slot_take<u, (S - 2) * NL>(x0, x1);        // chunk i (issued S - 1 groups ago) has landed; S - 2 groups stay in flight
-      __builtin_amdgcn_s_barrier();
-      {
-        const int c = min(c_begin + i + S - 1, c_last);
-        issue_w(c, (u + S - 1) % S);
-        s3_slot_load<(u + S - 1) % S>(xsrc + (long)c * S2_BK);
-      }
-      if (i >= n) { x0 = u32x4{0u, 0u, 0u, 0u}; x1 = x0; }   // padding iteration of the last trip (selects, not a branch)
-      const char* wt = smem + u * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 b = __builtin_bit_cast(bf16x8, ks == 0 ? x0 : x1);
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-          const int row = (h * TW + t) * 16 + l15;
-          const bf16x8 a = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
-        }
-      }
-    };
-    for (int tr = 0; tr < trips; ++tr) {
-      const int i0 = tr * S;
-      step(i0, std::integral_constant<int, 0>{});
-      step(i0 + 1, std::integral_constant<int, 1>{});
-      step(i0 + 2, std::integral_constant<int, 2>{});
-      if constexpr (S > 3) step(i0 + 3, std::integral_constant<int, 3>{});
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail groups: nothing may land in this workgroup's LDS / registers later
-  }
-  __builtin_amdgcn_s_barrier();
-
-  const int m = 16 * p + l15;
-#pragma unroll
-  for (int t = 0; t < TW; ++t) {
-    const int nn = n_tile + (h * TW + t) * 16 + 4 * lq;
-    if (nn >= N || m >= M) continue;
-    if (partial != nullptr) *(f32x4*)(partial + ((long)blockIdx.y * M + m) * N + nn) = acc[t];
-    else store_quad(acc[t], m, nn, ep, om);
-  }
-}
-
-// concrete kernels: amdgpu_num_vgpr takes a literal, and the ring registers sit right above it
-#define S3_KERNEL(NAME, MBV, BNV, SV)                                                                                              \
-  __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void NAME(const bf16_t* __restrict__ x, long ldx,         \
-      const bf16_t* __restrict__ W, long ldw, int M, int N, int K, int chunks_per_split, float* __restrict__ partial,             \
-      LiaEpilogue ep, LiaOutMap om) {                                                                                              \
-    lia_gemm_skinny3_body<MBV, BNV, SV, 1>(x, ldx, W, ldw, M, N, K, chunks_per_split, partial, ep, om);                           \
-  }
-S3_KERNEL(lia_gemm_skinny3_m128_kernel, 8, 128, 4)
-S3_KERNEL(lia_gemm_skinny3_m64_kernel, 4, 128, 4)
-S3_KERNEL(lia_gemm_skinny3_m128_s3_kernel, 8, 128, 3)
-S3_KERNEL(lia_gemm_skinny3_m64_s3_kernel, 4, 128, 3)
 
 // ---------------------------------------------------------------------------------------------
 // tiled regime
@@ -1308,15 +1173,6 @@ static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw,
                      split > 1 ? partial : nullptr, tickets, ep, om);
 }
 
-typedef void (*lia_s3_kernel_t)(const bf16_t*, long, const bf16_t*, long, int, int, int, int, float*, LiaEpilogue, LiaOutMap);
-static void launch_skinny3(lia_s3_kernel_t kern, int stages, const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
-                           int split, int cps, float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
-  constexpr int BN = 128;
-  dim3 grid((N + BN - 1) / BN, split, 1);
-  const size_t lds = (size_t)stages * BN * 128;       // <= 64 KB: no opt-in attribute needed
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, x, ldx, W, ldw, M, N, K, cps, split > 1 ? partial : nullptr, ep, om);
-}
-
 // A/B switch (tests, tools): LIA_FUSE_COMBINE=0 or lia_gemm_set_fuse_combine(0) keeps every post op a kernel of its own
 static int g_fuse_combine = [] { const char* e = getenv("LIA_FUSE_COMBINE"); return (e && !strcmp(e, "0")) ? 0 : 1; }();
 extern "C" void lia_gemm_set_fuse_combine(int on) { g_fuse_combine = on; }
@@ -1356,11 +1212,6 @@ static bool launch_fused_combine(const float* ws, int split, int M, int N, const
   }
   return false;
 }
-
-// r03's decode GEMM for 32 < M <= 128 (lia_gemm_skinny3_*): LIA_SKINNY3=0 or lia_gemm_set_skinny3(0) keeps r02's kernels (A/B runs, the
-// bit-identity test)
-static int g_skinny3 = [] { const char* e = getenv("LIA_SKINNY3"); return e ? atoi(e) : 1; }();
-extern "C" void lia_gemm_set_skinny3(int on) { g_skinny3 = on; }
 
 // experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row,
 // 3 = force the two-block x cut at 64 < M <= 128, 4 = forbid it
@@ -1431,6 +1282,27 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
         while (split > 1 && nchunks / split < 8) --split;
       }
     }
+    // r03: a gate | up projection (LIA_POST_SILU_MUL over interleaved rows) whose 128-row tiles alone fill >= 3/4 of the chip runs as
+    // ONE slice of 128-row workgroups: no fp32 slabs (29 MB written and read back for Llama-3-8B at B = 128), no combine launch, and
+    // the kernel's epilogue pairs the columns itself -- 72 -> 64 us per launch against two 256-row slices + the fused combine
+    // (tools/gemm_bench, cold weights).  The same split is used when the fusion is switched off (LIA_FUSE_COMBINE=0: plain store,
+    // then the stand-alone SiLU kernel), so both routes add the same products in the same order.
+    LiaEpilogue ep_s = *ep;
+    LiaOutMap om_s = *om;
+    const bool glu_shape = post && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK && (N % (2 * LIA_GU_BLOCK)) == 0 &&
+                           M > 64 && M <= 128 && force_split <= 0 && (N + 127) / 128 >= 192 && g_skinny_variant == 0 && !ep->residual;
+    if (glu_shape) {
+      rt = 1; mcut = false; split = 1;
+      if (post_done && g_fuse_combine && post->out && (post->ldo & 3) == 0) {
+        ep_s.glu = 1;
+        memset(&om_s, 0, sizeof(om_s));
+        om_s.base[0] = post->out; om_s.ld[0] = post->ldo; om_s.seg_n = N / 2; om_s.T = 1;
+        *post_done = 1;
+        ++g_fused_combines[LIA_POST_SILU_MUL];
+      }
+      ep = &ep_s;
+      om = &om_s;
+    }
     if (split > nchunks) split = nchunks;
     if (split > 1 && (size_t)split * M * N * sizeof(float) > workspace_bytes) split = 1;
     int cps = (nchunks + split - 1) / split;
@@ -1444,32 +1316,6 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     // when split x slab bytes per tile is a few tens of KB.
     static const bool in_launch = [] { const char* e = getenv("LIA_GEMM_SPLITK"); return e && !strcmp(e, "inlaunch"); }();
     unsigned* tk = (split > 1 && tickets && in_launch && (long)((N + 127) / 128) * 16 <= LIA_GEMM_MAX_TICKETS) ? tickets : nullptr;
-    // r03: 32 < M <= 128 -> lia_gemm_skinny3_kernel (x straight into registers, weights alone on the LDS-DMA path).
-    // LIA_SKINNY3=0 keeps r02's kernels (A/B, bit-identity tests); LIA_S3_SPLIT / LIA_S3_STAGES override the choice.
-    static const int s3_split = [] { const char* e = getenv("LIA_S3_SPLIT"); return e ? atoi(e) : 0; }();
-    static const int s3_stages = [] { const char* e = getenv("LIA_S3_STAGES"); return e ? atoi(e) : 0; }();
-    if (g_skinny3 && M > 32 && M <= 128 && tk == nullptr && g_skinny_variant == 0) {
-      const int bn = 128;
-      const int tiles3 = (N + bn - 1) / bn;
-      const int slots3 = 512;                           // two 64 KB workgroups per CU
-      int sp = force_split > 0 ? force_split : (s3_split ? s3_split : (slots3 + tiles3 / 2) / tiles3);
-      sp = sp < 1 ? 1 : (sp > 8 ? 8 : sp);
-      while (sp > 1 && nchunks / sp < 8) --sp;
-      if (sp > 1 && (size_t)sp * M * N * sizeof(float) > workspace_bytes) sp = 1;
-      int cps3 = (nchunks + sp - 1) / sp;
-      sp = (nchunks + cps3 - 1) / cps3;
-      const int stg = s3_stages == 3 ? 3 : 4;
-      if (ev0) (void)hipEventRecord(ev0, st);
-      if (M <= 64) launch_skinny3(stg == 3 ? lia_gemm_skinny3_m64_s3_kernel : lia_gemm_skinny3_m64_kernel, stg, x, ldx, W, ldw, M, N, K, sp, cps3, workspace, *ep, *om, st);
-      else launch_skinny3(stg == 3 ? lia_gemm_skinny3_m128_s3_kernel : lia_gemm_skinny3_m128_kernel, stg, x, ldx, W, ldw, M, N, K, sp, cps3, workspace, *ep, *om, st);
-      if (ev1) (void)hipEventRecord(ev1, st);
-      if (sp > 1) {
-        if (post && post_done && launch_fused_combine(workspace, sp, M, N, *ep, *om, *post, st)) { *post_done = 1; return 0; }
-        long nq = (long)M * (N / 4);
-        hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace, sp, M, N, *ep, *om);
-      }
-      return 0;
-    }
     if (ev0) (void)hipEventRecord(ev0, st);
     if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);

@@ -189,39 +189,3 @@ def test_online_cooperative_split_changes_host_set_mid_generation(fmt, pol, monk
     assert all(model.layers[i].raw_host_ptr() is not None for i in sup)      # every candidate keeps a raw copy for the host cores
     sched.close()
     model.close()
-
-
-@pytest.mark.parametrize("M", [33, 64, 100, 128])
-@pytest.mark.parametrize("N,K,split", [(6144, 4096, 4), (4096, 4096, 8), (4096, 14336, 8), (28672, 4096, 2), (7168, 7168, 3), (1040, 512, 1),
-                                       (1040, 640, 5)])
-def test_skinny3_is_bit_identical_to_skinny2(M, N, K, split):
-    """lia_gemm_skinny3_* (r03: the x operand in a hand-allocated register ring, weights alone in the LDS ring) against
-    lia_gemm_skinny2_kernel (r02) at the SAME split: same fragments, same MFMA, same k order per accumulator -> the same bits.
-    Shapes: the Llama-3-8B and OPT-30B decode GEMMs, ragged M, a ragged last weight tile (N = 1040), slices of 8 / 2 chunks with a
-    short last slice (640 / 64 = 10 chunks over 5 slices)."""
-    import ctypes
-    import torch
-    from lia_amd import _native as N_, ops
-    lib = N_.lib()
-    lib.lia_gemm_set_skinny3.argtypes = [ctypes.c_int]
-    lib.lia_gemm_set_skinny3.restype = None
-    ctx = ops.Context(0, 8 * 128 * max(N, 4096) * 4 + (1 << 20))
-    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
-    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
-    w = (0.05 * torch.randn((N, K), generator=g, device="cuda")).to(torch.bfloat16)
-    b = torch.randn((N,), generator=g, device="cuda").to(torch.bfloat16)
-    r = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
-    torch.cuda.synchronize()
-    try:
-        lib.lia_gemm_set_skinny3(1)
-        y3 = ctx.linear(x, w, b, r, split_k=split)
-        ctx.synchronize()
-        lib.lia_gemm_set_skinny3(0)
-        y2 = ctx.linear(x, w, b, r, split_k=split)
-        ctx.synchronize()
-    finally:
-        lib.lia_gemm_set_skinny3(1)
-    assert torch.equal(y3.view(torch.int16), y2.view(torch.int16)), f"{(y3 != y2).sum().item()} of {y3.numel()} outputs differ"
-    ref = (x.float() @ w.float().t())
-    assert float((y3.float() - (ref + b.float() + r.float())).abs().max()) < 0.5          # and it is a GEMM (coarse sanity bound)
-    ctx.close()
