@@ -65,6 +65,7 @@ def build_parser():
     ap.add_argument("--coop-steps", type=int, default=16, help="decode steps of the cooperative leg (the controller settles in the first half)")
     ap.add_argument("--no-dp-extra-legs", action="store_true", help="N > 1: skip the KV-in-HBM and all-gather legs")
     ap.add_argument("--dp-extra-steps", type=int, default=6)
+    ap.add_argument("--dp-extra-timeout", type=int, default=420, help="seconds the extra legs may take before the run ends with the headline line only")
     ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the policy-1 CPU baseline leg")
     ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
     ap.add_argument("--cxl-nodes", default=None, help="NUMA nodes of the CXL tier, e.g. 2,3 (default LIA_CXL_NODES or 2,3)")
@@ -508,12 +509,13 @@ def main(argv=None):
                                 "layers are parked in HBM and delivered to the host caches AFTER the first token (kv_delivery below; LIA_DEFER_KV=0 "
                                 "delivers beside the prefill as the reference's store_cache does, modeling_opt.py:334-345), so unlike the reference's "
                                 "number this one does not contain the D2H of the cache; prefill_ms_incl_kv_delivery does") if (streamed and kvd.get("bytes")) else None,
-            "kv_delivery": ({"deferred": True, "bytes": kvd.get("bytes"), "issue_to_landed_ms": kvd.get("issue_to_landed_ms"),
+            "kv_delivery": ({"deferred": True, "bytes": kvd.get("bytes"), "device_ms": kvd.get("device_ms"), "gbs": ((kvd.get("bytes") or 0) / kvd["device_ms"] / 1e6) if kvd.get("device_ms") else None,
                              "host_wait_ms_in_first_decode_step": kvd.get("host_wait_ms"), "first_decode_step_ms": 1e3 * lat[1] if len(lat) > 1 else None}
                             if (streamed and kvd.get("bytes")) else {"deferred": False}),
-            "prefill_ms_incl_kv_delivery": (prefill_ms + (kvd.get("issue_to_landed_ms") or 0.0)) if (streamed and kvd.get("bytes")) else prefill_ms,
-            "prefill_ms_incl_kv_delivery_note": "time until the HOST caches hold the prompt's K/V (what the reference's first-token latency contains); here the "
-                                                "delivery runs under decode step 1, which it does not slow down (kv_delivery.first_decode_step_ms vs decode_latency_ms.mean)",
+            "prefill_ms_incl_kv_delivery": (prefill_ms + (kvd.get("device_ms") or 0.0)) if (streamed and kvd.get("bytes")) else prefill_ms,
+            "prefill_ms_incl_kv_delivery_note": "prefill_ms + the device time of the deferred K/V delivery = when the HOST caches would hold the prompt's K/V had the "
+                                                "delivery run right behind the prefill (what the reference's first-token latency contains); here it runs under "
+                                                "decode step 1, which it does not slow down (kv_delivery.first_decode_step_ms vs decode_latency_ms.mean)",
             "protocol": {"entry_point": "lia_amd.generation.generate(token_latency=True)", "max_new_tokens": new,
                          "prefill_ms": prefill_ms, "decode_tokens_per_s": B * world / dec_mean_s,
                          "definition": "prefill = latency_list[0]; decode = batch / mean(latency_list[1:]) (run_generation.py:345-354); "
@@ -622,8 +624,25 @@ def main(argv=None):
 
     # ---- N > 1: two short extra legs so that ONE line shows why the curve bends (same model, same ranks) -------------------
     if dist is not None and (world > 1 or force_dp) and not is_llama and not a.no_dp_extra_legs and n_gpu < shape.layers:
-        extra = dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index)
+        # The headline of this run is already measured.  It is printed NOW, and again -- extended -- as the last line when the legs
+        # are done: should a leg hang in a collective (one rank failing where the others do not), a watchdog ends every rank with
+        # exit code 0 and the line above stays the last JSON line of the output instead of the whole run being lost.
+        import signal
         if rank == 0:
+            out["dp_extra_legs"] = "pending (this line is re-printed with value_kv_in_hbm / value_allgather when they finish)"
+            print(json.dumps(out), flush=True)
+
+        def _watchdog(signum, frame):
+            sys.stderr.write(f"bench.py: rank {rank}: the extra data-parallel legs exceeded {a.dp_extra_timeout} s; keeping the headline line\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+        signal.signal(signal.SIGALRM, _watchdog)
+        signal.alarm(a.dp_extra_timeout)
+        extra = dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index)
+        signal.alarm(0)
+        if rank == 0:
+            out.pop("dp_extra_legs", None)
             out.update(extra)
     if rank == 0:
         out["host_memory_gib"] = {k: (None if v is None else round(v / 2**30, 2)) for k, v in hostinfo.cgroup_memory().items()}

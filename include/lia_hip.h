@@ -136,6 +136,9 @@ int lia_ctx_kv_store_wait(lia_ctx* ctx); /* host-blocks until every policy-0 K/V
  * right before that layer's host attention.  row_elems = heads * head_dim. */
 int lia_kv_deliver(lia_ctx* ctx, const lia_kv* dev, lia_kv* host, int T, int row_elems, int* ticket);
 int lia_kv_deliver_wait(lia_ctx* ctx, int ticket); /* host-blocks until that delivery has landed; frees the ticket */
+/* device time (first copy's start -> last copy's end, on the delivery stream) of the deliveries issued since the last call; blocks
+ * until they have landed.  What the reference's first-token latency contains and this build's does not (bench.py kv_delivery). */
+int lia_kv_deliver_batch_ms(lia_ctx* ctx, double* ms);
 
 /* ---- individual sub-layer ops (same kernels the layer call uses; exposed for parity tests) ------ */
 /* F.layer_norm, decoder.py:107-119 */

@@ -86,6 +86,8 @@ struct lia_ctx {
   unsigned* gemm_tickets;    // 16384 zeroed split-K tile tickets (lia_gemm.hip: the in-launch combine re-arms them)
   std::vector<hipEvent_t>* deliver_events;   // lia_kv_deliver tickets (events on the d2h stream), recycled round-robin
   std::vector<char>* deliver_pending;
+  hipEvent_t deliver_t0, deliver_t1;         // timing events on the d2h stream around one batch of deliveries (lia_kv_deliver_batch_ms)
+  bool deliver_batch_open;
   // cross-layer chaining (lia_ctx_chain_next_norm): the combine of a layer call's last GEMM also normalises the output row with
   // the NEXT layer's first-norm weights into the workspace's norm buffer; the next call finds it there and skips its first norm
   const bf16_t *chain_g, *chain_b;
@@ -158,6 +160,7 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
   if (c->ws) (void)hipFree(c->ws);
   if (c->gemm_tickets) (void)hipFree(c->gemm_tickets);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
+  if (c->deliver_t0) { (void)hipEventDestroy(c->deliver_t0); (void)hipEventDestroy(c->deliver_t1); }
   if (c->deliver_events) {
     for (hipEvent_t e : *c->deliver_events) (void)hipEventDestroy(e);
     delete c->deliver_events;
@@ -281,14 +284,31 @@ extern "C" int lia_kv_deliver(lia_ctx* c, const lia_kv* dev, lia_kv* host, int T
   // behind the compute stream's work so far (the layer that filled the holding cache), on the K/V delivery stream
   HIP_TRY(hipEventRecord((*c->deliver_events)[id], c->compute));
   HIP_TRY(hipStreamWaitEvent(c->d2h, (*c->deliver_events)[id], 0));
+  if (!c->deliver_t0) { HIP_TRY(hipEventCreate(&c->deliver_t0)); HIP_TRY(hipEventCreate(&c->deliver_t1)); }
+  if (!c->deliver_batch_open) { HIP_TRY(hipEventRecord(c->deliver_t0, c->d2h)); c->deliver_batch_open = true; }
   // the strided 2-D form even though the rows are contiguous: the runtime serves it with a blit kernel, a linear copy would
   // queue on the SDMA engine behind the next step's weight copies (see the policy-0 delivery in lia_layer_forward)
   const size_t width = (size_t)dev->batch * row_elems * 2;
   HIP_TRY(hipMemcpy2DAsync(host->k, width, dev->k, width, width, T, hipMemcpyDeviceToHost, c->d2h));
   HIP_TRY(hipMemcpy2DAsync(host->v, width, dev->v, width, width, T, hipMemcpyDeviceToHost, c->d2h));
   HIP_TRY(hipEventRecord((*c->deliver_events)[id], c->d2h));
+  HIP_TRY(hipEventRecord(c->deliver_t1, c->d2h));
   (*c->deliver_pending)[id] = 1;
   *ticket = id;
+  return LIA_OK;
+}
+
+// Device time of the deliveries issued since the last call of this function (first copy's start to last copy's end on the K/V
+// delivery stream); blocks until the last one has landed.  For the benchmark's prefill accounting.
+extern "C" int lia_kv_deliver_batch_ms(lia_ctx* c, double* ms) {
+  if (!c || !ms) return LIA_ERR_INVALID;
+  *ms = 0.0;
+  if (!c->deliver_batch_open) return LIA_OK;
+  HIP_TRY(hipEventSynchronize(c->deliver_t1));
+  float f = 0.f;
+  HIP_TRY(hipEventElapsedTime(&f, c->deliver_t0, c->deliver_t1));
+  *ms = f;
+  c->deliver_batch_open = false;
   return LIA_OK;
 }
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lia_ctx_kv_store_wait": (c_int, [c_void_p]),
     "lia_kv_deliver": (c_int, [c_void_p, ctypes.POINTER(KV), ctypes.POINTER(KV), c_int, c_int, ctypes.POINTER(c_int)]),
     "lia_kv_deliver_wait": (c_int, [c_void_p, c_int]),
+    "lia_kv_deliver_batch_ms": (c_int, [c_void_p, ctypes.POINTER(c_double)]),
     "lia_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
     "lia_linear": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int,
                            c_int, c_int, c_int, c_int, c_void_p]),

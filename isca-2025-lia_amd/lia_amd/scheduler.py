@@ -399,7 +399,7 @@ class OffloadScheduler:
         self._outstanding = {}
         self._coop = None           # CoopController of the cooperative split (cpu_layers=-1), kept across generations
         self._coop_key = None
-        self.kv_delivery = {"bytes": 0, "issue_to_landed_ms": None, "host_wait_ms": 0.0}   # of the last deferred delivery
+        self.kv_delivery = {"bytes": 0, "device_ms": None, "host_wait_ms": 0.0}   # of the last deferred delivery
 
     # -- resources -----------------------------------------------------------------------------------
     def _ensure(self, rows, B, T, n_gpu):
@@ -466,7 +466,10 @@ class OffloadScheduler:
                 self._outstanding.pop(t, None)
         self.kv_delivery["host_wait_ms"] += 1e3 * (time.time() - t0)
         if not pend and self.kv_delivery.get("_issued_at") is not None:
-            self.kv_delivery["issue_to_landed_ms"] = 1e3 * (time.time() - self.kv_delivery.pop("_issued_at"))
+            self.kv_delivery.pop("_issued_at")
+            ms = ctypes.c_double()
+            N.check(self.ctx.lib.lia_kv_deliver_batch_ms(self.ctx.handle, ctypes.byref(ms)), "lia_kv_deliver_batch_ms")
+            self.kv_delivery["device_ms"] = ms.value          # first copy's start -> last copy's end on the delivery stream
 
     def _await_all_deliveries(self):
         """every outstanding delivery of this scheduler, whichever generation issued it: their copies read the shared holding
@@ -476,6 +479,10 @@ class OffloadScheduler:
             owner = ref()
             if owner is not None and getattr(owner, "pending", None):
                 owner.pending.pop(idx, None)
+        if self._outstanding:
+            ms = ctypes.c_double()
+            N.check(self.ctx.lib.lia_kv_deliver_batch_ms(self.ctx.handle, ctypes.byref(ms)), "lia_kv_deliver_batch_ms")   # close the timing batch
+            self.kv_delivery.pop("_issued_at", None)
         self._outstanding.clear()
 
     def _resident(self, idx):
@@ -627,7 +634,7 @@ class OffloadScheduler:
             import weakref
             self._await_kv(kv_state)              # (a KVState reused for a second prefill: never drop a ticket unawaited)
             kv_state.pending = {}
-            self.kv_delivery = {"bytes": 0, "issue_to_landed_ms": None, "host_wait_ms": 0.0, "_issued_at": time.time()}
+            self.kv_delivery = {"bytes": 0, "device_ms": None, "host_wait_ms": 0.0, "_issued_at": time.time()}
             for idx in range(n_gpu, L):
                 if kv_state.kv[idx].on_device:
                     continue
