@@ -124,6 +124,13 @@ typedef struct {
  * the host attends. */
 int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
                       const lia_bf16* x, lia_bf16* y, lia_kv* kv, int B, int T, int pos0, int b0, void* stream);
+/* The LAST decoder layer of a prefill (build-defined; the reference computes every position of every layer, decoder.py:172-335):
+ * only hidden[:, -1, :] of the last layer feeds the final LayerNorm and lm_head (models.py:424-431), but its K/V rows of EVERY
+ * position feed the decode steps.  So: LN1 and the q | k | v projection on all B x T rows (cache written exactly as by
+ * lia_layer_forward), then attention -- one query per row over the T keys --, out-proj, LN2, fc1 and fc2 on the last position
+ * of each row only.  y_last: device [B, 1, H].  policy 0 or 3, T > 1, pos0 == 0.  Saves 9/12 of the layer's GEMM flops. */
+int lia_layer_forward_last(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
+                           const lia_bf16* x, lia_bf16* y_last, lia_kv* kv, int B, int T, int pos0, int b0, void* stream);
 /* dst / src: device memory or pinned (mapped) host memory; bytes % 16 == 0; asynchronous on `stream`.  Kernel copy used for
  * the small activation hops of the cooperative policies (modeling_opt.py:320-355 load_activation / store_hidden). */
 int lia_blit(void* dst, const void* src, size_t bytes, void* stream);

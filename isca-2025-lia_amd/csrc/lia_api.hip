@@ -547,8 +547,10 @@ static int ensure_host_stage(lia_ctx* c, size_t bytes) {
   return LIA_OK;
 }
 
-extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
-                                 const lia_bf16* x, lia_bf16* y, lia_kv* kv, int B, int T, int pos0, int b0, void* stream) {
+// tail = 1 (lia_layer_forward_last): LN1 and the q | k | v projection run on all B x T rows (the cache needs every K/V row), everything
+// behind them -- attention, out-proj, LN2, fc1, fc2 -- only on the LAST position of each row; y is then [B, 1, H].
+static int layer_forward_impl(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16], const lia_bf16* x,
+                              lia_bf16* y, lia_kv* kv, int B, int T, int pos0, int b0, void* stream, int tail) {
   if (!ctx) return LIA_ERR_INVALID;
   int rc = check_desc(d);
   if (rc) return rc;
@@ -564,6 +566,7 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
     return LIA_ERR_INVALID;
   }
   if (T > 1 && pos0 != 0) { lia_set_error("lia_layer_forward: multi-token call must be a prefill (pos0 == 0)"); return LIA_ERR_INVALID; }
+  if (tail && (policy == 2 || T < 2)) { lia_set_error("lia_layer_forward_last: a GPU-attention prefill (policy 0 / 3, T > 1) only"); return LIA_ERR_INVALID; }
   if ((policy == 3) != (kv->on_device != 0)) {
     lia_set_error("lia_layer_forward: policy %d needs a %s cache", policy, policy == 3 ? "device" : "host");
     return LIA_ERR_INVALID;
@@ -596,6 +599,9 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
                          (W[7] == W[5] + H);
   const float eps = d->ln_eps;
   const size_t S = (size_t)pos0 + T;
+  // rows behind the projection: all of them, or the last position of each batch row (row b*T + T-1: stride T*H)
+  const long Mt = tail ? (long)B : M;
+  const long tail_off = tail ? (long)(T - 1) * H : 0, tail_ld = tail ? (long)T * H : (long)H;
   // chaining state: a hint for THIS call's last GEMM, and whether the previous call already left LN1(x) in `ln`
   const bf16_t *chain_g = ctx->chain_armed ? ctx->chain_g : nullptr, *chain_b = ctx->chain_armed ? ctx->chain_b : nullptr;
   ctx->chain_armed = false;
@@ -665,8 +671,9 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
     lia_blit_launch(ao, ha, one, st);
   } else {
     // GPU attention (attentions.py:443-536)
-    int arc = T == 1 ? lia_attn_decode_launch(qb, H, kdst, vdst, ao, H, B, (int)S, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st)
-                     : lia_attn_prefill_launch(qb, H, kdst, vdst, ao, H, B, T, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st);
+    // (tail: the last query of a causal block attends every key -- one decode-style query per row over the S rows just written)
+    int arc = (T == 1 || tail) ? lia_attn_decode_launch(qb + tail_off, tail_ld, kdst, vdst, ao, H, B, (int)S, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st)
+                               : lia_attn_prefill_launch(qb, H, kdst, vdst, ao, H, B, T, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st);
     if (arc) { lia_set_error("attention: unsupported head_dim %d / S %zu", hd, S); return LIA_ERR_INVALID; }
     if (policy == 0) {
       // deliver rows [pos0, pos0+T) of batch rows [b0, b0+B) to the host cache
@@ -688,19 +695,19 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
   // out-proj + bias, residual (decoder.py:225-229); LN2 (:268-276) rides in the split-K combine when there is one
   int ln2_done = 0;
   {
-    LiaEpilogue ep{W[9], x, H, 0};
+    LiaEpilogue ep{W[9], x + tail_off, tail_ld, 0};
     LiaOutMap om = plain_out(h1, H, H);
     LiaPost post{};
     post.kind = LIA_POST_LAYERNORM; post.g = W[10]; post.b = W[11]; post.eps = eps; post.out = ln; post.ldo = H;
-    rc = gemm_checked(ctx, ao, H, W[8], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st, &post, &ln2_done);
+    rc = gemm_checked(ctx, ao, H, W[8], (int)Mt, H, H, ep, om, gws, w.gemm_bytes, 0, st, &post, &ln2_done);
     if (rc) return rc;
   }
   // fc1 + relu (:282-285), fc2 + residual (:306-310)
-  if (!ln2_done) lia_layernorm_launch(h1, H, W[10], W[11], ln, H, M, H, eps, st);
+  if (!ln2_done) lia_layernorm_launch(h1, H, W[10], W[11], ln, H, Mt, H, eps, st);
   {
     LiaEpilogue ep{W[13], nullptr, 0, 1};
     LiaOutMap om = plain_out(f1, F, F);
-    rc = gemm_checked(ctx, ln, H, W[12], (int)M, F, H, ep, om, gws, w.gemm_bytes, 0, st);
+    rc = gemm_checked(ctx, ln, H, W[12], (int)Mt, F, H, ep, om, gws, w.gemm_bytes, 0, st);
     if (rc) return rc;
   }
   {
@@ -709,12 +716,22 @@ extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int poli
     LiaPost post{};
     int chained = 0;
     if (chain_g && chain_b) { post.kind = LIA_POST_LAYERNORM; post.g = chain_g; post.b = chain_b; post.eps = eps; post.out = ln; post.ldo = H; }
-    rc = gemm_checked(ctx, f1, F, W[14], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st, post.kind ? &post : nullptr, &chained);
+    rc = gemm_checked(ctx, f1, F, W[14], (int)Mt, H, F, ep, om, gws, w.gemm_bytes, 0, st, post.kind ? &post : nullptr, &chained);
     if (rc) return rc;
-    if (chained) { ctx->normed_src = y; ctx->normed_buf = ln; ctx->normed_rows = M; ctx->normed_h = H; }
+    if (chained) { ctx->normed_src = y; ctx->normed_buf = ln; ctx->normed_rows = Mt; ctx->normed_h = H; }
   }
   HIP_TRY(hipGetLastError());
   return LIA_OK;
+}
+
+extern "C" int lia_layer_forward(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
+                                 const lia_bf16* x, lia_bf16* y, lia_kv* kv, int B, int T, int pos0, int b0, void* stream) {
+  return layer_forward_impl(ctx, d, policy, weights, x, y, kv, B, T, pos0, b0, stream, 0);
+}
+
+extern "C" int lia_layer_forward_last(lia_ctx* ctx, const lia_layer_desc* d, int policy, const void* const weights[16],
+                                      const lia_bf16* x, lia_bf16* y_last, lia_kv* kv, int B, int T, int pos0, int b0, void* stream) {
+  return layer_forward_impl(ctx, d, policy, weights, x, y_last, kv, B, T, pos0, b0, stream, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -58,6 +58,8 @@ SIGNATURES = {
     "lia_layer_workspace_bytes": (c_size_t, [ctypes.POINTER(LayerDesc), c_int]),
     "lia_layer_forward": (c_int, [c_void_p, ctypes.POINTER(LayerDesc), c_int, ctypes.POINTER(c_void_p * 16), c_void_p,
                                   c_void_p, ctypes.POINTER(KV), c_int, c_int, c_int, c_int, c_void_p]),
+    "lia_layer_forward_last": (c_int, [c_void_p, ctypes.POINTER(LayerDesc), c_int, ctypes.POINTER(c_void_p * 16), c_void_p,
+                                       c_void_p, ctypes.POINTER(KV), c_int, c_int, c_int, c_int, c_void_p]),
     "lia_ctx_kv_store_wait": (c_int, [c_void_p]),
     "lia_kv_deliver": (c_int, [c_void_p, ctypes.POINTER(KV), ctypes.POINTER(KV), c_int, c_int, ctypes.POINTER(c_int)]),
     "lia_kv_deliver_wait": (c_int, [c_void_p, c_int]),

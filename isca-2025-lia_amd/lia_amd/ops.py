@@ -143,6 +143,13 @@ class Context:
                                            ctypes.byref(kv), B, T, pos0, b0, self._st(stream)), "lia_layer_forward")
 
 
+    def layer_forward_last(self, desc, policy, weight_ptrs, x, y_last, kv, B, T, pos0, b0=0, stream=None):
+        """lia_layer_forward_last: the last layer of a prefill -- K/V of every position, the rest on the last position only;
+        y_last: [B,1,H] device."""
+        N.check(self.lib.lia_layer_forward_last(self.handle, ctypes.byref(desc), policy, ctypes.byref(weight_ptrs), _ptr(x), _ptr(y_last),
+                                                ctypes.byref(kv), B, T, pos0, b0, self._st(stream)), "lia_layer_forward_last")
+
+
 def make_desc(hidden, heads, ffn, eps=1e-5):
     return N.LayerDesc(hidden, heads, ffn, eps)
 

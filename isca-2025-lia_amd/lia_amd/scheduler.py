@@ -392,6 +392,9 @@ class OffloadScheduler:
         # policy-0 prefill: keep the fresh K/V of the streamed layers in HBM until the prefill's last layer has run and deliver
         # them to the host caches then (lia_kv_deliver), instead of beside the prefill's weight stream.  LIA_DEFER_KV=0: deliver at once.
         self.defer_kv = os.environ.get("LIA_DEFER_KV", "1") != "0"
+        # the last layer of a prefill computes everything behind its q|k|v projection on the last position only (lia_layer_forward_last);
+        # LIA_PREFILL_TAIL=0: every position, as the reference does
+        self.prefill_tail = os.environ.get("LIA_PREFILL_TAIL", "1") != "0"
         self._kv_hold = None        # ((B, T, first streamed layer), [(k, v, KV struct) per streamed layer])
         # every delivery ticket not yet waited for, whichever KVState it belongs to: ticket -> (weakref(KVState), layer).  The
         # holding caches are shared by all generations of this scheduler, so a new prefill may only write them once ALL of these
@@ -579,12 +582,19 @@ class OffloadScheduler:
 
         if n_gpu < L and overlap:
             pipe.prefetch(first_streamed)                          # no-op if the previous step already wrapped to it
+        # the prefill's last layer: only hidden[:, -1, :] feeds lm_head (models.py:424-431), its K/V of every position feed decode
+        tail_last = self.prefill_tail and is_prefill and T > 1 and pos0 == 0 and (policy in (0, 3) or n_gpu == L) and (L - 1) not in host_now
+        xlast = None
         for idx in range(L):
             if idx < n_gpu:
                 # resident layer: whole batch, everything on the GPU incl. KV (policy 3; :1246-1260)
                 if not is_prefill and idx + 1 < n_gpu:
                     nw = self._resident(idx + 1)                   # decode: LN1 of the next resident layer rides in this layer's fc2 combine
                     ctx.chain_next_norm(nw[0], nw[1])
+                if tail_last and idx == L - 1:
+                    xlast = torch.empty((B, 1, sh.hidden), dtype=torch.bfloat16, device="cuda")
+                    ctx.layer_forward_last(m.desc, 3, self._resident(idx), x, xlast, kv_state.kv[idx], B, T, pos0, 0)
+                    continue
                 ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
                 x, y = y, x
                 continue
@@ -617,9 +627,14 @@ class OffloadScheduler:
                     pol = 2            # a candidate host layer that the GPU computes this step: its cache lives on the host
                 if hold is not None and pol == 0:
                     pol, kvl = 3, hold[idx - n_gpu][2]             # same arithmetic, rows land in the HBM holding cache
+                if tail_last and idx == L - 1:
+                    xlast = torch.empty((B, 1, sh.hidden), dtype=torch.bfloat16, device="cuda")
                 for i in range(B // mini):
                     sl = slice(i * mini, (i + 1) * mini)
-                    ctx.layer_forward(m.desc, pol, wptrs, x[sl], y[sl], kvl, mini, T, pos0, i * mini)
+                    if tail_last and idx == L - 1:
+                        ctx.layer_forward_last(m.desc, pol, wptrs, x[sl], xlast[sl], kvl, mini, T, pos0, i * mini)
+                    else:
+                        ctx.layer_forward(m.desc, pol, wptrs, x[sl], y[sl], kvl, mini, T, pos0, i * mini)
             else:
                 ctx.layer_forward(m.desc, 2, wptrs, x, y, kv_state.kv[idx], B, T, pos0, 0)   # :1493-1543
             pipe.release(idx)
@@ -627,7 +642,7 @@ class OffloadScheduler:
             if not overlap:
                 ctx.synchronize()
 
-        logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
+        logits, nxt = ctx.lm_head(x if xlast is None else xlast, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
         if hold is not None:
             # the deferred deliveries, in the order the first decode step will need them; tickets are awaited per layer there
             import time

@@ -189,3 +189,69 @@ def test_online_cooperative_split_changes_host_set_mid_generation(fmt, pol, monk
     assert all(model.layers[i].raw_host_ptr() is not None for i in sup)      # every candidate keeps a raw copy for the host cores
     sched.close()
     model.close()
+
+
+@pytest.mark.parametrize("policy", [3, 0])
+@pytest.mark.parametrize("H,heads,F,B,T", [(256, 4, 1024, 4, 16), (512, 4, 2048, 3, 24), (7168, 56, 28672, 4, 256)])
+def test_layer_forward_last_equals_last_position_of_full_prefill(policy, H, heads, F, B, T, oracle):
+    """lia_layer_forward_last (the prefill's LAST layer: K/V of every position, attention / out-proj / MLP on the last position
+    only) against lia_layer_forward on the same inputs: the caches must be bit-identical (same q|k|v GEMM), the last position's
+    hidden state agrees to rounding (decode-style attention and M = B GEMMs instead of the causal block and M = B*T ones), and
+    both agree with the oracle's full layer."""
+    import torch
+    from lia_amd import _native as N, ops
+    from test_gpu_ops import _layer_setup, assert_close, to_bits, to_dev
+    W = synth.make_layer(21, H, F, 0.02)
+    desc, wdev, wptrs = _layer_setup(torch, ops, W, H, heads, F)
+    d = H // heads
+    ctx = ops.Context(0, ops.workspace_bytes(desc, B * T))
+    xb = synth.make_hidden(22, B, T, H)
+    x = to_dev(torch, xb)
+
+    def caches():
+        if policy == 3:
+            k = torch.zeros((T, B, heads, d), dtype=torch.bfloat16, device="cuda")
+            v = torch.zeros_like(k)
+        else:
+            k = torch.zeros((T, B, heads, d), dtype=torch.bfloat16).pin_memory()
+            v = torch.zeros((T, B, heads, d), dtype=torch.bfloat16).pin_memory()
+        return k, v, N.KV(k.data_ptr(), v.data_ptr(), T, B, int(policy == 3))
+
+    k1, v1, kv1 = caches()
+    y_full = torch.empty_like(x)
+    ctx.layer_forward(desc, policy, wptrs, x, y_full, kv1, B, T, 0)
+    ctx.synchronize(); ctx.kv_store_wait()
+    k2, v2, kv2 = caches()
+    y_last = torch.empty((B, 1, H), dtype=torch.bfloat16, device="cuda")
+    ctx.layer_forward_last(desc, policy, wptrs, x, y_last, kv2, B, T, 0)
+    ctx.synchronize(); ctx.kv_store_wait()
+    assert torch.equal(k1.view(torch.int16), k2.view(torch.int16)) and torch.equal(v1.view(torch.int16), v2.view(torch.int16))
+    got, full = to_bits(y_last)[:, 0], to_bits(y_full)[:, -1]
+    okc, ovc = np.zeros((T, B, heads, d), np.uint16), np.zeros((T, B, heads, d), np.uint16)
+    oracle.lib().lia_oracle_set_fast(0)
+    ref = oracle.layer_forward(3, W, xb, okc, ovc, 0, heads)[:, -1]
+    q = 2.0 ** (np.floor(np.log2(np.abs(synth.bf16_bits_to_f32(ref)).max())) - 7)
+    for name, other in (("full prefill", full), ("oracle", ref)):
+        err = np.abs(synth.bf16_bits_to_f32(got) - synth.bf16_bits_to_f32(other))
+        print(f"\nlast-only vs {name}: {100 * (got == other).mean():.1f} % bit-identical, max err {err.max():.4g} ({err.max() / q:.2f} quanta)")
+        assert err.max() <= 3 * q and (err <= q).mean() >= 0.99
+    with pytest.raises(ValueError):
+        ctx.layer_forward_last(desc, policy, wptrs, x[:, :1].contiguous(), y_last, kv2, B, 1, 0)        # not a multi-token prefill
+    ctx.close()
+
+
+def test_generate_with_and_without_the_prefill_tail(monkeypatch):
+    """LIA_PREFILL_TAIL=0 (every position of the last layer, as the reference computes it) and the default give the golden ids"""
+    import torch
+    from lia_amd.generation import generate
+    z, m, ids, c = _load("generate_h256")
+    outs = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("LIA_PREFILL_TAIL", tail)
+        for flags in (HEADLINE, dict(gpu_percentage=100, prefill_policy=0, decoding_policy=2, pin_weight=True)):
+            model = _model(m, c)
+            out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], **flags)
+            assert model._lia_scheduler.prefill_tail == (tail == "1")
+            assert (out.numpy() == z["ids_bf16"]).all(), (tail, flags, out[0, c["T"]:].tolist())
+            model._lia_scheduler.close()
+            model.close()
