@@ -167,9 +167,13 @@ def test_edge_cases_tiny_prompt_batch1_and_max_positions(oracle):
         model = LiaOPTModel.from_numpy(shape, m)
         out = generate(model, torch.from_numpy(ids), max_new_tokens=new, min_new_tokens=new, prefill_policy=0, decoding_policy=2,
                        gpu_percentage=50, pin_weight=True)
-        ref, _ = oracle.generate(m, ids, new, heads, 0, 2, 50)
+        ref, _, ref_logits = oracle.generate(m, ids, new, heads, 0, 2, 50, return_logits=True)
         assert out.shape == (B, T + new)
-        assert (out.numpy() == ref).mean() > 0.9 and (out.numpy()[:, :T + 2] == ref[:, :T + 2]).all(), (out.tolist(), ref.tolist())
+        # equal to the oracle; a row may part from it only at a near-tie of the oracle's own logits (reported, not hidden)
+        from parity_util import ids_equal_or_near_tie
+        first, gaps = ids_equal_or_near_tie(out.numpy(), ref, ref_logits, T, f"B={B} T={T}")
+        print(f"\nedge case B={B} T={T} new={new}: first divergent step {first}, smallest top-2 gaps per step {[round(g, 3) for g in gaps]}")
+        assert (out.numpy()[:, :T + 2] == ref[:, :T + 2]).all(), (out.tolist(), ref.tolist())
         model._lia_scheduler.close()
         model.close()
     model = LiaOPTModel.from_numpy(shape, m)

@@ -87,7 +87,7 @@ def test_llama_generate_ids_match_hf(gpu_pct, mb, fmt, monkeypatch):
 
 
 @pytest.mark.parametrize("B,S,kvh", [(3, 1, 2), (5, 127, 2), (2, 128, 1), (16, 129, 2), (128, 1037, 8), (7, 2050, 3)])
-def test_grouped_decode_attention_d128(B, S, kvh):
+def test_grouped_decode_attention_d128(B, S, kvh, oracle):
     """lia_attn_decode_kernel<128, 4> (four query heads per K/V head, the DPP row sum of q.k) at sizes up to Llama-3-8B's decode
     step, against a plain fp32 restatement of HF's eager grouped attention at one query position."""
     import torch
@@ -117,4 +117,11 @@ def test_grouped_decode_attention_d128(B, S, kvh):
     ref = torch.einsum("bhgs,bhsd->bhgd", p, vf).reshape(B, heads * d)
     err = (out.float() - ref).abs()
     assert float(err.max()) <= 0.02 + 0.016 * float(ref.abs().max()), float(err.max())
+    # ... and against oracle/'s restatement of the same attention (lia_oracle_attn_gqa), same rounding points: almost every output
+    # bit-identical, none further than one bf16 quantum of the largest
+    ob = oracle.attention_gqa(to_bits(q).reshape(B, 1, heads * d), to_bits(kc), to_bits(vc), S, heads, kvh)
+    gb = to_bits(out).reshape(B, 1, heads * d)
+    of, gf = synth.bf16_bits_to_f32(ob), synth.bf16_bits_to_f32(gb)
+    quantum = 2.0 ** (np.floor(np.log2(np.abs(of).max())) - 7)
+    assert np.abs(of - gf).max() <= quantum and (ob == gb).mean() >= 0.99, (float(np.abs(of - gf).max()), float((ob == gb).mean()))
     ctx.close()
