@@ -192,6 +192,11 @@ size_t lia_llama_workspace_bytes(const lia_llama_desc* d, int max_rows);
 int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x, lia_bf16* y,
                             lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int T, int pos0, int b0,
                             void* stream);
+/* the Llama counterpart of lia_layer_forward_last: the LAST layer of a prefill -- norm, q | k | v projection and RoPE on every row
+ * (the cache holds every position), attention / o / MLP on the last position of each row; y_last: [B, 1, H]; T > 1, pos0 == 0 */
+int lia_llama_layer_forward_last(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x,
+                                 lia_bf16* y_last, lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int T,
+                                 int pos0, int b0, void* stream);
 int lia_llama_embed(const int64_t* ids, const lia_bf16* tok, lia_bf16* y, int B, int T, int H, void* stream);
 int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* normw, const lia_bf16* lm,
                       int vocab, float eps, int suppress_token, lia_bf16* logits, int64_t* next_ids, void* stream);

@@ -797,9 +797,11 @@ extern "C" size_t lia_llama_workspace_bytes(const lia_llama_desc* d, int max_row
   return llama_ws(d, max_rows).total;
 }
 
-extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x,
-                                       lia_bf16* y, lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int T,
-                                       int pos0, int b0, void* stream) {
+// tail = 1 (lia_llama_layer_forward_last): see layer_forward_impl -- norm, q | k | v projection and RoPE on every row, the rest on the
+// last position of each row; y is [B, 1, H]
+static int llama_layer_forward_impl(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x,
+                                    lia_bf16* y, lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int T,
+                                    int pos0, int b0, void* stream, int tail) {
   if (!ctx) return LIA_ERR_INVALID;
   int rc = check_llama_desc(d);
   if (rc) return rc;
@@ -811,8 +813,11 @@ extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, co
     lia_set_error("lia_llama_layer_forward: B=%d T=%d pos0=%d b0=%d vs cache batch=%d smax=%d", B, T, pos0, b0, kv->batch, kv->smax);
     return LIA_ERR_INVALID;
   }
+  if (tail && T < 2) { lia_set_error("lia_llama_layer_forward_last: a multi-token prefill only"); return LIA_ERR_INVALID; }
   const int H = d->hidden, F = d->ffn, hd = H / d->heads, KD = d->kv_heads * hd;
   const long M = (long)B * T;
+  const long Mt = tail ? (long)B : M;
+  const long tail_off = tail ? (long)(T - 1) * H : 0, tail_ld = tail ? (long)T * H : (long)H;
   const LlamaWs w = llama_ws(d, M);
   if (w.total > ctx->ws_bytes) { lia_set_error("lia_llama_layer_forward: workspace %zu < %zu", ctx->ws_bytes, w.total); return LIA_ERR_MEMORY; }
   hipStream_t st = (hipStream_t)stream;
@@ -872,47 +877,59 @@ extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, co
                         kv->batch + B, st);
     }
   }
-  int arc = T == 1 ? lia_attn_decode_launch(qb, H, kv->k, kv->v, ao, H, B, pos0 + 1, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st)
-                   : lia_attn_prefill_launch(qb, H, kv->k, kv->v, ao, H, B, T, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st);
+  int arc = (T == 1 || tail) ? lia_attn_decode_launch(qb + tail_off, tail_ld, kv->k, kv->v, ao, H, B, pos0 + T, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st)
+                             : lia_attn_prefill_launch(qb, H, kv->k, kv->v, ao, H, B, T, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st);
   if (arc) { lia_set_error("llama attention: unsupported head_dim %d / S %d", hd, pos0 + T); return LIA_ERR_INVALID; }
   int norm2_done = 0, silu_done = 0;
   {  // o_proj + residual; the post-attention RMSNorm rides in the split-K combine when there is one
-    LiaEpilogue ep{nullptr, x, H, 0};
+    LiaEpilogue ep{nullptr, x + tail_off, tail_ld, 0};
     LiaOutMap om = plain_out(h1, H, H);
     LiaPost post{};
     post.kind = LIA_POST_RMSNORM; post.g = W[5]; post.eps = d->rms_eps; post.out = ln; post.ldo = H;
-    rc = gemm_checked(ctx, ao, H, W[4], (int)M, H, H, ep, om, gws, w.gemm_bytes, 0, st, &post, &norm2_done);
+    rc = gemm_checked(ctx, ao, H, W[4], (int)Mt, H, H, ep, om, gws, w.gemm_bytes, 0, st, &post, &norm2_done);
     if (rc) return rc;
   }
-  if (!norm2_done) lia_rmsnorm_launch(h1, H, W[5], ln, H, M, H, d->rms_eps, st);
+  if (!norm2_done) lia_rmsnorm_launch(h1, H, W[5], ln, H, Mt, H, d->rms_eps, st);
   const bool fused_gu = W[7] == W[6] + (size_t)F * H;
   if (fused_gu) {
     LiaOutMap om = plain_out(gu, 2 * F, 2 * F);
     LiaPost post{};
     post.kind = LIA_POST_SILU_MUL; post.out = act; post.ldo = F;     // act = silu(gate) * up straight from the combine / the tiled epilogue
     post.gu_block = d->gu_block;
-    rc = gemm_checked(ctx, ln, H, W[6], (int)M, 2 * F, H, none, om, gws, w.gemm_bytes, 0, st, &post, &silu_done);
+    rc = gemm_checked(ctx, ln, H, W[6], (int)Mt, 2 * F, H, none, om, gws, w.gemm_bytes, 0, st, &post, &silu_done);
     if (rc) return rc;
   } else {
     for (int part = 0; part < 2; ++part) {
       LiaOutMap om = plain_out(gu + (size_t)part * F, 2 * F, F);
-      rc = gemm_checked(ctx, ln, H, W[6 + part], (int)M, F, H, none, om, gws, w.gemm_bytes, 0, st);
+      rc = gemm_checked(ctx, ln, H, W[6 + part], (int)Mt, F, H, none, om, gws, w.gemm_bytes, 0, st);
       if (rc) return rc;
     }
   }
-  if (!silu_done) lia_silu_mul_launch(gu, act, M, F, fused_gu ? d->gu_block : 0, st);
+  if (!silu_done) lia_silu_mul_launch(gu, act, Mt, F, fused_gu ? d->gu_block : 0, st);
   {  // down_proj + residual (+ the next layer's input RMSNorm when the caller chained it)
     LiaEpilogue ep{nullptr, h1, H, 0};
     LiaOutMap om = plain_out(y, H, H);
     LiaPost post{};
     int chained = 0;
     if (chain_g) { post.kind = LIA_POST_RMSNORM; post.g = chain_g; post.eps = d->rms_eps; post.out = ln; post.ldo = H; }
-    rc = gemm_checked(ctx, act, F, W[8], (int)M, H, F, ep, om, gws, w.gemm_bytes, 0, st, post.kind ? &post : nullptr, &chained);
+    rc = gemm_checked(ctx, act, F, W[8], (int)Mt, H, F, ep, om, gws, w.gemm_bytes, 0, st, post.kind ? &post : nullptr, &chained);
     if (rc) return rc;
-    if (chained) { ctx->normed_src = y; ctx->normed_buf = ln; ctx->normed_rows = M; ctx->normed_h = H; }
+    if (chained) { ctx->normed_src = y; ctx->normed_buf = ln; ctx->normed_rows = Mt; ctx->normed_h = H; }
   }
   HIP_TRY(hipGetLastError());
   return LIA_OK;
+}
+
+extern "C" int lia_llama_layer_forward(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x,
+                                       lia_bf16* y, lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int T,
+                                       int pos0, int b0, void* stream) {
+  return llama_layer_forward_impl(ctx, d, weights, x, y, kv, cos_table, sin_table, B, T, pos0, b0, stream, 0);
+}
+
+extern "C" int lia_llama_layer_forward_last(lia_ctx* ctx, const lia_llama_desc* d, const void* const weights[9], const lia_bf16* x,
+                                            lia_bf16* y_last, lia_kv* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B,
+                                            int T, int pos0, int b0, void* stream) {
+  return llama_layer_forward_impl(ctx, d, weights, x, y_last, kv, cos_table, sin_table, B, T, pos0, b0, stream, 1);
 }
 
 extern "C" int lia_llama_embed(const int64_t* ids, const lia_bf16* tok, lia_bf16* y, int B, int T, int H, void* stream) {

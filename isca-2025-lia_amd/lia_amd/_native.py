@@ -80,6 +80,8 @@ SIGNATURES = {
     "lia_llama_workspace_bytes": (c_size_t, [ctypes.POINTER(LlamaDesc), c_int]),
     "lia_llama_layer_forward": (c_int, [c_void_p, ctypes.POINTER(LlamaDesc), ctypes.POINTER(c_void_p * 9), c_void_p, c_void_p,
                                         ctypes.POINTER(KV), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lia_llama_layer_forward_last": (c_int, [c_void_p, ctypes.POINTER(LlamaDesc), ctypes.POINTER(c_void_p * 9), c_void_p, c_void_p,
+                                             ctypes.POINTER(KV), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lia_llama_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lia_llama_lm_head": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p,
                                   c_void_p, c_void_p]),

@@ -189,6 +189,7 @@ class LlamaScheduler:
         self.pack = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, 0: 0, 10: 10, 11: 11, 12: 12, False: 0, True: 12}[fmt]
         self.ctx = self.pipe = None
         self.hidden, self.resident, self.tables = {}, {}, None
+        self.prefill_tail = os.environ.get("LIA_PREFILL_TAIL", "1") != "0"      # last layer of a prefill: last position only behind q|k|v
 
     def _ensure(self, rows, B, T, n_gpu, smax):
         sh, lib = self.model.shape, N.lib()
@@ -247,6 +248,7 @@ class LlamaScheduler:
                 self.resident[i] = self._ptrs(m.layers[i].device_ptr())
             return self.resident[i]
 
+        xlast = None
         for idx in range(L):
             if idx < n_gpu:
                 w = resident(idx)
@@ -261,18 +263,23 @@ class LlamaScheduler:
                         break
                     pipe.prefetch(nxt)
             nmb = B // mini
+            tail = self.prefill_tail and T > 1 and pos0 == 0 and idx == L - 1
+            if tail:
+                xlast = torch.empty((B, 1, sh.hidden), dtype=torch.bfloat16, device="cuda")
+            fn = lib.lia_llama_layer_forward_last if tail else lib.lia_llama_layer_forward
             for i in range(nmb):
                 sl = slice(i * mini, (i + 1) * mini)
-                N.check(lib.lia_llama_layer_forward(ctx.handle, ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(x[sl].data_ptr()),
-                                                    ctypes.c_void_p(y[sl].data_ptr()), ctypes.byref(kv_state.kv[idx]),
-                                                    ctypes.c_void_p(cos.data_ptr()), ctypes.c_void_p(sin.data_ptr()), mini, T, pos0,
-                                                    i * mini, st), "lia_llama_layer_forward")
+                N.check(fn(ctx.handle, ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(x[sl].data_ptr()),
+                           ctypes.c_void_p((xlast if tail else y)[sl].data_ptr()), ctypes.byref(kv_state.kv[idx]),
+                           ctypes.c_void_p(cos.data_ptr()), ctypes.c_void_p(sin.data_ptr()), mini, T, pos0, i * mini, st),
+                        "lia_llama_layer_forward")
             if idx >= n_gpu:
                 pipe.release(idx)
             x, y = y, x
         logits = torch.empty((B, sh.vocab), dtype=torch.bfloat16, device="cuda")
         nxt_ids = torch.empty((B,), dtype=torch.int64, device="cuda")
-        N.check(lib.lia_llama_lm_head(ctx.handle, ctypes.c_void_p(x.data_ptr()), B, T, sh.hidden, ctypes.c_void_p(m.final_norm_w.data_ptr()),
+        x_lm, T_lm = (x, T) if xlast is None else (xlast, 1)     # (the last layer already reduced the block to its last position)
+        N.check(lib.lia_llama_lm_head(ctx.handle, ctypes.c_void_p(x_lm.data_ptr()), B, T_lm, sh.hidden, ctypes.c_void_p(m.final_norm_w.data_ptr()),
                                       ctypes.c_void_p(m.lm_head.data_ptr()), sh.vocab, sh.rms_eps, suppress_token,
                                       ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(nxt_ids.data_ptr()), st), "lia_llama_lm_head")
         ctx.synchronize()

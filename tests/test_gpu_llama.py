@@ -125,3 +125,39 @@ def test_grouped_decode_attention_d128(B, S, kvh, oracle):
     quantum = 2.0 ** (np.floor(np.log2(np.abs(of).max())) - 7)
     assert np.abs(of - gf).max() <= quantum and (ob == gb).mean() >= 0.99, (float(np.abs(of - gf).max()), float((ob == gb).mean()))
     ctx.close()
+
+
+@pytest.mark.parametrize("name", LAYER_CASES[:1])
+def test_llama_layer_forward_last_equals_last_position(oracle, name):
+    """lia_llama_layer_forward_last (the prefill's last layer: norm, q|k|v and RoPE on every row, the rest on the last position):
+    caches bit-identical to the full call, last position's hidden state equal to rounding."""
+    import torch
+    from lia_amd import _native as N, ops
+    from lia_amd.llama import LiaLlamaModel, LlamaShape, rope_tables
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    H, heads, kvh, F, B, T, new, seed = [int(v) for v in z["cfg"]]
+    m = synth.make_llama_model(seed, 64, H, heads, kvh, F, 1, float(z["w_std"][0]))
+    shape = LlamaShape("t", H, heads, kvh, F, 1, 64, max_pos=T + 4, rope_theta=float(z["theta"][0]))
+    model = LiaLlamaModel.from_numpy(shape, m)
+    model.place(1, True, False)
+    d = H // heads
+    lib = N.lib()
+    ctx = ops.Context(0, max(lib.lia_llama_workspace_bytes(ctypes.byref(model.desc), B * T), 1 << 24))
+    cos, sin = rope_tables(T + 4, d, shape.rope_theta)
+    w = (ctypes.c_void_p * 9)(*[model.layers[0].device_ptr() + o for o in model.offsets])
+    x = to_dev(torch, synth.make_hidden(seed + 1, B, T, H))
+    outs = []
+    for fn, shp in ((lib.lia_llama_layer_forward, (B, T, H)), (lib.lia_llama_layer_forward_last, (B, 1, H))):
+        kc = torch.zeros((T, B, kvh, d), dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        kv = N.KV(kc.data_ptr(), vc.data_ptr(), T, B, 1)
+        y = torch.empty(shp, dtype=torch.bfloat16, device="cuda")
+        N.check(fn(ctx.handle, ctypes.byref(model.desc), ctypes.byref(w), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                   ctypes.byref(kv), ctypes.c_void_p(cos.data_ptr()), ctypes.c_void_p(sin.data_ptr()), B, T, 0, 0, ctypes.c_void_p(ctx.stream)))
+        ctx.synchronize()
+        outs.append((y, kc, vc))
+    (yf, kf, vf), (yl, kl, vl) = outs
+    assert torch.equal(kf.view(torch.int16), kl.view(torch.int16)) and torch.equal(vf.view(torch.int16), vl.view(torch.int16))
+    assert_close(to_bits(yl)[:, 0], to_bits(yf)[:, -1], 0.07, 0.016, 0.75, "llama last-only vs full prefill")
+    ctx.close()
+    model.close()
