@@ -627,20 +627,23 @@ def main(argv=None):
         # The headline of this run is already measured.  It is printed NOW, and again -- extended -- as the last line when the legs
         # are done: should a leg hang in a collective (one rank failing where the others do not), a watchdog ends every rank with
         # exit code 0 and the line above stays the last JSON line of the output instead of the whole run being lost.
-        import signal
+        import threading
         if rank == 0:
             out["dp_extra_legs"] = "pending (this line is re-printed with value_kv_in_hbm / value_allgather when they finish)"
             print(json.dumps(out), flush=True)
 
-        def _watchdog(signum, frame):
+        def _watchdog():
+            # a thread, not SIGALRM: the main thread of a hung rank sits inside a C call (an RCCL wait, a stream synchronize) and would
+            # never reach a Python signal handler
             sys.stderr.write(f"bench.py: rank {rank}: the extra data-parallel legs exceeded {a.dp_extra_timeout} s; keeping the headline line\n")
             sys.stderr.flush()
             os._exit(0)
 
-        signal.signal(signal.SIGALRM, _watchdog)
-        signal.alarm(a.dp_extra_timeout)
+        timer = threading.Timer(a.dp_extra_timeout, _watchdog)
+        timer.daemon = True
+        timer.start()
         extra = dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index)
-        signal.alarm(0)
+        timer.cancel()
         if rank == 0:
             out.pop("dp_extra_legs", None)
             out.update(extra)

@@ -190,3 +190,22 @@ def test_coop_controller_converges_on_a_synthetic_box():
             ms = max(link, host) * (1 + random.uniform(-0.01, 0.01))
             ctl.observe(ms, min(1.0, link / ms))
         assert ctl.c == 18, (start, ctl.report())            # argmin of max(link, host) for these rates
+
+
+def test_bench_first_divergence_reports_step_and_gap():
+    """bench.py's ids_check: legs are compared over their common length; the first divergent step and the top-2 logit gap there"""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("lia_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    T = 3
+    a = torch.tensor([[1, 2, 3, 10, 11, 12, 13], [1, 2, 3, 10, 11, 12, 13]])
+    b = torch.tensor([[1, 2, 3, 10, 11, 99], [1, 2, 3, 10, 11, 12]])            # shorter leg; row 0 parts at step 2
+    logits = [torch.zeros((2, 8), dtype=torch.bfloat16) for _ in range(3)]
+    logits[2][0, 5], logits[2][0, 6] = 8.0, 7.9375
+    r = bench.first_divergence(a, b, T, logits)
+    assert r["ids_equal"] is False and r["steps_compared"] == 3 and r["first_divergent_step"] == 2
+    assert abs(r["top2_logit_gap_at_divergence"] - 0.0625) < 1e-6 and abs(r["bf16_quantum_at_top_logit"] - 0.0625) < 1e-9
+    same = bench.first_divergence(a, a[:, :5], T)
+    assert same == {"ids_equal": True, "steps_compared": 2, "first_divergent_step": None}
