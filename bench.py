@@ -265,8 +265,9 @@ def pmc_traffic(kernel_substr):
 
 def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index):
     """N > 1 (every rank calls this): value_kv_in_hbm -- the same broadcast stream with policy 3/3 (KV cache in HBM, no host
-    attention: what removes the per-rank host-thread bottleneck) -- and value_allgather -- every rank pins 1/N of each streamed
-    layer and reads it over ITS OWN host link, one all-gather per layer over xGMI.  Short legs (--dp-extra-steps)."""
+    attention: what removes the per-rank host-thread bottleneck) --, value_allgather -- every rank pins 1/N of each streamed
+    layer and reads it over ITS OWN host link, one all-gather per layer over xGMI -- and value_allgather_kv_in_hbm, both
+    together.  Short legs (--dp-extra-steps)."""
     import torch
     from lia_amd.generation import generate
     from lia_amd.model import LiaOPTModel
@@ -309,6 +310,9 @@ def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs,
             m2._lia_scheduler = OffloadScheduler(m2, device=dev_index, dp_group=group, pack12=fmt)
             m2._lia_scheduler.host_threads = host_threads
             leg("allgather", m2, gen_kwargs)
+            # ... and both together: every rank's own link AND no host attention -- the configuration in which neither the root's
+            # PCIe link nor the shared CPU quota bounds the step
+            leg("allgather_kv_in_hbm", m2, dict(gen_kwargs, prefill_policy=3, decoding_policy=3))
             m2._lia_scheduler.close()
             m2.close()
         except Exception as e:
