@@ -273,6 +273,10 @@ def main():
     run_layer_case(dec, att, mha, "layer_h256_d64", 256, 4, 1024, 4, 32, 2, 12, 0.08, False)
     run_layer_case(dec, att, mha, "layer_h512_d128", 512, 4, 2048, 2, 40, 2, 13, 0.06, True)
     run_layer_case(dec, att, mha, "layer_h256_b1", 256, 4, 1024, 1, 17, 2, 14, 0.08, False)
+    # r03: the reference's own functions at the HEADLINE layer shape (OPT-30B: 7168 / 56 heads / 28672, N(0, 0.02) weights): 1.2 GB
+    # of weights re-derived from the seed, 1.2 MB of outputs kept.  Not named layer_* on purpose: at this width two correct
+    # implementations agree to one bf16 quantum, not bit for bit (tests/test_gpu_fullsize_oracle.py), so it has tests of its own.
+    run_layer_case(dec, att, mha, "fullsize_layer_opt30b", 7168, 56, 28672, 2, 8, 1, 15, 0.02, False)
     run_embed_case("embed_prefill", 512, 64, 128, 2, 9, 0, 21)
     run_embed_case("embed_decode", 512, 64, 128, 2, 1, 9, 21)
     search_generate_case("generate_tiny", 512, 64, 128, 4, 512, 3, 2, 8, 6, seed0=31, w_std=0.12)

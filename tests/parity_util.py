@@ -26,3 +26,31 @@ def ids_equal_or_near_tie(got_ids, ref_ids, ref_logits, T, what=""):
                                                         f"{gaps[s][r]:.4f} (bf16 quantum {quanta[s][r]:.4f}): not a near-tie")
             break
     return first, [float(g.min()) for g in gaps]
+
+
+_FULLSIZE = {}
+
+
+def fullsize_opt30b_case():
+    """(fixture, W, x, decode x) of tests/golden/fullsize_layer_opt30b.npz -- outputs of the reference's OPTDecoderLayer_forward at the
+    OPT-30B layer shape (make_golden.py).  The 616 M weights are re-derived from the seed (~1 min of numpy), once per process."""
+    import os
+    if not _FULLSIZE:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_layer_opt30b.npz"))
+        H, heads, F, B, T, new, seed, ident = [int(v) for v in z["cfg"]]
+        _FULLSIZE.update(z=z, cfg=(H, heads, F, B, T, new), W=synth.make_layer(seed, H, F, float(z["w_std"][0])),
+                         x=synth.make_hidden(seed + 1, B, T, H, bool(ident)), xs=synth.make_hidden(seed + 100, B, 1, H, bool(ident)))
+    return _FULLSIZE
+
+
+def quantum_bound(got, ref, what, min_exact, max_quanta=3.0, within_one=0.999):
+    """two correct bf16 implementations of a wide layer: every element within `max_quanta` bf16 quanta of the tensor's largest
+    value (+ 2 ulp of its own), `within_one` of them within one quantum, at least `min_exact` bit-identical; prints the rates"""
+    a, b = synth.bf16_bits_to_f32(got), synth.bf16_bits_to_f32(ref)
+    q = 2.0 ** (np.floor(np.log2(max(float(np.abs(b).max()), 2.0 ** -120))) - 7)
+    err = np.abs(a - b)
+    frac = float((got == ref).mean())
+    print(f"\n{what}: {100 * frac:.2f} % bit-identical, max |err| {err.max():.4g} = {err.max() / q:.2f} quanta of max |ref| {np.abs(b).max():.3g}, "
+          f"{100 * (err <= q).mean():.3f} % within one quantum")
+    assert (err <= max_quanta * q + 2.0 ** -6 * np.abs(b)).all(), f"{what}: max err {err.max():.4g} > {max_quanta} quanta ({q:.3g})"
+    assert (err <= q).mean() >= within_one and frac >= min_exact, f"{what}: {100 * (err <= q).mean():.2f} % within one quantum, {100 * frac:.2f} % identical"

@@ -446,3 +446,49 @@ def test_llama3_8b_decode_layer_fused_routes_are_bit_identical(llama_layer):
         lib.lia_gemm_set_fuse_combine(1)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_opt30b_shape_layer_vs_reference_golden():
+    """lia_layer_forward at the headline layer shape against outputs of the REFERENCE'S OWN functions executed at that shape
+    (tests/golden/fullsize_layer_opt30b.npz, make_golden.py): policy 3 prefill + decode, policy 0 prefill into a host cache,
+    policy 2 decode with the host attention -- the same bound the oracle meets against this fixture on the CPU
+    (tests/test_oracle_golden.py::test_fullsize_opt30b_layer_oracle_vs_reference)."""
+    import torch
+    from lia_amd import _native as N, hostinfo, ops
+    from parity_util import fullsize_opt30b_case, quantum_bound
+    from test_gpu_ops import _layer_setup, to_dev
+    c = fullsize_opt30b_case()
+    z, W, x, xs = c["z"], c["W"], c["x"], c["xs"]
+    H, heads, F, B, T, new = c["cfg"]
+    d = H // heads
+    desc, wdev, wptrs = _layer_setup(torch, ops, W, H, heads, F)
+    ctx = ops.Context(0, ops.workspace_bytes(desc, B * T))
+    ctx.set_host_threads(hostinfo.usable_cpus())
+    smax = T + new
+    kc = torch.zeros((smax, B, heads, d), dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    kv = N.KV(kc.data_ptr(), vc.data_ptr(), smax, B, 1)
+    xd, xsd = to_dev(torch, x), to_dev(torch, xs)
+    y = torch.empty_like(xd)
+    ctx.layer_forward(desc, 3, wptrs, xd, y, kv, B, T, 0)
+    ctx.synchronize()
+    quantum_bound(to_bits(y), z["p3_hidden"], "HIP vs reference, policy-3 prefill hidden", 0.4)
+    ys = torch.empty_like(xsd)
+    ctx.layer_forward(desc, 3, wptrs, xsd, ys, kv, B, 1, T)
+    ctx.synchronize()
+    quantum_bound(to_bits(ys), z["p3_dec0_hidden"], "HIP vs reference, policy-3 decode hidden", 0.3)
+    quantum_bound(to_bits(kc), z["p3_kcache"], "K cache", 0.97, max_quanta=1.0)
+    quantum_bound(to_bits(vc), z["p3_vcache"], "V cache", 0.97, max_quanta=1.0)
+    hk = torch.zeros((smax, B, heads, d), dtype=torch.bfloat16).pin_memory()
+    hv = torch.zeros((smax, B, heads, d), dtype=torch.bfloat16).pin_memory()
+    kvh = N.KV(hk.data_ptr(), hv.data_ptr(), smax, B, 0)
+    y0 = torch.empty_like(xd)
+    ctx.layer_forward(desc, 0, wptrs, xd, y0, kvh, B, T, 0)
+    ctx.synchronize(); ctx.kv_store_wait()
+    quantum_bound(to_bits(y0), z["p0_hidden"], "HIP vs reference, policy-0 prefill hidden", 0.4)
+    quantum_bound(to_bits(hk)[:T], z["p0_key"], "host K rows", 0.97, max_quanta=1.0)
+    y2 = torch.empty_like(xsd)
+    ctx.layer_forward(desc, 2, wptrs, xsd, y2, kvh, B, 1, T)
+    ctx.synchronize()
+    quantum_bound(to_bits(y2), z["p2_dec0_hidden"], "HIP vs reference, policy-2 decode hidden", 0.2)
+    ctx.close()
