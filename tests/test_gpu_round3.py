@@ -255,3 +255,50 @@ def test_generate_with_and_without_the_prefill_tail(monkeypatch):
             assert (out.numpy() == z["ids_bf16"]).all(), (tail, flags, out[0, c["T"]:].tolist())
             model._lia_scheduler.close()
             model.close()
+
+
+def test_tier_moves_leave_the_layer_usable_when_the_host_allocation_is_refused(monkeypatch):
+    """to_pinned / to_cxl / the sharded pin free the old copy first; when the guard (or the allocation, or the copy)
+    then fails, the layer must stay where it can be rebuilt from -- the raw copy in device memory -- not end up with tier None."""
+    import torch
+    from lia_amd import hostinfo
+    from lia_amd.generation import generate
+    z, m, ids, c = _load("generate_h256")
+    model = _model(m, c)
+    flags = dict(prefill_policy=0, decoding_policy=2, gpu_percentage=25, pin_weight=True)
+    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], **flags)
+    assert (out.numpy() == z["ids_bf16"]).all()
+    st = model.layers[-1]
+    assert st.tier == "pinned"
+
+    def refuse(nbytes, what, ceiling=0.93):
+        raise MemoryError(f"{what}: refused by the test")
+
+    monkeypatch.setattr(hostinfo, "guard_host_allocation", refuse)
+    for move in (lambda: st.to_pinned(10), lambda: st.to_cxl(0), lambda: st.to_pinned(0, shard=(0, 2))):
+        with pytest.raises(MemoryError):
+            move()
+        assert st.tier == "device" and st._dev is not None and st._ptr is None        # nothing lost, nothing leaked
+    monkeypatch.undo()
+    model.placed_for = None                       # (the failed moves changed a tier behind the placement key)
+    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], **flags)
+    assert (out.numpy() == z["ids_bf16"]).all() and st.tier == "pinned"
+    model._lia_scheduler.close()
+    model.close()
+
+
+def test_load_packed_checks_the_container_before_mapping(tmp_path, monkeypatch):
+    """load_packed registers (pins) every streamed layer file; the whole plan is judged first and each mapping again"""
+    from lia_amd import hostinfo, packed_checkpoint
+    from lia_amd.model import OPTShape
+    sh = OPTShape("t", 256, 4, 1024, 3, vocab=512, max_pos=64)
+    packed_checkpoint.write_dummy_checkpoint(sh, str(tmp_path), wire=10)
+    model = packed_checkpoint.load_packed(str(tmp_path), n_gpu_layers=1)
+    assert [st.tier for st in model.layers] == ["device", "mapped", "mapped"]
+    assert all(st.map_mode in ("shared-readonly", "private") for st in model.layers[1:])
+    model.close()
+    calls = []
+    monkeypatch.setattr(hostinfo, "check_host_allocation", lambda n, what, safety=0.85: calls.append(n) or (_ for _ in ()).throw(MemoryError(what)))
+    with pytest.raises(MemoryError):
+        packed_checkpoint.load_packed(str(tmp_path), n_gpu_layers=1)
+    assert calls and calls[0] > 0
