@@ -269,12 +269,6 @@ int lia_stream_stats(lia_streamer* s, double* bytes, double* busy_ms, int reset)
  * online cooperative-split controller, which must not wait for the prefetched layers) */
 int lia_stream_poll_stats(lia_streamer* s, double* bytes, double* busy_ms);
 void* lia_stream_copy_stream(lia_streamer* s);
-/* For callers that put collectives between lia_stream_copy_chunk and lia_stream_mark_ready (data-parallel weight broadcast /
- * all-gather): wait for the collectives on the auxiliary stream, not on the copy stream, and name it with lia_stream_order_on
- * before lia_stream_decode_packed / lia_stream_mark_ready -- the load's completion is recorded there and the copy engine goes on
- * with the next layer at once.  The order stream of a slot lasts until its next lia_stream_begin. */
-void* lia_stream_aux_stream(lia_streamer* s);
-int lia_stream_order_on(lia_streamer* s, int slot, void* stream);
 
 /* ---- host memory tiers ------------------------------------------------------------------------------
  * The four exports of the reference's libnuma shim, lia/cxl/numa_alloc.c:7,25,66,108 (same names, same

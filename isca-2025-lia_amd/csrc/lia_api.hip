@@ -984,8 +984,6 @@ struct lia_streamer {
   std::vector<hipEvent_t> landed;
   std::vector<char> decoded_on_side;
   hipStream_t copy;
-  hipStream_t aux;        // lia_stream_aux_stream: where a data-parallel caller waits for its collectives (created on demand)
-  std::vector<hipStream_t> order;   // per slot: the stream on which "this load is complete" is recorded (NULL = the copy stream)
   std::vector<hipEvent_t> copied, released, t0, t1;
   std::vector<char> has_release, timing_pending, was_marked;
   std::vector<size_t> pending_bytes;
@@ -1010,8 +1008,7 @@ extern "C" int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, l
   *out = nullptr;
   lia_streamer* s = new lia_streamer();
   s->ctx = ctx; s->n_slots = n_slots; s->slot_bytes = align_up(slot_bytes, 256);
-  s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr; s->staging = nullptr; s->staging_bytes = 0; s->aux = nullptr;
-  s->order.assign(n_slots, nullptr);
+  s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr; s->staging = nullptr; s->staging_bytes = 0;
   HIP_TRY(hipMalloc((void**)&s->slots, s->slot_bytes * n_slots));
   if (ctx->serialized) s->copy = ctx->compute;
   else HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
@@ -1043,7 +1040,6 @@ extern "C" void lia_stream_destroy(lia_streamer* s) {
     if (s->decode != s->ctx->compute) (void)hipStreamDestroy(s->decode);
     (void)hipFree(s->staging);
   }
-  if (s->aux && s->aux != s->ctx->compute) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
   if (s->copy != s->ctx->compute) (void)hipStreamDestroy(s->copy);
   delete s;
 }
@@ -1054,24 +1050,6 @@ extern "C" void* lia_stream_slot_ptr(lia_streamer* s, int slot) {
 }
 
 extern "C" void* lia_stream_copy_stream(lia_streamer* s) { return s ? (void*)s->copy : nullptr; }
-
-// Data-parallel callers put collectives between the host copy and "ready" (lia_stream_begin / copy_chunk / mark_ready).  Waiting
-// for them ON the copy stream would hold the next layer's host copy behind this layer's last broadcast (the copy engine idles
-// ~1 ms of every 15); instead the caller waits on this auxiliary stream and names it with lia_stream_order_on: the load's
-// completion point (landed -> wire decode, ready event, busy-time end) is then recorded there and the copy stream runs on.
-extern "C" void* lia_stream_aux_stream(lia_streamer* s) {
-  if (!s) return nullptr;
-  if (!s->aux) {
-    if (s->ctx->serialized) s->aux = s->ctx->compute;
-    else if (hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking) != hipSuccess) { s->aux = nullptr; return nullptr; }
-  }
-  return (void*)s->aux;
-}
-extern "C" int lia_stream_order_on(lia_streamer* s, int slot, void* stream) {
-  if (!s || slot < 0 || slot >= s->n_slots) return LIA_ERR_INVALID;
-  s->order[slot] = (hipStream_t)stream;      // until the slot's next lia_stream_begin
-  return LIA_OK;
-}
 
 // prefetch = begin + copy_chunk(whole layer) + mark_ready.  The three-step form lets a data-parallel caller
 // interleave RCCL broadcasts of the chunks (on streams ordered after the copy stream) before the slot is
@@ -1085,7 +1063,6 @@ extern "C" int lia_stream_begin(lia_streamer* s, int slot) {
   if (s->was_marked[slot]) HIP_TRY(hipStreamWaitEvent(s->copy, s->copied[slot], 0));
   HIP_TRY(hipEventRecord(s->t0[slot], s->copy));
   s->pending_bytes[slot] = 0;
-  s->order[slot] = nullptr;
   return LIA_OK;
 }
 
@@ -1172,9 +1149,8 @@ extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_valu
   // The decode runs on its own stream behind an event, so the copy engine moves on to the next layer at once.
   // It must not start before the slot's previous consumer released it: begin() made the COPY stream wait for that,
   // and `landed` is recorded on the copy stream after the copy, so the order is inherited.
-  hipStream_t os = s->order[slot] ? s->order[slot] : s->copy;          // (a data-parallel load completes behind its collectives)
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));                       // copy-engine busy time ends here
-  HIP_TRY(hipEventRecord(s->landed[slot], os));
+  HIP_TRY(hipEventRecord(s->landed[slot], s->copy));
   HIP_TRY(hipStreamWaitEvent(s->decode, s->landed[slot], 0));
   lia_packed_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, format, s->decode);
   HIP_TRY(hipGetLastError());
@@ -1214,7 +1190,7 @@ extern "C" int lia_stream_mark_ready(lia_streamer* s, int slot) {
     return LIA_OK;
   }
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));
-  HIP_TRY(hipEventRecord(s->copied[slot], s->order[slot] ? s->order[slot] : s->copy));
+  HIP_TRY(hipEventRecord(s->copied[slot], s->copy));
   s->timing_pending[slot] = 1;
   s->was_marked[slot] = 1;
   return LIA_OK;

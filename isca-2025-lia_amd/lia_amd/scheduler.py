@@ -49,9 +49,6 @@ class WeightPipeline:
             from .dp import RawDeviceBuffer
             self.slot_tensors = [RawDeviceBuffer(p, model.layer_bytes).tensor() for p in self.slot_ptrs]
             self.copy_stream = torch.cuda.ExternalStream(self.lib.lia_stream_copy_stream(h))
-            # the collectives of a layer are waited for on this stream, so the copy stream moves on to the next layer's host copy
-            self.aux_ptr = self.lib.lia_stream_aux_stream(h)
-            self.aux_stream = torch.cuda.ExternalStream(self.aux_ptr)
             self.staging_tensors = None
             # the root tells every rank which layers travel pack12-encoded and how many bytes each one ships
             meta = torch.zeros((len(model.layers), 2), dtype=torch.int64, device="cuda")
@@ -108,16 +105,9 @@ class WeightPipeline:
             def before(off, n):
                 N.check(copy_fn(self.handle, slot, off, ctypes.c_void_p(base + off), n, pinned), "lia_stream_copy_chunk")
         with torch.cuda.stream(self.copy_stream):
-            works = broadcast_chunked(dp.dist, target, dp.root, dp.chunk_bytes, before_chunk=before)   # each one behind its chunk's H2D
-            if dp.dist.get_backend() != "nccl":
-                for w in works:
-                    w.wait()          # gloo (validation runs): host-blocking, completion ordered on the copy stream as before
-        if dp.dist.get_backend() == "nccl":
-            with torch.cuda.stream(self.aux_stream):
-                for w in works:
-                    w.wait()          # the AUX stream waits for RCCL's stream: neither the host nor the copy engine blocks,
-            #                           and the next layer's H2D does not queue behind this layer's last broadcast
-            N.check(self.lib.lia_stream_order_on(self.handle, slot, ctypes.c_void_p(self.aux_ptr)), "lia_stream_order_on")
+            works = broadcast_chunked(dp.dist, target, dp.root, dp.chunk_bytes, before_chunk=before)
+            for w in works:
+                w.wait()              # the copy stream waits for RCCL's stream; the host does not block
         if packed:
             N.check(self.lib.lia_stream_decode_packed(self.handle, slot, self.model.layer_bytes // 2, int(packed)), "lia_stream_decode_packed")
         N.check(self.lib.lia_stream_mark_ready(self.handle, slot), "lia_stream_mark_ready")
@@ -154,10 +144,7 @@ class WeightPipeline:
         mine = full[r * sh:(r + 1) * sh]
         with torch.cuda.stream(self.copy_stream):
             if dp.dist.get_backend() == "nccl":
-                work = dp.dist.all_gather_into_tensor(full, mine, async_op=True)      # in place: `mine` is slice r of `full`; behind the H2D
-                with torch.cuda.stream(self.aux_stream):
-                    work.wait()
-                N.check(self.lib.lia_stream_order_on(self.handle, slot, ctypes.c_void_p(self.aux_ptr)), "lia_stream_order_on")
+                dp.dist.all_gather_into_tensor(full, mine, async_op=True).wait()      # in place: `mine` is slice r of `full`
             else:
                 parts = [torch.empty_like(mine) for _ in range(G)]                    # gloo (validation runs): out of place
                 dp.dist.all_gather(parts, mine.clone())
