@@ -302,3 +302,33 @@ def test_load_packed_checks_the_container_before_mapping(tmp_path, monkeypatch):
     with pytest.raises(MemoryError):
         packed_checkpoint.load_packed(str(tmp_path), n_gpu_layers=1)
     assert calls and calls[0] > 0
+
+
+def test_bench_line_contract_on_a_small_model():
+    """bench.py end to end on opt-125m dims (seconds): ONE JSON line as the last line of stdout, with the contract's keys, the
+    binding roofline named (`pcie` for a streamed configuration, the dominant kernel's HBM figures as a sub-object), the CPU
+    baseline, the oracle parity sample and the id checks of the legs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", "opt-125m", "--batch", "8", "--prompt", "32", "--steps", "4",
+                        "--warmup", "1", "--gpu-percentage", "25", "--raw-steps", "2", "--cpu-steps", "2", "--coop-steps", "4"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    d = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "tokens/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 8 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"] + 1e-9
+    rf = d["roofline"]
+    assert rf["bound"] == "pcie" and rf["unit"] == "GB/s" and rf["peak"] == 63.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["traffic"] > 0
+    dk = rf["dominant_kernel"]
+    assert dk["bound"] == "hbm" and dk["peak"] == 8000.0 and abs(dk["frac"] - dk["achieved"] / 8000.0) < 1e-9 and dk["launches"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "tokens/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["parity"]["max_err_in_quanta"] <= 3.0 and d["parity"]["frac_within_one_quantum"] >= 0.99
+    assert d["ids_check"]["pack10_vs_raw_wire"]["ids_equal"] is True
+    assert d["kv_delivery"]["deferred"] in (True, False) and d["config"]["new_tokens"] == 6
