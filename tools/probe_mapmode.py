@@ -5,7 +5,7 @@ from lia_amd import hostinfo
 from lia_amd.model import OPTShape
 from lia_amd.packed_checkpoint import write_dummy_checkpoint, load_packed
 sh = OPTShape("t", 2048, 16, 8192, 6, vocab=4096, max_pos=128)
-d = tempfile.mkdtemp(dir="gpurun_out")
+d = tempfile.mkdtemp(dir="/tmp")
 m0 = hostinfo.cgroup_memory()["current"]
 write_dummy_checkpoint(sh, d, wire=10)
 m1 = hostinfo.cgroup_memory()["current"]
