@@ -243,6 +243,9 @@ def main(argv=None):
     res = summarize(total_time, args.num_iter, args.num_warmup, total_list, args.batch_size)
     if "decode_tokens_per_s" in res:
         print("Decode throughput: %.2f tokens/s, prefill %.1f ms" % (res["decode_tokens_per_s"], res["prefill_ms"]))
+    coop = getattr(model._lia_scheduler, "coop_report", lambda: None)()
+    if coop:
+        print("Cooperative split (online): %d host-computed decode layers, ms per step by count %s" % (coop["host_layers"], coop["ms_by_count"]))
     return res
 
 

@@ -541,6 +541,10 @@ class OffloadScheduler:
                 self.pipe.drain()
             self.resident_ptrs.clear()
         m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=cpu_set, shard=shard)
+        if coop is not None and is_prefill:
+            # a new generation: its first decode step also waits for the prefill's K/V deliveries and loads layers on demand --
+            # not a sample of the steady state
+            coop.settle, coop.acc = max(coop.settle, 1), []
         host_act = coop.host_set() if coop is not None else cpu_set   # the layers whose DECODE step runs on the host cores
         host_now = host_act if not is_prefill else frozenset()    # layers this forward computes on the host
         t_fwd0 = None
