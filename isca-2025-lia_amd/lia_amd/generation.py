@@ -101,10 +101,7 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         # EOS is suppressed while fewer than min_new_tokens were generated (HF MinNewTokensLengthLogitsProcessor)
         suppress = eos_token_id if (eos_token_id is not None and step < min_new_tokens) else -1
         logits, nxt = sched.forward(cur, kv, max_new_tokens=max_new_tokens, suppress_token=suppress, **lia)
-        # the scheduler mirrors the ids into pinned host memory behind the argmax kernel (scheduler.IdsMirror); Tensor.cpu() otherwise
-        next_tokens = getattr(sched, "last_ids_host", None)
-        if next_tokens is None:
-            next_tokens = nxt.cpu()
+        next_tokens = nxt.cpu()
         same_as_device = eos_token_id is None or all_unfinished        # no row was replaced by the pad token below
         if eos_token_id is not None:
             next_tokens = next_tokens * unfinished + pad_token_id * (1 - unfinished)   # greedy_search.py:398-405

@@ -189,8 +189,6 @@ class LlamaScheduler:
         self.pack = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, 0: 0, 10: 10, 11: 11, 12: 12, False: 0, True: 12}[fmt]
         self.ctx = self.pipe = None
         self.hidden, self.resident, self.tables = {}, {}, None
-        from .scheduler import IdsMirror
-        self._ids_mirror, self.last_ids_host = IdsMirror(), None
         self.prefill_tail = os.environ.get("LIA_PREFILL_TAIL", "1") != "0"      # last layer of a prefill: last position only behind q|k|v
 
     def _ensure(self, rows, B, T, n_gpu, smax):
@@ -284,9 +282,7 @@ class LlamaScheduler:
         N.check(lib.lia_llama_lm_head(ctx.handle, ctypes.c_void_p(x_lm.data_ptr()), B, T_lm, sh.hidden, ctypes.c_void_p(m.final_norm_w.data_ptr()),
                                       ctypes.c_void_p(m.lm_head.data_ptr()), sh.vocab, sh.rms_eps, suppress_token,
                                       ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(nxt_ids.data_ptr()), st), "lia_llama_lm_head")
-        mirrored = self._ids_mirror.capture(ctx, nxt_ids)
         ctx.synchronize()
-        self.last_ids_host = self._ids_mirror.read(B) if mirrored else None
         kv_state.len = pos0 + T
         return logits, nxt_ids
 

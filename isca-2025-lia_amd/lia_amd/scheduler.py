@@ -252,32 +252,6 @@ class PinnedPool:
         return torch.frombuffer(buf, dtype=torch.int16).view(torch.bfloat16).view(*shape)
 
 
-class IdsMirror:
-    """The argmax ids of a forward, mirrored into pinned host memory by a kernel blit on the compute stream right behind the
-    argmax kernel: when the forward's own synchronize returns they are already on the host, and the token loop needs no
-    `Tensor.cpu()` (a D2H copy on torch's stream plus its synchronize: ~0.1 ms of GPU idle between two decode steps, 1-2 % of a
-    resident-model step).  greedy_search.py:395-408 reads `next_tokens` on the host every step."""
-
-    def __init__(self):
-        self.ptr, self.cap = None, 0
-
-    def capture(self, ctx, nxt):
-        nbytes = (nxt.numel() * 8 + 15) // 16 * 16
-        if nbytes > self.cap:
-            if self.ptr:
-                PinnedPool.release(self.ptr, self.cap)
-            self.cap = max(nbytes, 4096)
-            self.ptr = PinnedPool.acquire(self.cap)
-        if nxt.numel() * 8 == nbytes:
-            N.check(ctx.lib.lia_blit(ctypes.c_void_p(self.ptr), ctypes.c_void_p(nxt.data_ptr()), nbytes, ctypes.c_void_p(ctx.stream)), "lia_blit")
-            return True
-        return False                     # an odd batch: 8 B short of a 16-byte multiple; the caller falls back to Tensor.cpu()
-
-    def read(self, n):
-        buf = (ctypes.c_char * (8 * n)).from_address(self.ptr)
-        return torch.frombuffer(buf, dtype=torch.int64).clone()
-
-
 class KVState:
     """Per-layer KV caches of one generation: seq-major [Smax,B,h,d] (attentions.py:462-476), in HBM for
     resident layers and in pinned host memory for streamed ones (lia/modeling_opt.py:1270-1281)."""
@@ -426,8 +400,6 @@ class OffloadScheduler:
         # holding caches are shared by all generations of this scheduler, so a new prefill may only write them once ALL of these
         # have landed (a generation that ended at its prefill, a second live KVState, a KVState reused with len reset)
         self._outstanding = {}
-        self._ids_mirror = IdsMirror()
-        self.last_ids_host = None   # the last forward's argmax ids on the host (None: read them with Tensor.cpu())
         self._coop = None           # CoopController of the cooperative split (cpu_layers=-1), kept across generations
         self._coop_key = None
         self.kv_delivery = {"bytes": 0, "device_ms": None, "host_wait_ms": 0.0}   # of the last deferred delivery
@@ -602,7 +574,6 @@ class OffloadScheduler:
             logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
             ctx.synchronize()
             kv_state.len = pos0 + T
-            self.last_ids_host = None
             return logits, nxt
         def next_streamed(i, wrapped):
             """the streamed layer after i that needs a slot: decode forwards skip the host-computed layers"""
@@ -676,8 +647,6 @@ class OffloadScheduler:
                 ctx.synchronize()
 
         logits, nxt = ctx.lm_head(x if xlast is None else xlast, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
-        mirrored = self._ids_mirror.capture(ctx, nxt)
-        self.last_ids_host = None
         if hold is not None:
             # the deferred deliveries, in the order the first decode step will need them; tickets are awaited per layer there
             import time
@@ -700,8 +669,6 @@ class OffloadScheduler:
             if policy == 0 or (is_prefill and cpu_set):
                 ctx.kv_store_wait()                                # host cache complete before the next step reads it
         kv_state.len = pos0 + T
-        if mirrored:
-            self.last_ids_host = self._ids_mirror.read(B)         # (every path above ended with a synchronize of the compute stream)
         if t_fwd0 is not None:
             import time
             step_ms = 1e3 * (time.time() - t_fwd0)
