@@ -54,6 +54,16 @@ def make_layer(seed, H, F, w_std=0.02):
         elif name.endswith("_b"):
             t = 0.05 * rs.standard_normal(shape)
         else:
+            n = int(np.prod(shape))
+            if n > (1 << 22):
+                # big matrices (the full-size fixtures: 616 M values per OPT-30B layer) in chunks -- the SAME stream of normals
+                # (RandomState.standard_normal is sequential), without multi-GB float64 temporaries
+                bits = np.empty(n, np.uint16)
+                for o in range(0, n, 1 << 22):
+                    m = min(1 << 22, n - o)
+                    bits[o:o + m] = f32_to_bf16_bits((w_std * rs.standard_normal(m)).astype(np.float32))
+                out[name] = bits.reshape(shape)
+                continue
             t = w_std * rs.standard_normal(shape)
         out[name] = f32_to_bf16_bits(t.astype(np.float32))
     return out
