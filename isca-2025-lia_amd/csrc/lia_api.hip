@@ -30,9 +30,6 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
 extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
                                       int B, int S, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
                                       hipStream_t st);
-extern "C" int lia_attn_decode_fused_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
-                                            int B, int S, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
-                                            const LiaQkvFuse* fuse, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -456,11 +453,9 @@ extern "C" int lia_linear(lia_ctx* ctx, const lia_bf16* x, long ldx, const lia_b
   return gemm_checked(ctx, x, ldx, w, M, N, K, ep, om, (float*)ctx->ws, have, split_k, (hipStream_t)stream);
 }
 
-// deferred_split (nullable): the caller's attention kernel can finish the projection itself (decode, device cache); when the GEMM is
-// split over K no combine is launched and *deferred_split = the number of slabs in `ws` (0: q / k / v were written as usual)
 static int qkv_project(lia_ctx* ctx, const bf16_t* x, const bf16_t* w, const bf16_t* bias, bf16_t* qout, bf16_t* kdst,
                        bf16_t* vdst, bool kv_cache_mode, int B, int T, int H, int cache_batch, int b0, int pos0,
-                       float* ws, size_t ws_bytes, hipStream_t st, int* deferred_split = nullptr) {
+                       float* ws, size_t ws_bytes, hipStream_t st) {
   LiaEpilogue ep{bias, nullptr, 0, 0};
   LiaOutMap om;
   memset(&om, 0, sizeof(om));
@@ -468,15 +463,6 @@ static int qkv_project(lia_ctx* ctx, const bf16_t* x, const bf16_t* w, const bf1
   om.ld[0] = om.ld[1] = om.ld[2] = H;
   om.cache_mode[1] = om.cache_mode[2] = kv_cache_mode ? 1 : 0;
   om.seg_n = H; om.T = T; om.Bc = cache_batch; om.b0 = b0; om.pos0 = pos0;
-  if (deferred_split) {
-    *deferred_split = 0;
-    LiaPost post{};
-    post.defer = 1;
-    int done = 0;
-    int rc = gemm_checked(ctx, x, H, w, B * T, 3 * H, H, ep, om, ws, ws_bytes, 0, st, &post, &done);
-    if (rc == 0 && done >= 100) *deferred_split = done - 100;
-    return rc;
-  }
   return gemm_checked(ctx, x, H, w, B * T, 3 * H, H, ep, om, ws, ws_bytes, 0, st);
 }
 
@@ -650,10 +636,8 @@ static int layer_forward_impl(lia_ctx* ctx, const lia_layer_desc* d, int policy,
   }
 
   // q | k | v projection (attentions.py:393-394, 418)
-  int qkv_slabs = 0;      // > 0: the decode attention kernel finishes the projection out of this many split-K slabs (r03)
   if (fused_qkv) {
-    rc = qkv_project(ctx, ln, W[2], W[3], qb, kdst, vdst, cache_mode, B, T, H, dst_batch, dst_b0, dst_pos0, gws, w.gemm_bytes, st,
-                     (policy == 3 && T == 1) ? &qkv_slabs : nullptr);
+    rc = qkv_project(ctx, ln, W[2], W[3], qb, kdst, vdst, cache_mode, B, T, H, dst_batch, dst_b0, dst_pos0, gws, w.gemm_bytes, st);
     if (rc) return rc;
   } else {
     for (int i = 0; i < 3; ++i) {
@@ -688,11 +672,7 @@ static int layer_forward_impl(lia_ctx* ctx, const lia_layer_desc* d, int policy,
   } else {
     // GPU attention (attentions.py:443-536)
     // (tail: the last query of a causal block attends every key -- one decode-style query per row over the S rows just written)
-    LiaQkvFuse fz;
-    memset(&fz, 0, sizeof(fz));
-    if (qkv_slabs > 0) { fz.partial = gws; fz.split = qkv_slabs; fz.M = (int)M; fz.N = 3 * H; fz.bias = W[3]; fz.hq = H; fz.kd = H; }
-    int arc = (T == 1 || tail) ? lia_attn_decode_fused_launch(qb + tail_off, tail_ld, kdst, vdst, ao, H, B, (int)S, d->heads, d->heads, hd, dst_batch, dst_b0, 0,
-                                                              qkv_slabs > 0 ? &fz : nullptr, st)
+    int arc = (T == 1 || tail) ? lia_attn_decode_launch(qb + tail_off, tail_ld, kdst, vdst, ao, H, B, (int)S, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st)
                                : lia_attn_prefill_launch(qb, H, kdst, vdst, ao, H, B, T, d->heads, d->heads, hd, dst_batch, dst_b0, 0, st);
     if (arc) { lia_set_error("attention: unsupported head_dim %d / S %zu", hd, S); return LIA_ERR_INVALID; }
     if (policy == 0) {
@@ -860,7 +840,7 @@ static int llama_layer_forward_impl(lia_ctx* ctx, const lia_llama_desc* d, const
   // are G segments of the k / v width, the k and v segments scatter into the seq-major cache; in decode the rotation of the q and
   // k heads rides in the split-K combine
   const bool fused_qkv = fused_kv && W[2] == W[1] + (size_t)H * H && G + 2 <= LIA_OUT_SEGS;
-  int rope_done = 0, qkv_slabs = 0;
+  int rope_done = 0;
   if (fused_qkv) {
     LiaOutMap om;
     memset(&om, 0, sizeof(om));
@@ -870,10 +850,8 @@ static int llama_layer_forward_impl(lia_ctx* ctx, const lia_llama_desc* d, const
     LiaPost post{};
     post.kind = LIA_POST_ROPE; post.cos_t = cos_table; post.sin_t = sin_table; post.rot_heads = d->heads + d->kv_heads; post.hd = hd;
     post.pos0 = pos0; post.T = T;
-    post.defer = T == 1;            // decode: the attention kernel combines, rotates and scatters its own slice (LiaQkvFuse)
     rc = gemm_checked(ctx, ln, H, W[1], (int)M, H + 2 * KD, H, none, om, gws, w.gemm_bytes, 0, st, &post, &rope_done);
     if (rc) return rc;
-    if (rope_done >= 100) { qkv_slabs = rope_done - 100; rope_done = 1; }
   } else {  // q projection
     LiaOutMap om = plain_out(qb, H, H);
     rc = gemm_checked(ctx, ln, H, W[1], (int)M, H, H, none, om, gws, w.gemm_bytes, 0, st);
@@ -899,13 +877,7 @@ static int llama_layer_forward_impl(lia_ctx* ctx, const lia_llama_desc* d, const
                         kv->batch + B, st);
     }
   }
-  LiaQkvFuse fz;
-  memset(&fz, 0, sizeof(fz));
-  if (qkv_slabs > 0) {
-    fz.partial = gws; fz.split = qkv_slabs; fz.M = (int)M; fz.N = H + 2 * KD; fz.cos_t = cos_table; fz.sin_t = sin_table; fz.hq = H; fz.kd = KD;
-  }
-  int arc = (T == 1 || tail) ? lia_attn_decode_fused_launch(qb + tail_off, tail_ld, kv->k, kv->v, ao, H, B, pos0 + T, d->heads, d->kv_heads, hd, kv->batch, b0, 1,
-                                                            qkv_slabs > 0 ? &fz : nullptr, st)
+  int arc = (T == 1 || tail) ? lia_attn_decode_launch(qb + tail_off, tail_ld, kv->k, kv->v, ao, H, B, pos0 + T, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st)
                              : lia_attn_prefill_launch(qb, H, kv->k, kv->v, ao, H, B, T, d->heads, d->kv_heads, hd, kv->batch, b0, 1, st);
   if (arc) { lia_set_error("llama attention: unsupported head_dim %d / S %d", hd, pos0 + T); return LIA_ERR_INVALID; }
   int norm2_done = 0, silu_done = 0;

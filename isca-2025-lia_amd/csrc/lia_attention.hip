@@ -15,7 +15,6 @@
 // resident layers (device cache) and the streamed prefill (staging slab that is then copied to the
 // host cache).
 #include <cstdlib>
-#include <string.h>
 #include "lia_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -472,7 +471,7 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
                                                                const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
                                                                long ldo, int S, int heads, int kv_heads, int Bc, int b0,
-                                                               float scaling, int post_scale, LiaQkvFuse fz) {
+                                                               float scaling, int post_scale) {
   constexpr int LPK = D / 8;          // lanes per key
   constexpr int KPP = 256 / LPK;      // keys per pass of the workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -488,47 +487,6 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   const float qscale = post_scale ? 1.0f : scaling;
   const int sub = tid % LPK, kslot = tid / LPK;
 
-  // r03: finish the q | k | v projection here (LiaQkvFuse): this workgroup's (G + 2) * D columns of row b out of the split-K
-  // slabs, bias, RoPE at position S - 1; q stays in LDS, the new K / V row goes to the cache, then everything is as before.
-  bf16_t* qs = (bf16_t*)(scratch + (size_t)G * 8);              // [G][D], used only when fused
-  if (fz.partial != nullptr) {
-    const LiaEpilogue ep{fz.bias, nullptr, 0, 0, 0};
-    const int pos = S - 1;
-    bf16_t* knew = const_cast<bf16_t*>(kbase) + (long)pos * kv_row;
-    bf16_t* vnew = const_cast<bf16_t*>(vbase) + (long)pos * kv_row;
-    if (fz.cos_t != nullptr) {
-      constexpr int GPH = D / 8;                                  // groups of 4 (i, i + D/2) pairs per head
-      if (tid < (G + 1) * GPH) {
-        const int hs = tid / GPH, gi = tid % GPH;               // head slot: 0..G-1 the query heads of the group, G the key head
-        const int n0 = (hs < G ? (kh * G + hs) * D : fz.hq + kh * D) + 4 * gi, n1 = n0 + D / 2;
-        const f32x4 a = epilogue_quad(splitk_sum(fz.partial, fz.split, fz.M, fz.N, b, n0), b, n0, ep);
-        const f32x4 c = epilogue_quad(splitk_sum(fz.partial, fz.split, fz.M, fz.N, b, n1), b, n1, ep);
-        const uint2 oa{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])}, ob{pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3])};
-        const uint2 c0 = *(const uint2*)(fz.cos_t + (long)pos * D + 4 * gi), c1 = *(const uint2*)(fz.cos_t + (long)pos * D + D / 2 + 4 * gi);
-        const uint2 s0 = *(const uint2*)(fz.sin_t + (long)pos * D + 4 * gi), s1 = *(const uint2*)(fz.sin_t + (long)pos * D + D / 2 + 4 * gi);
-        uint2 ra, rb;
-        lia_rope_pair(oa.x, ob.x, c0.x, c1.x, s0.x, s1.x, ra.x, rb.x);
-        lia_rope_pair(oa.y, ob.y, c0.y, c1.y, s0.y, s1.y, ra.y, rb.y);
-        bf16_t* dst = hs < G ? qs + hs * D : knew;
-        *(uint2*)(dst + 4 * gi) = ra;
-        *(uint2*)(dst + D / 2 + 4 * gi) = rb;
-      } else if (tid < (G + 1) * GPH + D / 4) {
-        const int vq = tid - (G + 1) * GPH, n = fz.hq + fz.kd + kh * D + 4 * vq;
-        const f32x4 a = epilogue_quad(splitk_sum(fz.partial, fz.split, fz.M, fz.N, b, n), b, n, ep);
-        *(uint2*)(vnew + 4 * vq) = uint2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
-      }
-    } else {
-      for (int u = tid; u < (G + 2) * (D / 4); u += 256) {
-        const int hs = u / (D / 4), qd = u % (D / 4);
-        const int n = (hs < G ? (kh * G + hs) * D : (hs == G ? fz.hq + kh * D : fz.hq + fz.kd + kh * D)) + 4 * qd;
-        const f32x4 a = epilogue_quad(splitk_sum(fz.partial, fz.split, fz.M, fz.N, b, n), b, n, ep);
-        bf16_t* dst = hs < G ? qs + hs * D : (hs == G ? knew : vnew);
-        *(uint2*)(dst + 4 * qd) = uint2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
-      }
-    }
-    __syncthreads();            // (drains the cache-row stores too: the key / value loops below read row S - 1 from memory)
-  }
-
   // the (scaled, bf16-rounded) query slice of each head of the group as packed bf16 pairs: q . k runs on v_dot2c_f32_bf16,
   // two products per instruction and no unpacking of the key (the products of two bf16 are exact in fp32 either way; the
   // sum is rounded to bf16 right after): Llama-3-8B's grouped decode attention 119.6 -> 114.5 us per layer.  (Requesting
@@ -537,8 +495,7 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   uint32_t qp[G][4];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const uint4 v = fz.partial != nullptr ? *(const uint4*)(qs + g * D + 8 * sub)
-                                          : *(const uint4*)(q + (long)b * ldq + (long)(kh * G + g) * D + 8 * sub);
+    uint4 v = *(const uint4*)(q + (long)b * ldq + (long)(kh * G + g) * D + 8 * sub);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) qp[g][j] = pack_bf16x2(bf2f(w[j] & 0xffff) * qscale, bf2f(w[j] >> 16) * qscale);
@@ -693,19 +650,19 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
 
 template <int D>
 static int launch_decode(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo, int B, int S, int heads,
-                         int kv_heads, int Bc, int b0, float scaling, int post_scale, const LiaQkvFuse& fz, hipStream_t st) {
+                         int kv_heads, int Bc, int b0, float scaling, int post_scale, hipStream_t st) {
   const int G = heads / kv_heads;
   dim3 grid(kv_heads, B);
   const int kpp = 256 / (D / 8);
   const int Spad = (S + 3) & ~3;
   (void)kpp;
-  size_t lds = ((size_t)G * Spad + (size_t)4 * G * D + (size_t)G * 8) * sizeof(float) + (size_t)G * D * sizeof(bf16_t);   // + the fused q
+  size_t lds = ((size_t)G * Spad + (size_t)4 * G * D + (size_t)G * 8) * sizeof(float);
   if (lds > 160 * 1024) return -1;
 #define LIA_DEC(GV)                                                                                                            \
   {                                                                                                                            \
     static bool attr = false;                                                                                                  \
     if (!attr) { (void)hipFuncSetAttribute((const void*)lia_attn_decode_kernel<D, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-    hipLaunchKernelGGL((lia_attn_decode_kernel<D, GV>), grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale, fz); \
+    hipLaunchKernelGGL((lia_attn_decode_kernel<D, GV>), grid, dim3(256), lds, st, q, ldq, kc, vc, out, ldo, S, heads, kv_heads, Bc, b0, scaling, post_scale); \
   }
   switch (G) {
     case 1: LIA_DEC(1) break;
@@ -718,27 +675,16 @@ static int launch_decode(const bf16_t* q, long ldq, const bf16_t* kc, const bf16
   return 0;
 }
 
-// fuse (nullable): the q | k | v projection's split-K slabs -- the kernel then finishes the projection for its own slice
-// (LiaQkvFuse, lia_common.h) and q / the cache row S - 1 need not have been written
-extern "C" int lia_attn_decode_fused_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
-                                            int B, int S, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
-                                            const LiaQkvFuse* fuse, hipStream_t st) {
-  if (B <= 0 || S <= 0) return 0;
-  if (kv_heads <= 0 || heads % kv_heads) return -1;
-  const float scaling = 1.0f / sqrtf((float)d);
-  LiaQkvFuse fz;
-  memset(&fz, 0, sizeof(fz));
-  if (fuse) fz = *fuse;
-  switch (d) {
-    case 128: return launch_decode<128>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, fz, st);
-    case 64: return launch_decode<64>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, fz, st);
-    case 32: return launch_decode<32>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, fz, st);
-    default: return -1;
-  }
-}
-
 extern "C" int lia_attn_decode_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
                                       int B, int S, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
                                       hipStream_t st) {
-  return lia_attn_decode_fused_launch(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, d, Bc, b0, post_scale, nullptr, st);
+  if (B <= 0 || S <= 0) return 0;
+  if (kv_heads <= 0 || heads % kv_heads) return -1;
+  const float scaling = 1.0f / sqrtf((float)d);
+  switch (d) {
+    case 128: return launch_decode<128>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, st);
+    case 64: return launch_decode<64>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, st);
+    case 32: return launch_decode<32>(q, ldq, kc, vc, out, ldo, B, S, heads, kv_heads, Bc, b0, scaling, post_scale, st);
+    default: return -1;
+  }
 }

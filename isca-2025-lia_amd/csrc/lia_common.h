@@ -59,29 +59,6 @@ __device__ __forceinline__ float lia_epilogue_apply(float acc, float bias, bool 
   return t;
 }
 
-// the four finished values (every reference rounding point applied: they are bf16-representable)
-__device__ __forceinline__ f32x4 epilogue_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep) {
-  float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
-  if (hb) {
-    uint2 bb = *(const uint2*)(ep.bias + n);
-    b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
-  }
-  if (hr) {
-    uint2 rr = *(const uint2*)(ep.residual + (long)m * ep.ldr + n);
-    r[0] = bf2f(rr.x & 0xffff); r[1] = bf2f(rr.x >> 16); r[2] = bf2f(rr.y & 0xffff); r[3] = bf2f(rr.y >> 16);
-  }
-  return f32x4{lia_epilogue_apply(v[0], b[0], hb, ep.relu, r[0], hr), lia_epilogue_apply(v[1], b[1], hb, ep.relu, r[1], hr),
-               lia_epilogue_apply(v[2], b[2], hb, ep.relu, r[2], hr), lia_epilogue_apply(v[3], b[3], hb, ep.relu, r[3], hr)};
-}
-
-// the fp32 split-K partial slabs [S][M][N] of one output quad, added slice 0, 1, ... (the order of every combine)
-__device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ partial, int S, int M, int N, int m, int n) {
-  f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
-  for (int s = 1; s < S; ++s) a += *(const f32x4*)(partial + ((long)s * M + m) * N + n);     // slice 0, 1, ...: the order of the plain combine
-  return a;
-}
-
 // Where a GEMM output row lands.  Up to LIA_OUT_SEGS equal-width column segments (fused q|k|v projection),
 // each with its own base / leading dimension; a segment in "cache" mode scatters token row
 // m = b*T + t to the seq-major KV-cache row (pos0 + t)*Bc + b0 + b  (attentions.py:457-458,475-476,
@@ -128,23 +105,6 @@ struct LiaPost {
   const bf16_t* cos_t;
   const bf16_t* sin_t;
   int rot_heads, hd, pos0, T;
-  // defer = 1 (a decode q | k | v projection, T == 1): when the GEMM is split over K, launch NO combine -- the decode attention
-  // kernel combines the slabs of its own (row, KV head) slice in its prologue (LiaQkvFuse) -- and report 100 + slices in *post_done
-  int defer;
-};
-
-// What the decode attention kernel needs to finish the q | k | v projection itself (r03): the split-K slabs of the projection,
-// its bias, and (Llama) the RoPE tables.  Workgroup (row b, KV head kh) combines the G query heads of its group, its K head and
-// its V head -- (G + 2) * D of the row's N columns --, rotates, keeps q in LDS and writes the new K / V row of the cache, with
-// the device functions of the stand-alone combines (splitk_sum, epilogue_quad, lia_rope_pair): same bits, one launch fewer.
-struct LiaQkvFuse {
-  const float* partial;   // [split][M][N] fp32; NULL = q and the cache row are already finished (the plain kernel)
-  int split, M, N;
-  const bf16_t* bias;     // [N] or NULL
-  const bf16_t* cos_t;    // [pos][D] or NULL (no rotation: OPT)
-  const bf16_t* sin_t;
-  int hq;                 // columns of the q block (heads * D): k starts there, v at hq + kd
-  int kd;                 // columns of the k (and v) block (kv_heads * D)
 };
 
 // sum over the LIA_ROW_THREADS threads of a workgroup, the same value in every thread (red: LIA_ROW_WAVES floats of LDS, used

@@ -24,6 +24,22 @@
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: 4 consecutive columns n..n+3 of row m
 // ---------------------------------------------------------------------------------------------
+// the four finished values (every reference rounding point applied: they are bf16-representable)
+__device__ __forceinline__ f32x4 epilogue_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep) {
+  float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+  if (hb) {
+    uint2 bb = *(const uint2*)(ep.bias + n);
+    b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
+  }
+  if (hr) {
+    uint2 rr = *(const uint2*)(ep.residual + (long)m * ep.ldr + n);
+    r[0] = bf2f(rr.x & 0xffff); r[1] = bf2f(rr.x >> 16); r[2] = bf2f(rr.y & 0xffff); r[3] = bf2f(rr.y >> 16);
+  }
+  return f32x4{lia_epilogue_apply(v[0], b[0], hb, ep.relu, r[0], hr), lia_epilogue_apply(v[1], b[1], hb, ep.relu, r[1], hr),
+               lia_epilogue_apply(v[2], b[2], hb, ep.relu, r[2], hr), lia_epilogue_apply(v[3], b[3], hb, ep.relu, r[3], hr)};
+}
+
 __device__ __forceinline__ void store_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep, const LiaOutMap& om) {
   float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
   const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
@@ -59,6 +75,12 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __r
     a += b;
   }
   store_quad(a, m, n, ep, om);
+}
+
+__device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ partial, int S, int M, int N, int m, int n) {
+  f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
+  for (int s = 1; s < S; ++s) a += *(const f32x4*)(partial + ((long)s * M + m) * N + n);     // slice 0, 1, ...: the order of the plain combine
+  return a;
 }
 
 // ---- split-K combines that also do the next op of the decode layer (LiaPost, lia_common.h) ----
@@ -1308,8 +1330,6 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     if (split > 1 && tk == nullptr) {
-      // a decode q | k | v projection whose consumer (the decode attention kernel) combines the slabs itself: no launch here
-      if (post && post_done && post->defer && g_fuse_combine) { *post_done = 100 + split; ++g_fused_combines[0]; return 0; }
       if (post && post_done && launch_fused_combine(workspace, split, M, N, *ep, *om, *post, st)) { *post_done = 1; return 0; }
       long nq = (long)M * (N / 4);
       hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace,
