@@ -245,7 +245,7 @@ def first_divergence(ids_a, ids_b, T, logits_b=None):
 
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass of this same command
-    (profiles/r02_opt30b_bench_pmc_hbm.json, tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).
+    (the newest profiles/r*_opt30b_bench_pmc_hbm.json, tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 fetch correction).
     PMC collection cannot run inside the timed benchmark, so the live line carries the committed measurement and names it."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_opt30b_pmc_hbm.json")) +
