@@ -62,7 +62,7 @@ def build_parser():
     ap.add_argument("--no-raw-leg", action="store_true", help="skip the second, shorter leg with raw bf16 on the wire")
     ap.add_argument("--raw-steps", type=int, default=6)
     ap.add_argument("--no-cooperative-leg", action="store_true", help="skip the build-defined cooperative-split leg (value_cooperative)")
-    ap.add_argument("--coop-steps", type=int, default=16, help="decode steps of the cooperative leg (the controller settles in the first half)")
+    ap.add_argument("--coop-steps", type=int, default=28, help="decode steps of the cooperative leg (the controller's search takes 12-20; value_cooperative = the last 8)")
     ap.add_argument("--no-dp-extra-legs", action="store_true", help="N > 1: skip the KV-in-HBM and all-gather legs")
     ap.add_argument("--dp-extra-steps", type=int, default=6)
     ap.add_argument("--dp-extra-timeout", type=int, default=420, help="seconds the extra legs may take before the run ends with the headline line only")
@@ -584,7 +584,7 @@ def main(argv=None):
                                                         wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]))
             coop_kwargs = dict(gen_kwargs, cpu_layers=-1, cpu_layers_start=c0)      # -1: the scheduler's online controller, seeded by the plan
             ids_coop, lat_coop, logits_coop = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **coop_kwargs)
-            tail = lat_coop[-max(1, a.coop_steps // 2):]                             # after the controller has settled
+            tail = lat_coop[-max(1, min(8, a.coop_steps // 2)):]                     # after the controller's search
             out["value_cooperative"] = B / (sum(tail) / len(tail))
             out["cooperative_leg"] = {"planned_host_layers": c0, "controller": sched.coop_report(), "decode_steps": len(lat_coop) - 1,
                                       "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail), "leg_s": time.time() - t0,

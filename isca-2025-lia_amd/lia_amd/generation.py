@@ -78,13 +78,14 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
     else:
         # caches sized [T+new, B, h, d] like modeling_opt.py:1277-1278; in HBM for every layer when both policies are 3
         on_dev = lia["prefill_policy"] == 3 and lia["decoding_policy"] == 3
-        host_layers = ()
+        host_layers, dual_layers = (), ()
         if on_dev and lia.get("cpu_layers", 0) > 0:
             host_layers = OffloadScheduler.cpu_layer_set(n_gpu, L, lia["cpu_layers"])
         elif on_dev and lia.get("cpu_layers", 0) < 0 and getattr(sched, "dp", None) is None and n_gpu < L - 1:
-            # online count: every CANDIDATE host layer keeps its cache on the host (the GPU serves it with policy 2 when it is not chosen)
-            host_layers = sched._coop_controller(n_gpu, L, B, T, max_new_tokens, lia["gpu_percentage"], 3, lia.get("cpu_layers_start")).superset()
-        kv = KVState(model, n_gpu, B, T + max_new_tokens, all_on_device=on_dev, host_layers=host_layers)
+            # online count: every CANDIDATE host layer has a cache buffer on both sides; the cache lives where the layer is computed
+            coop = sched._coop_controller(n_gpu, L, B, T, max_new_tokens, lia["gpu_percentage"], 3, lia.get("cpu_layers_start"))
+            host_layers, dual_layers = coop.host_set(), coop.superset()
+        kv = KVState(model, n_gpu, B, T + max_new_tokens, all_on_device=on_dev, host_layers=host_layers, dual_layers=dual_layers)
     unfinished = torch.ones(B, dtype=torch.int64)
     all_unfinished = True
     latency_list, logits_list = [], []

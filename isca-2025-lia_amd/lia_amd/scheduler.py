@@ -256,39 +256,67 @@ class KVState:
     """Per-layer KV caches of one generation: seq-major [Smax,B,h,d] (attentions.py:462-476), in HBM for
     resident layers and in pinned host memory for streamed ones (lia/modeling_opt.py:1270-1281)."""
 
-    def __init__(self, model, n_gpu, B, smax, all_on_device=False, host_layers=()):
+    def __init__(self, model, n_gpu, B, smax, all_on_device=False, host_layers=(), dual_layers=()):
         """host_layers (with all_on_device): layers whose cache stays in pinned host memory all the same -- the layers the
-        cooperative split computes on the host cores (scheduler.forward cpu_layers)."""
+        cooperative split computes on the host cores (scheduler.forward cpu_layers).  dual_layers (with all_on_device): the
+        CANDIDATE host layers of the online split: a buffer in HBM and one in pinned host memory each, the cache living in one of
+        them at a time (host_layers says where it starts) and moved by `move_cache` when the controller changes the host set."""
         sh = model.shape
         self.B, self.smax, self.len = B, smax, 0
         self.pending = {}          # layer -> ticket of a deferred K/V delivery (scheduler.forward, lia_kv_deliver)
         self.all_on_device = all_on_device
         host_layers = frozenset(host_layers) if all_on_device else frozenset()
+        dual_layers = frozenset(dual_layers) if all_on_device else frozenset()
         if all_on_device:
             n_gpu = sh.layers          # policy 3 for streamed layers too: every cache lives in HBM
         from . import hostinfo
-        hostinfo.check_host_allocation(2 * (sh.layers - n_gpu + len(host_layers)) * smax * B * sh.hidden * 2, "host KV cache")
-        self.tensors, self.kv, self._pinned = [], [], []
+        hostinfo.check_host_allocation(2 * (sh.layers - n_gpu + len(host_layers | dual_layers)) * smax * B * sh.hidden * 2, "host KV cache")
+        self.tensors, self.kv, self._pinned, self.dual = [], [], [], {}
         shape = (smax, B, sh.heads, sh.head_dim)
         nbytes = 2 * smax * B * sh.heads * sh.head_dim
+
+        def device_pair():
+            k = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+            return k, torch.empty_like(k)
+
+        def host_pair():
+            pk, pv = PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes)
+            self._pinned += [(pk, nbytes), (pv, nbytes)]
+            return PinnedPool.as_tensor(pk, shape), PinnedPool.as_tensor(pv, shape)
+
         for i in range(sh.layers):
-            if i < n_gpu and i not in host_layers:
-                k = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
-                v = torch.empty_like(k)
-                on_dev = 1
+            on_dev = 1 if (i < n_gpu and i not in host_layers) else 0
+            if i in dual_layers:
+                self.dual[i] = {1: device_pair(), 0: host_pair()}
+                k, v = self.dual[i][on_dev]
             else:
-                pk, pv = PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes)
-                self._pinned += [(pk, nbytes), (pv, nbytes)]
-                k, v = PinnedPool.as_tensor(pk, shape), PinnedPool.as_tensor(pv, shape)
-                on_dev = 0
+                k, v = device_pair() if on_dev else host_pair()
             self.tensors.append((k, v))
             self.kv.append(N.KV(k.data_ptr(), v.data_ptr(), smax, B, on_dev))
+
+    def move_cache(self, lib, i, to_device):
+        """The cache of dual layer i changes sides: rows [0, len) (contiguous in the seq-major layout) copied over the host link,
+        `kv[i]` re-pointed.  Synchronous; the caller has synchronized the compute stream and awaited the layer's K/V delivery."""
+        to_device = 1 if to_device else 0
+        if i not in self.dual:
+            raise ValueError(f"layer {i} has one KV cache only (KVState(dual_layers=...) names the layers that can change sides)")
+        if self.kv[i].on_device == to_device:
+            return 0
+        nbytes = self.len * self.B * self.tensors[i][0].shape[2] * self.tensors[i][0].shape[3] * 2
+        dst = self.dual[i][to_device]
+        for s_t, d_t in zip(self.tensors[i], dst):
+            if nbytes:
+                fn = lib.lia_memcpy_h2d if to_device else lib.lia_memcpy_d2h
+                N.check(fn(ctypes.c_void_p(d_t.data_ptr()), ctypes.c_void_p(s_t.data_ptr()), ctypes.c_size_t(nbytes)), "lia_memcpy (KV cache move)")
+        self.tensors[i] = dst
+        self.kv[i] = N.KV(dst[0].data_ptr(), dst[1].data_ptr(), self.smax, self.B, to_device)
+        return 2 * nbytes
 
     def close(self):
         """Hand the pinned blocks back to the pool (the tensors over them must not be used afterwards)."""
         if self._pinned and torch.cuda.is_available():
             torch.cuda.synchronize()      # policy-0 K/V deliveries may still be landing in these blocks
-        self.tensors, self.kv = [], []
+        self.tensors, self.kv, self.dual = [], [], {}
         for ptr, nbytes in self._pinned:
             PinnedPool.release(ptr, nbytes)
         self._pinned = []
@@ -305,19 +333,29 @@ class CoopController:
 
     r02 picked the count once from a 4-second calibration (planner.plan_cpu_layers) and landed 129 ... 177 tok/s depending on
     which socket the GPU hangs off.  Here the count follows the MEASURED decode steps: the host set of size c is the first c
-    layers of a fixed nested order (`order`: farthest-point spread over the streamed layers, so every prefix is evenly
-    spread and raw host copies are kept for the first c_max only); a step is max(link time of the streamed layers, host +
-    GPU time), so the controller hill-climbs on the step time, exploring first in the direction the copy engine's idle share
-    points to (link >= 97 % busy: one more host layer shortens the link time; less: the host is the bottleneck, one fewer).
-    One settle step after every change (queued copies still reflect the old set), `measure` steps per setting (step times repeat
-    to 0.2 % on a quiet box, so one is enough)."""
+    layers of a fixed nested order (`order`, every prefix spread over the streamed layers, raw host copies kept for the first
+    c_max only).  A step is max(link time of the streamed layers, host + GPU time): roughly a V in c, but on a shared box the
+    bottom is flat to ~1 % with +10 % spikes on single steps, and the first version (a +-1 hill climb on the last sample) walked
+    away from the minimum on a spike and stalled two counts below it (results/r03_final2_*).  So this is a pattern search:
+    measure the centre, then centre +- stride for stride 4, 2, 1 -- first on the side the copy engine's idle share points to (link
+    >= 97 % busy: more host layers shorten the link time; less: the host is the bottleneck) -- moving the centre whenever a
+    candidate beats it by > 0.5 % and carrying on in that direction; a count's value is the MINIMUM of its last `keep` samples
+    (spikes only ever add time).  One settle step after every change (queued copies still reflect the old set).  Converged, it
+    stays on the centre -- single slow steps move nothing -- and searches again from stride 2 after `expire` steps or when the
+    centre's own recent steps are all > 5 % above the value it converged on (the box changed); every `probe_every` steps it
+    re-measures centre +- 1 (a spike on a candidate's single sample can end the search one or two counts off; the second look
+    costs five steps at a neighbouring count and repairs that)."""
 
-    def __init__(self, order, start, c_max, measure=1, expire=48):
+    STRIDES = (4, 2, 1)
+
+    def __init__(self, order, start, c_max, expire=96, keep=3, probe_every=16):
         self.order, self.c_max = list(order), min(int(c_max), len(order))
         self.c = max(0, min(int(start), self.c_max))
-        self.measure, self.expire = measure, expire
-        self.rec = {}                 # c -> [mean step ms, samples, step index of the last sample]
-        self.acc, self.settle, self.step, self.moves = [], 1, 0, 0
+        self.expire, self.keep, self.probe_every = expire, keep, probe_every
+        self.samples = {}             # c -> [(step, ms), ...] the last `keep`
+        self.centre, self.stride_i, self.pending, self.direction = self.c, 0, None, 0
+        self.converged_at, self.converged_ms, self.c_conv, self.last_probe, self.probing = None, None, None, 0, False
+        self.settle, self.step, self.moves, self.searches = 1, 0, 0, 1
         self.trace = []               # (step, c, ms, link busy share)
 
     def host_set(self, c=None):
@@ -326,6 +364,25 @@ class CoopController:
     def superset(self):
         return frozenset(self.order[:self.c_max])
 
+    def new_sequence(self):
+        """a new generation: its first decode step also waits for the prefill's K/V deliveries and loads layers on demand"""
+        self.settle = max(self.settle, 1)
+
+    def value(self, c):
+        v = [ms for st, ms in self.samples.get(c, ()) if self.step - st <= self.expire]
+        return min(v) if v else None
+
+    def _go(self, c):
+        if c != self.c:
+            self.c, self.settle, self.moves = c, 1, self.moves + 1
+        return self.c
+
+    def _candidates(self, busy, again=False):
+        s = self.STRIDES[self.stride_i]
+        side = (1, -1) if busy >= 0.97 else (-1, 1)
+        return [(self.centre + d * s, d) for d in side
+                if 0 <= self.centre + d * s <= self.c_max and (again or self.value(self.centre + d * s) is None)]
+
     def observe(self, step_ms, busy_share):
         """one finished decode step at the current c -> the c of the next step"""
         self.step += 1
@@ -333,43 +390,44 @@ class CoopController:
         if self.settle > 0:
             self.settle -= 1
             return self.c
-        self.acc.append((step_ms, busy_share))
-        if len(self.acc) < self.measure:
-            return self.c
-        ms = sum(a for a, _ in self.acc) / len(self.acc)
-        busy = sum(b for _, b in self.acc) / len(self.acc)
-        self.acc = []
-        self.rec[self.c] = [ms, self.measure, self.step]
-        for k in [k for k, v in self.rec.items() if self.step - v[2] > self.expire and k != self.c]:
-            del self.rec[k]           # old measurements age out: the box may have changed (another tenant, clocks)
-        # while the link is saturated (>= 99 % busy: the host side has slack) and the previous move up paid, climb two layers at a time
-        prev = getattr(self, "_prev", None)
-        want = None
-        if prev is not None and prev[0] in self.rec and self.c > prev[0] and busy >= 0.99 and ms < 0.995 * self.rec[prev[0]][0]:
-            cand = self.c + 2
-            if cand <= self.c_max and cand not in self.rec and (self.c + 1) not in self.rec:
-                want = cand
-        up, down = self.c + 1, self.c - 1
-        first, second = (up, down) if busy >= 0.97 else (down, up)
-        if want is None:
-            for cand in (first, second):
-                if 0 <= cand <= self.c_max and cand not in self.rec:
-                    # explore the side the link points to; the other side only when this setting is not already the better one
-                    if cand == first or (first in self.rec and self.rec[first][0] >= ms):
-                        want = cand
-                        break
-        if want is None:
-            near = [k for k in self.rec if abs(k - self.c) <= 2]
-            best = min(near, key=lambda k: self.rec[k][0])
-            want = best if self.rec[best][0] < 0.995 * ms else self.c        # hysteresis: move only for > 0.5 %
-        self._prev = (self.c, ms)
-        if want != self.c:
-            self.c, self.settle, self.moves = want, 1, self.moves + 1
-        return self.c
+        self.samples[self.c] = (self.samples.get(self.c, []) + [(self.step, step_ms)])[-self.keep:]
+        if self.converged_at is not None and not self.probing:
+            recent = [ms for _, ms in self.samples[self.c]]
+            drifted = len(recent) >= self.keep and min(recent) > 1.05 * self.converged_ms
+            if self.step - self.converged_at >= self.expire or drifted:
+                # search again around where we are: everything measured before is stale
+                self.samples = {self.c: self.samples[self.c][-1:]}
+                self.centre, self.stride_i, self.pending, self.direction = self.c, 1, None, 0
+                self.converged_at, self.searches = None, self.searches + 1
+            elif self.step - self.last_probe >= self.probe_every:
+                self.stride_i, self.probing = len(self.STRIDES) - 1, True
+                self.pending = self._candidates(busy_share, again=True)
+            else:
+                return self.c
+        if self.pending is None:                                  # the centre has just been measured: open this stride
+            self.pending = self._candidates(busy_share)
+        elif self.c != self.centre:                               # a candidate has just been measured
+            if self.value(self.c) < 0.995 * self.value(self.centre):
+                d, s = self.direction, self.STRIDES[self.stride_i]
+                self.centre = self.c
+                nxt = self.centre + d * s                         # it paid: carry on the same way before looking back
+                self.pending = [(nxt, d)] if 0 <= nxt <= self.c_max and self.value(nxt) is None else []
+        while not self.pending:
+            if self.stride_i + 1 >= len(self.STRIDES):
+                if self.converged_at is None or self.centre != self.c_conv:
+                    self.converged_at, self.converged_ms, self.c_conv = self.step, self.value(self.centre), self.centre
+                self.last_probe, self.probing = self.step, False
+                return self._go(self.centre)
+            self.stride_i += 1
+            self.pending = self._candidates(busy_share)
+        cand, self.direction = self.pending.pop(0)
+        return self._go(cand)
 
     def report(self):
-        return {"host_layers": self.c, "max_host_layers": self.c_max, "moves": self.moves, "steps_observed": self.step,
-                "ms_by_count": {str(k): round(v[0], 2) for k, v in sorted(self.rec.items())}, "trace_tail": self.trace[-12:]}
+        return {"host_layers": self.c, "centre": self.centre, "converged": self.converged_at is not None, "max_host_layers": self.c_max,
+                "moves": self.moves, "searches": self.searches, "steps_observed": self.step,
+                "ms_by_count": {str(k): round(self.value(k), 2) for k in sorted(self.samples) if self.value(k) is not None},
+                "trace_tail": self.trace[-12:]}
 
 
 class OffloadScheduler:
@@ -528,9 +586,17 @@ class OffloadScheduler:
             cpu_set = coop.superset()                                # layers that keep a raw host copy (and a host KV cache)
         else:
             cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and cpu_layers > 0 and decoding_policy in (2, 3) and self.dp is None) else frozenset()
-        if cpu_set and decoding_policy == 3 and any(kv_state.kv[i].on_device for i in cpu_set):
-            raise ValueError("cpu_layers with the KV cache in HBM: the host-computed layers need a host cache "
-                             "(KVState(..., all_on_device=True, host_layers=OffloadScheduler.cpu_layer_set(...)))")
+        if cpu_set and decoding_policy == 3:
+            # the host-computed layers need their cache on the host; with the online count a candidate's cache follows the host set
+            need_host = coop.host_set() if coop is not None else cpu_set
+            fixed = [i for i in need_host if i not in getattr(kv_state, "dual", {}) and kv_state.kv[i].on_device]
+            if fixed:
+                raise ValueError("cpu_layers with the KV cache in HBM: the host-computed layers need a host cache "
+                                 "(KVState(..., all_on_device=True, host_layers=OffloadScheduler.cpu_layer_set(...)), "
+                                 f"dual_layers=... for the online count); layers {fixed[:4]}")
+            if is_prefill and kv_state.len == 0:
+                for i in getattr(kv_state, "dual", {}):                  # an empty cache changes sides for free
+                    kv_state.move_cache(N.lib(), i, to_device=(i not in need_host))
         shard = (self.dp.rank, self.dp.world) if (self.dp is not None and self.dp.world > 1 and self.dp.mode == "allgather") else None
         wire = self.pack12 if (prefill_policy != 1 and decoding_policy != 1) else 0
         if m.placed_for != m._place_key(n_gpu, pin_weight, enable_cxl, wire, cpu_set, shard):
@@ -542,9 +608,7 @@ class OffloadScheduler:
             self.resident_ptrs.clear()
         m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=cpu_set, shard=shard)
         if coop is not None and is_prefill:
-            # a new generation: its first decode step also waits for the prefill's K/V deliveries and loads layers on demand --
-            # not a sample of the steady state
-            coop.settle, coop.acc = max(coop.settle, 1), []
+            coop.new_sequence()                                      # the first decode step is not a sample of the steady state
         host_act = coop.host_set() if coop is not None else cpu_set   # the layers whose DECODE step runs on the host cores
         host_now = host_act if not is_prefill else frozenset()    # layers this forward computes on the host
         t_fwd0 = None
@@ -625,10 +689,10 @@ class OffloadScheduler:
                 # (build-defined; the reference reserves 3 for resident layers, :1175-1176)
                 # a host-computed layer keeps its cache on the host: its prefill delivers K/V there (policy 0) even when the
                 # other streamed layers keep theirs in HBM (policy 3)
-                pol = 0 if (policy == 3 and idx in cpu_set) else policy
                 kvl = kv_state.kv[idx]
+                pol = 0 if (policy == 3 and not kvl.on_device) else policy
                 if pol == 0 and not is_prefill and policy == 3:
-                    pol = 2            # a candidate host layer that the GPU computes this step: its cache lives on the host
+                    pol = 2            # a host layer of the split that the GPU computes this step: its cache lives on the host
                 if hold is not None and pol == 0:
                     pol, kvl = 3, hold[idx - n_gpu][2]             # same arithmetic, rows land in the HBM holding cache
                 if tail_last and idx == L - 1:
@@ -675,8 +739,14 @@ class OffloadScheduler:
             busy = (self.pipe.poll_stats()[1] - busy0) / max(step_ms, 1e-6) if self.pipe else 0.0
             before = coop.host_set()
             coop.observe(step_ms, min(busy, 1.0))
-            for li in coop.host_set() - before:                   # newly host-computed: a queued copy of it will never be used
+            after = coop.host_set()
+            for li in after - before:                             # newly host-computed: a queued copy of it will never be used
                 pipe.forget(li)
+            if decoding_policy == 3 and after != before:
+                # KV in HBM: the cache of a layer that changes sides follows it (0.5 GB per layer at the headline shape, ~10 ms)
+                for li in sorted(after ^ before):
+                    self._await_kv(kv_state, li)
+                    self.kv_moved_bytes = getattr(self, "kv_moved_bytes", 0) + kv_state.move_cache(ctx.lib, li, to_device=(li not in after))
         return logits, nxt
 
     def _coop_controller(self, n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, start):

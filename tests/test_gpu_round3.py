@@ -160,8 +160,8 @@ def test_online_cooperative_split_changes_host_set_mid_generation(fmt, pol, monk
     """cpu_layers = -1: the scheduler's CoopController moves the number of host-computed decode layers BETWEEN decode steps.  The
     controller is scripted here to jump around (3 -> 1 -> 2 -> 0 -> 3 ...), which exercises every transition the real one can
     make: layers leaving the host set are streamed again (on demand, then prefetched), layers entering it have their queued
-    copies forgotten; with the cache in HBM (3/3) a candidate layer the GPU computes runs policy 2 over its host cache.
-    Greedy ids must equal the HF golden run."""
+    copies forgotten; with the cache in HBM (3/3) every candidate layer has a cache buffer on both sides and the cache FOLLOWS the
+    layer (KVState.move_cache: host when the host cores compute it, HBM otherwise).  Greedy ids must equal the HF golden run."""
     import torch
     from lia_amd import scheduler as S
     from lia_amd.generation import generate
@@ -187,6 +187,8 @@ def test_online_cooperative_split_changes_host_set_mid_generation(fmt, pol, monk
     assert sched.coop_report()["max_host_layers"] == 3
     sup = sched._coop.superset()
     assert all(model.layers[i].raw_host_ptr() is not None for i in sup)      # every candidate keeps a raw copy for the host cores
+    if pol == (3, 3):
+        assert getattr(sched, "kv_moved_bytes", 0) > 0                       # caches really changed sides between steps
     sched.close()
     model.close()
 
