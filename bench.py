@@ -62,6 +62,7 @@ def build_parser():
     ap.add_argument("--no-raw-leg", action="store_true", help="skip the second, shorter leg with raw bf16 on the wire")
     ap.add_argument("--raw-steps", type=int, default=6)
     ap.add_argument("--no-cooperative-leg", action="store_true", help="skip the build-defined cooperative-split leg (value_cooperative)")
+    ap.add_argument("--no-cooperative-kv-leg", action="store_true", help="skip the cooperative split's KV-in-HBM variant (value_cooperative_kv_in_hbm)")
     ap.add_argument("--coop-steps", type=int, default=28, help="decode steps of the cooperative leg (the controller's search takes 12-20; value_cooperative = the last 8)")
     ap.add_argument("--no-dp-extra-legs", action="store_true", help="N > 1: skip the KV-in-HBM and all-gather legs")
     ap.add_argument("--dp-extra-steps", type=int, default=6)
@@ -594,6 +595,26 @@ def main(argv=None):
             del logits_coop
         except Exception as e:
             out["cooperative_leg"] = {"error": f"{type(e).__name__}: {e}"}
+        if not a.no_cooperative_kv_leg and "error" not in out["cooperative_leg"]:
+            # the same split with the other streamed layers' KV cache in HBM (policies 3/3, build-defined): no host attention for the
+            # GPU-computed layers; a candidate layer's cache follows it between HBM and the host (KVState.move_cache)
+            try:
+                t0 = time.time()
+                c3, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
+                                                planner.Box(host_threads=host_threads,
+                                                            wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
+                                                kv_in_hbm=True)
+                kv_kwargs = dict(gen_kwargs, prefill_policy=3, decoding_policy=3, cpu_layers=-1, cpu_layers_start=c3)
+                ids_kv, lat_kv, logits_kv = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **kv_kwargs)
+                tail = lat_kv[-max(1, min(8, a.coop_steps // 2)):]
+                out["value_cooperative_kv_in_hbm"] = B / (sum(tail) / len(tail))
+                out["cooperative_kv_in_hbm_leg"] = {"planned_host_layers": c3, "controller": sched.coop_report(), "decode_steps": len(lat_kv) - 1,
+                                                    "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail),
+                                                    "kv_moved_bytes": getattr(sched, "kv_moved_bytes", 0), "leg_s": time.time() - t0}
+                ids_check["cooperative_kv_in_hbm_vs_headline"] = first_divergence(out_ids, ids_kv, T, logits_kv)
+                del logits_kv
+            except Exception as e:
+                out["cooperative_kv_in_hbm_leg"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline: the reference's policy 1 ("compute everything on CPU", IPEX/AMX there) on this box's host cores ----------
     if rank == 0 and world == 1 and not is_llama and not a.no_cpu_baseline:

@@ -334,3 +334,6 @@ def test_bench_line_contract_on_a_small_model():
     assert d["parity"]["max_err_in_quanta"] <= 3.0 and d["parity"]["frac_within_one_quantum"] >= 0.99
     assert d["ids_check"]["pack10_vs_raw_wire"]["ids_equal"] is True
     assert d["kv_delivery"]["deferred"] in (True, False) and d["config"]["new_tokens"] == 6
+    assert d["value_cooperative"] > 0 and "error" not in d["cooperative_leg"]
+    assert d["value_cooperative_kv_in_hbm"] > 0 and "error" not in d["cooperative_kv_in_hbm_leg"], d.get("cooperative_kv_in_hbm_leg")
+    assert d["ids_check"]["cooperative_vs_headline"]["steps_compared"] >= 4 and d["ids_check"]["cooperative_kv_in_hbm_vs_headline"]["steps_compared"] >= 4
