@@ -329,14 +329,46 @@ static inline __m512 dp32(__m512 acc, const lia_bf16* a, const lia_bf16* b) {
 }
 #endif
 
+// sums of four 16-lane accumulators as one xmm (a0, a1, a2, a3): unpack/add transposes instead of four horizontal reductions
+static inline __m128 reduce4(__m512 a0, __m512 a1, __m512 a2, __m512 a3) {
+  const __m512 s01 = _mm512_add_ps(_mm512_unpacklo_ps(a0, a1), _mm512_unpackhi_ps(a0, a1));   // per 128-bit lane: a0[0]+a0[2], a1[0]+a1[2], a0[1]+a0[3], a1[1]+a1[3]
+  const __m512 s23 = _mm512_add_ps(_mm512_unpacklo_ps(a2, a3), _mm512_unpackhi_ps(a2, a3));
+  const __m512 s = _mm512_add_ps(_mm512_castpd_ps(_mm512_unpacklo_pd(_mm512_castps_pd(s01), _mm512_castps_pd(s23))),
+                                 _mm512_castpd_ps(_mm512_unpackhi_pd(_mm512_castps_pd(s01), _mm512_castps_pd(s23))));   // lane: sum4(a0), sum4(a1), sum4(a2), sum4(a3)
+  const __m256 h = _mm256_add_ps(_mm512_castps512_ps256(s), _mm512_extractf32x8_ps(s, 1));
+  return _mm_add_ps(_mm256_castps256_ps128(h), _mm256_extractf128_ps(h, 1));
+}
+
+// f32_to_bf16 on 16 lanes, bit for bit (round to nearest even, NaNs quieted), as fp32 values again
+static inline __m512 round_bf16_x16(__m512 t) {
+  const __m512i u = _mm512_castps_si512(t);
+  const __mmask16 nan = _mm512_cmpgt_epu32_mask(_mm512_and_si512(u, _mm512_set1_epi32(0x7fffffff)), _mm512_set1_epi32(0x7f800000));
+  __m512i r = _mm512_add_epi32(u, _mm512_add_epi32(_mm512_set1_epi32(0x7fff), _mm512_and_si512(_mm512_srli_epi32(u, 16), _mm512_set1_epi32(1))));
+  r = _mm512_and_si512(r, _mm512_set1_epi32((int)0xffff0000u));
+  const __m512i q = _mm512_and_si512(_mm512_or_si512(u, _mm512_set1_epi32(0x00400000)), _mm512_set1_epi32((int)0xffff0000u));
+  return _mm512_castsi512_ps(_mm512_mask_blend_epi32(nan, r, q));
+}
+static inline void store_bf16_x16(lia_bf16* p, __m512 rounded, __mmask16 m) {
+  _mm256_mask_storeu_epi16((void*)p, m, _mm512_cvtepi32_epi16(_mm512_srli_epi32(_mm512_castps_si512(rounded), 16)));
+}
+static inline __m512 load_bf16_x16(const lia_bf16* p, __mmask16 m) {
+  return _mm512_castsi512_ps(_mm512_slli_epi32(_mm512_cvtepu16_epi32(_mm256_maskz_loadu_epi16(m, (const void*)p)), 16));
+}
+
 // Decode-sized M (<= 256): the weights are streamed once and x (M x K, ~0.9 MB at M = 64, K = 7168) must stay close
 // to the core.  Tiles of 64 weight rows x K-chunks of <= 2048: per chunk the x slice (M x 4 KB) and the tile's weight
 // slice (256 KB) both sit in L2, a 4 x 4 zmm block runs over the chunk, and the chunk sums land in a thread-local
 // fp32 tile C[M][64] (L1).  With the whole K in one pass x overflows L2 and every 4 weight rows re-read it from L3.
 static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                                int M, int N, int K, int relu) {
-  constexpr int RB = 4, NT = 64, KC = 2048;
+  constexpr int RB = 4, NT = 64;
+  // A/B knobs of tools/host_linear_bench.py, read once: K-chunk length, and how the NEXT four weight rows' chunk is
+  // prefetched while this one is multiplied (0 off, 1 into L2, 2 into L1).  The rows of a tile are K * 2 bytes apart, so every
+  // 4-row block starts on cold lines the hardware prefetcher has not seen; its 16 KB are spread over the block's m-loop.
+  static const int KC = [] { const char* e = getenv("LIA_HOST_LINEAR_KC"); int v = e ? atoi(e) : 2048; return v >= 32 ? (v / 32) * 32 : 2048; }();
+  static const int PF = [] { const char* e = getenv("LIA_HOST_LINEAR_PF"); return e ? atoi(e) : 1; }();
   const int ntiles = (N + NT - 1) / NT;
+  const int mblocks = (M + RB - 1) / RB;
 #pragma omp parallel
   {
     float* C = (float*)aligned_alloc(64, (size_t)((M + 3) & ~3) * NT * sizeof(float));
@@ -346,12 +378,28 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
       memset(C, 0, (size_t)((M + 3) & ~3) * NT * sizeof(float));
       for (int k0 = 0; k0 < K; k0 += KC) {
         const int kl = K - k0 < KC ? K - k0 : KC;
+        const int lines = kl / 32, lp = (lines + mblocks - 1) / mblocks;     // 64-byte lines per row chunk, per m-block
         for (int nb = 0; nb < ntn; nb += RB) {
           const int nr = ntn - nb < RB ? ntn - nb : RB;
           const lia_bf16* wr = w + (long)(nt0 + nb) * K + k0;
+          // what this thread reads next: the following four rows of the chunk, or the tile's first rows in the next chunk
+          const lia_bf16* wn = nullptr;
+          int wn_rows = 0;
+          if (PF) {
+            if (nb + RB < ntn) { wn = wr + (long)RB * K; wn_rows = ntn - nb - RB < RB ? ntn - nb - RB : RB; }
+            else if (k0 + KC < K) { wn = w + (long)nt0 * K + k0 + KC; wn_rows = ntn < RB ? ntn : RB; }
+          }
           for (int m0 = 0; m0 < M; m0 += RB) {
             const int mr = M - m0 < RB ? M - m0 : RB;
             const lia_bf16* xr = x + (long)m0 * K + k0;
+            if (wn) {
+              const int l0 = (m0 / RB) * lp, l1 = l0 + lp < lines ? l0 + lp : lines;
+              for (int j = 0; j < wn_rows; ++j)
+                for (int l = l0; l < l1; ++l) {
+                  if (PF == 2) _mm_prefetch((const char*)(wn + (long)j * K) + 64 * l, _MM_HINT_T0);
+                  else _mm_prefetch((const char*)(wn + (long)j * K) + 64 * l, _MM_HINT_T1);
+                }
+            }
             __m512 acc[RB][RB];
             for (int i = 0; i < RB; ++i)
               for (int j = 0; j < RB; ++j) acc[i][j] = _mm512_setzero_ps();
@@ -367,18 +415,24 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
                 for (int i = 0; i < mr; ++i)
                   for (int j = 0; j < nr; ++j) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
             }
-            for (int i = 0; i < mr; ++i)
-              for (int j = 0; j < nr; ++j) C[(m0 + i) * NT + nb + j] += _mm512_reduce_add_ps(acc[i][j]);
+            // C is padded to whole 4 x 4 blocks (rows to a multiple of 4, NT = 64 columns); lanes of an edge block beyond mr / nr
+            // hold zeros and are never read back
+            for (int i = 0; i < mr; ++i) {
+              float* c = C + (m0 + i) * NT + nb;
+              _mm_storeu_ps(c, _mm_add_ps(_mm_loadu_ps(c), reduce4(acc[i][0], acc[i][1], acc[i][2], acc[i][3])));
+            }
           }
         }
       }
       for (int m = 0; m < M; ++m)
-        for (int j = 0; j < ntn; ++j) {
-          float t = C[m * NT + j] + (bias ? bf16_to_f32(bias[nt0 + j]) : 0.f);
-          t = round_bf16(t);
-          if (relu && t < 0.f) t = 0.f;
-          if (residual) t = round_bf16(bf16_to_f32(residual[(long)m * N + nt0 + j]) + t);
-          y[(long)m * N + nt0 + j] = f32_to_bf16(t);
+        for (int j = 0; j < ntn; j += 16) {
+          const __mmask16 msk = ntn - j >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << (ntn - j)) - 1);
+          __m512 t = _mm512_loadu_ps(C + m * NT + j);
+          if (bias) t = _mm512_add_ps(t, load_bf16_x16(bias + nt0 + j, msk));
+          t = round_bf16_x16(t);
+          if (relu) t = _mm512_mask_blend_ps(_mm512_cmp_ps_mask(t, _mm512_setzero_ps(), _CMP_LT_OQ), t, _mm512_setzero_ps());
+          if (residual) t = round_bf16_x16(_mm512_add_ps(load_bf16_x16(residual + (long)m * N + nt0 + j, msk), t));
+          store_bf16_x16(y + (long)m * N + nt0 + j, t, msk);
         }
     }
     free(C);
@@ -486,19 +540,30 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   if (n_threads > 0) omp_set_num_threads(n_threads);
   const lia_bf16* const* W = (const lia_bf16* const*)weights;
   const long M = (long)B * T;
-  std::vector<lia_bf16> ln((size_t)M * H), q((size_t)M * H), k((size_t)M * H), v((size_t)M * H), ao((size_t)M * H),
-      h1((size_t)M * H), f1((size_t)M * F);
-  host_layernorm(x, W[0], W[1], ln.data(), M, H, d->ln_eps);
-  host_linear(ln.data(), W[4], W[5], nullptr, k.data(), M, H, H, 0);
-  host_linear(ln.data(), W[6], W[7], nullptr, v.data(), M, H, H, 0);
-  host_linear(ln.data(), W[2], W[3], nullptr, q.data(), M, H, H, 0);
-  int rc = lia_host_attention(q.data(), k.data(), v.data(), kcache, vcache, ao.data(), B, T, pos0, heads, H / heads, cache_batch,
-                              b0, n_threads);
-  if (rc) return rc;
-  host_linear(ao.data(), W[8], W[9], x, h1.data(), M, H, H, 0);
-  host_layernorm(h1.data(), W[10], W[11], ln.data(), M, H, d->ln_eps);
-  host_linear(ln.data(), W[12], W[13], nullptr, f1.data(), M, F, H, 1);
-  host_linear(f1.data(), W[14], W[15], h1.data(), y, M, H, F, 0);
+  // the intermediates live in one scratch block per calling thread that only ever grows: std::vector zero-filled 9 MB per
+  // decode call at the OPT-30B shape (single-threaded, ~3 % of the layer) and paid the page faults again after every free
+  struct Scratch { lia_bf16* p = nullptr; size_t n = 0; ~Scratch() { free(p); } };
+  static thread_local Scratch scratch;
+  const size_t mh = ((size_t)M * H + 31) & ~(size_t)31, mf = ((size_t)M * F + 31) & ~(size_t)31, need = 6 * mh + mf;
+  if (scratch.n < need) {
+    free(scratch.p);
+    scratch.p = (lia_bf16*)aligned_alloc(64, need * sizeof(lia_bf16));
+    scratch.n = scratch.p ? need : 0;
+    if (!scratch.p) { lia_set_error("lia_host_layer_forward: out of host memory (%zu bytes of scratch)", need * sizeof(lia_bf16)); return LIA_ERR_MEMORY; }
+  }
+  // (a prefill-sized call -- policy 1 over B * T rows -- gives its block back on return: see the end of the function)
+  lia_bf16 *ln = scratch.p, *q = ln + mh, *k = q + mh, *v = k + mh, *ao = v + mh, *h1 = ao + mh, *f1 = h1 + mh;
+  host_layernorm(x, W[0], W[1], ln, M, H, d->ln_eps);
+  host_linear(ln, W[4], W[5], nullptr, k, M, H, H, 0);
+  host_linear(ln, W[6], W[7], nullptr, v, M, H, H, 0);
+  host_linear(ln, W[2], W[3], nullptr, q, M, H, H, 0);
+  int rc = lia_host_attention(q, k, v, kcache, vcache, ao, B, T, pos0, heads, H / heads, cache_batch, b0, n_threads);
+  if (rc) return rc;                                                       // (the block stays with the thread; the next call reuses it)
+  host_linear(ao, W[8], W[9], x, h1, M, H, H, 0);
+  host_layernorm(h1, W[10], W[11], ln, M, H, d->ln_eps);
+  host_linear(ln, W[12], W[13], nullptr, f1, M, F, H, 1);
+  host_linear(f1, W[14], W[15], h1, y, M, H, F, 0);
+  if (scratch.n * sizeof(lia_bf16) > ((size_t)64 << 20)) { free(scratch.p); scratch.p = nullptr; scratch.n = 0; }
   return LIA_OK;
 }
 

@@ -31,9 +31,9 @@ def run(wptr, label):
     args = (ctypes.byref(desc), ctypes.byref(w), x.ctypes.data, y.ctypes.data, k.ctypes.data, v.ctypes.data, S + 8, B, B, 1, S, 0, threads)
     N.check(L.lia_host_layer_forward(*args))
     t0 = time.time()
-    for _ in range(3):
+    for _ in range(10):
         N.check(L.lia_host_layer_forward(*args))
-    print(f"{label}: {(time.time() - t0) / 3 * 1e3:.2f} ms per layer step (threads={threads})")
+    print(f"{label}: {(time.time() - t0) / 10 * 1e3:.2f} ms per layer step (threads={threads})")
 
 
 run(flat.ctypes.data, "pageable weights")

@@ -22,7 +22,7 @@ for name, n, k in (("qkv", 21504, 7168), ("out", 7168, 7168), ("fc1", 28672, 716
     args = (x.ctypes.data, w.ctypes.data, None, None, y.ctypes.data, M, n, k, 0, threads)
     L.lia_host_linear(*args)
     t0 = time.time()
-    for _ in range(3):
+    for _ in range(10):
         L.lia_host_linear(*args)
-    dt = (time.time() - t0) / 3
+    dt = (time.time() - t0) / 10
     print(f"{name}: {dt * 1e3:.2f} ms  {2 * n * k / dt / 1e9:.1f} GB/s of weights  {2.0 * M * n * k / dt / 1e12:.2f} TFLOP/s  threads={threads}")
