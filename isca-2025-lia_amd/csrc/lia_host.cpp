@@ -355,39 +355,49 @@ static inline __m512 load_bf16_x16(const lia_bf16* p, __mmask16 m) {
   return _mm512_castsi512_ps(_mm512_slli_epi32(_mm512_cvtepu16_epi32(_mm256_maskz_loadu_epi16(m, (const void*)p)), 16));
 }
 
-// Decode-sized M (<= 256): the weights are streamed once and x (M x K, ~0.9 MB at M = 64, K = 7168) must stay close
-// to the core.  Tiles of 64 weight rows x K-chunks of <= 2048: per chunk the x slice (M x 4 KB) and the tile's weight
-// slice (256 KB) both sit in L2, a 4 x 4 zmm block runs over the chunk, and the chunk sums land in a thread-local
-// fp32 tile C[M][64] (L1).  With the whole K in one pass x overflows L2 and every 4 weight rows re-read it from L3.
-static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
-                               int M, int N, int K, int relu) {
-  constexpr int RB = 4, NT = 64;
-  // A/B knobs of tools/host_linear_bench.py, read once: K-chunk length, and how the NEXT four weight rows' chunk is
-  // prefetched while this one is multiplied (0 off, 1 into L2, 2 into L1).  The rows of a tile are K * 2 bytes apart, so every
-  // 4-row block starts on cold lines the hardware prefetcher has not seen; its 16 KB are spread over the block's m-loop.
+template <int RN>   // RN weight rows x 4 activation rows per register block: 4 (16 accumulators) or 6 (24 + 4 x rows + 1 w row = 29 zmm)
+static void host_linear_skinny_t(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
+                                 int M, int N, int K, int relu) {
+  constexpr int RB = 4;
+  // rows per tile: 8 ... 16 register blocks, chosen so the tiles deal out evenly over the threads (N = 7168 in 96-row tiles is
+  // 75 tiles = 4.7 rounds of 16 threads, the last one a third empty; in 90-row tiles it is 80 = 5 rounds exactly)
+  int NT = 16 * RN;
+  {
+    const int T = omp_get_max_threads(), blocks = (N + RN - 1) / RN;
+    long best = -1;
+    for (int per = 16; per >= 8; --per) {
+      const int tiles = (blocks + per - 1) / per;
+      const long span = (long)((tiles + T - 1) / T) * per;                 // makespan in register blocks
+      if (best < 0 || span < best) { best = span; NT = per * RN; }
+    }
+  }
+  // A/B knobs of tools/host_linear_bench.py, read once: K-chunk length, and how the NEXT weight rows' chunk is prefetched while
+  // this one is multiplied (0 off, 1 into L2, 2 into L1).  The rows of a tile are K * 2 bytes apart, so every block of rows
+  // starts on cold lines the hardware prefetcher has not seen; its 16-24 KB are spread over the block's m-loop.
   static const int KC = [] { const char* e = getenv("LIA_HOST_LINEAR_KC"); int v = e ? atoi(e) : 2048; return v >= 32 ? (v / 32) * 32 : 2048; }();
   static const int PF = [] { const char* e = getenv("LIA_HOST_LINEAR_PF"); return e ? atoi(e) : 1; }();
   const int ntiles = (N + NT - 1) / NT;
   const int mblocks = (M + RB - 1) / RB;
+  const size_t crow = (size_t)NT + 8;                                      // C rows padded: an edge block's xmm stores stay inside
 #pragma omp parallel
   {
-    float* C = (float*)aligned_alloc(64, (size_t)((M + 3) & ~3) * NT * sizeof(float));
+    float* C = (float*)aligned_alloc(64, (((size_t)((M + 3) & ~3) * crow * sizeof(float)) + 63) & ~(size_t)63);
 #pragma omp for schedule(dynamic, 1)
     for (int tile = 0; tile < ntiles; ++tile) {
       const int nt0 = tile * NT, ntn = N - nt0 < NT ? N - nt0 : NT;
-      memset(C, 0, (size_t)((M + 3) & ~3) * NT * sizeof(float));
+      memset(C, 0, (size_t)((M + 3) & ~3) * crow * sizeof(float));
       for (int k0 = 0; k0 < K; k0 += KC) {
         const int kl = K - k0 < KC ? K - k0 : KC;
         const int lines = kl / 32, lp = (lines + mblocks - 1) / mblocks;     // 64-byte lines per row chunk, per m-block
-        for (int nb = 0; nb < ntn; nb += RB) {
-          const int nr = ntn - nb < RB ? ntn - nb : RB;
+        for (int nb = 0; nb < ntn; nb += RN) {
+          const int nr = ntn - nb < RN ? ntn - nb : RN;
           const lia_bf16* wr = w + (long)(nt0 + nb) * K + k0;
-          // what this thread reads next: the following four rows of the chunk, or the tile's first rows in the next chunk
+          // what this thread reads next: the following rows of the chunk, or the tile's first rows in the next chunk
           const lia_bf16* wn = nullptr;
           int wn_rows = 0;
           if (PF) {
-            if (nb + RB < ntn) { wn = wr + (long)RB * K; wn_rows = ntn - nb - RB < RB ? ntn - nb - RB : RB; }
-            else if (k0 + KC < K) { wn = w + (long)nt0 * K + k0 + KC; wn_rows = ntn < RB ? ntn : RB; }
+            if (nb + RN < ntn) { wn = wr + (long)RN * K; wn_rows = ntn - nb - RN < RN ? ntn - nb - RN : RN; }
+            else if (k0 + KC < K) { wn = w + (long)nt0 * K + k0 + KC; wn_rows = ntn < RN ? ntn : RN; }
           }
           for (int m0 = 0; m0 < M; m0 += RB) {
             const int mr = M - m0 < RB ? M - m0 : RB;
@@ -400,26 +410,29 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
                   else _mm_prefetch((const char*)(wn + (long)j * K) + 64 * l, _MM_HINT_T1);
                 }
             }
-            __m512 acc[RB][RB];
+            __m512 acc[RB][RN];
             for (int i = 0; i < RB; ++i)
-              for (int j = 0; j < RB; ++j) acc[i][j] = _mm512_setzero_ps();
-            if (mr == RB && nr == RB) {
+              for (int j = 0; j < RN; ++j) acc[i][j] = _mm512_setzero_ps();
+            if (mr == RB && nr == RN) {
               for (int k = 0; k < kl; k += 32) {
+#pragma GCC unroll 8
+                for (int j = 0; j < RN; ++j)
 #pragma GCC unroll 4
-                for (int i = 0; i < RB; ++i)
-#pragma GCC unroll 4
-                  for (int j = 0; j < RB; ++j) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
+                  for (int i = 0; i < RB; ++i) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
               }
             } else {
               for (int k = 0; k < kl; k += 32)
                 for (int i = 0; i < mr; ++i)
                   for (int j = 0; j < nr; ++j) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
             }
-            // C is padded to whole 4 x 4 blocks (rows to a multiple of 4, NT = 64 columns); lanes of an edge block beyond mr / nr
-            // hold zeros and are never read back
+            // lanes of an edge block beyond mr / nr hold zeros; C's rows are padded so the xmm stores stay inside
             for (int i = 0; i < mr; ++i) {
-              float* c = C + (m0 + i) * NT + nb;
+              float* c = C + (m0 + i) * crow + nb;
               _mm_storeu_ps(c, _mm_add_ps(_mm_loadu_ps(c), reduce4(acc[i][0], acc[i][1], acc[i][2], acc[i][3])));
+              if (RN > 4) {
+                const __m512 z = _mm512_setzero_ps();
+                _mm_storeu_ps(c + 4, _mm_add_ps(_mm_loadu_ps(c + 4), reduce4(acc[i][RN > 4 ? 4 : 0], acc[i][RN > 5 ? 5 : 0], z, z)));
+              }
             }
           }
         }
@@ -427,7 +440,7 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
       for (int m = 0; m < M; ++m)
         for (int j = 0; j < ntn; j += 16) {
           const __mmask16 msk = ntn - j >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << (ntn - j)) - 1);
-          __m512 t = _mm512_loadu_ps(C + m * NT + j);
+          __m512 t = _mm512_maskz_loadu_ps(msk, C + m * crow + j);
           if (bias) t = _mm512_add_ps(t, load_bf16_x16(bias + nt0 + j, msk));
           t = round_bf16_x16(t);
           if (relu) t = _mm512_mask_blend_ps(_mm512_cmp_ps_mask(t, _mm512_setzero_ps(), _CMP_LT_OQ), t, _mm512_setzero_ps());
@@ -437,6 +450,17 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
     }
     free(C);
   }
+}
+
+// Decode-sized M (<= 256): the weights are streamed once and x (M x K, ~0.9 MB at M = 64, K = 7168) must stay close
+// to the core.  Tiles of 64 (96) weight rows x K-chunks of <= 2048: per chunk the x slice (M x 4 KB) and the tile's weight
+// slice (256 KB) both sit in L2, a 4 x 4 (4 x 6) zmm block runs over the chunk, and the chunk sums land in a thread-local
+// fp32 tile C[M][64] (L1).  With the whole K in one pass x overflows L2 and every 4 weight rows re-read it from L3.
+static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
+                               int M, int N, int K, int relu) {
+  static const int RN = [] { const char* e = getenv("LIA_HOST_LINEAR_RN"); return e ? atoi(e) : 6; }();   // 14.8 -> 14.2 ms per OPT-30B decode layer
+  if (RN == 6) host_linear_skinny_t<6>(x, w, bias, residual, y, M, N, K, relu);
+  else host_linear_skinny_t<4>(x, w, bias, residual, y, M, N, K, relu);
 }
 
 // y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.

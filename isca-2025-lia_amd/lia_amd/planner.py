@@ -24,7 +24,7 @@ class Box:
     host_gbs_per_thread: float = 23.0  # host attention with the row-run prefetch: 46 GB/s at 2 threads ...
     host_gbs_cap: float = 220.0        # ... and 223 GB/s at 16 (the socket's DRAM)
     # host-computed layers, threads pinned to the NUMA node that holds the weights (bench.py / run_generation.py do that):
-    host_linear_gbs_per_thread: float = 4.4   # policy-1 linears at M = 64 beside the running weight stream (4.9 alone; 3.6 unpinned)
+    host_linear_gbs_per_thread: float = 7.0   # policy-1 linears at M = 64 beside the running weight stream (7.3 alone; r02's kernel: 4.4 / 4.9; 3.6 unpinned)
     host_attn_beside_stream: float = 0.8      # share of its rate the host attention keeps beside the stream (0.55 unpinned)
     wire_ratio: float = 0.675         # bytes shipped per weight byte: pack10 0.675, pack11 0.696, pack12 0.751, raw 1.0
     host_threads: int = 0
@@ -197,8 +197,9 @@ def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None, kv_in_hbm=False)
     decoding policy 2: a host layer costs its linears at the host's weight-read rate + the host attention, but frees one
     layer's worth of link time.  The step is max(link time of the remaining layers, sum of every layer's latency);
     returns (count, predicted ms per step).  kv_in_hbm: the GPU-computed streamed layers keep their cache in HBM (policy 3 /
-    3), so only the host-computed layers use the host cores.  Calibrated on the r01 scans, OPT-30B,
-    B = 64, 16 pinned host threads: 16 layers / 412 ms measured with the cache on the host, 19 layers / 367 ms with it in HBM."""
+    3), so only the host-computed layers use the host cores.  Calibrated on the r03 scans, OPT-30B,
+    B = 64, 16 pinned host threads: 18-19 layers / 384-390 ms measured with the cache on the host, 21-23 layers / 318-335 ms with it in
+    HBM (r01-r02, before the second pass over the host linears: 16 / 412 and 19 / 367)."""
     box = box or Box()
     L, H = shape.layers, shape.hidden
     n_gpu = int(L * gpu_percentage / 100)

@@ -34,17 +34,17 @@ def test_monotonic_in_gpu_percentage_and_plan_picks_resident_when_it_fits():
 
 
 def test_plan_cpu_layers_matches_the_measured_optimum():
-    """OPT-30B, B = 64, gpu% = 10, 16 pinned host threads, pack10 on the wire: the r01 scans found the link-bound/host-bound
-    crossover at 16 host-computed layers (412 ms per step) with the KV cache on the host and at 19 layers (367 ms) with the
-    GPU layers' cache in HBM."""
+    """OPT-30B, B = 64, gpu% = 10, 16 pinned host threads, pack10 on the wire: the r03 scans found the link-bound/host-bound
+    crossover at 18-19 host-computed layers (384-390 ms per step) with the KV cache on the host and at 21-23 layers (318-335 ms)
+    with the GPU layers' cache in HBM (16 / 412 and 19 / 367 with r02's host linears)."""
     from lia_amd import planner
     from lia_amd.model import resolve_shape
     sh = resolve_shape("opt-30b")
     box = planner.Box(host_threads=16, host_mem_gb=300.0)
     c, ms = planner.plan_cpu_layers(sh, 64, 256, 32, 10, box)
-    assert 14 <= c <= 18 and 380 <= ms <= 450, (c, ms)
+    assert 17 <= c <= 20 and 350 <= ms <= 400, (c, ms)
     c3, ms3 = planner.plan_cpu_layers(sh, 64, 256, 32, 10, box, kv_in_hbm=True)
-    assert 17 <= c3 <= 21 and 340 <= ms3 <= 400 and c3 >= c and ms3 < ms, (c3, ms3)
+    assert 20 <= c3 <= 24 and 310 <= ms3 <= 345 and c3 >= c and ms3 < ms, (c3, ms3)
     # a raw wire format makes every shipped layer dearer, so more layers move to the host; few host threads -> fewer
     c_raw, _ = planner.plan_cpu_layers(sh, 64, 256, 32, 10, planner.Box(host_threads=16, host_mem_gb=300.0, wire_ratio=1.0))
     c_weak, _ = planner.plan_cpu_layers(sh, 64, 256, 32, 10, planner.Box(host_threads=4, host_mem_gb=300.0))

@@ -30,10 +30,13 @@ def run(wptr, label):
     w = ops.weight_ptr_array(wptr, offs)
     args = (ctypes.byref(desc), ctypes.byref(w), x.ctypes.data, y.ctypes.data, k.ctypes.data, v.ctypes.data, S + 8, B, B, 1, S, 0, threads)
     N.check(L.lia_host_layer_forward(*args))
-    t0 = time.time()
-    for _ in range(10):
+    ts = []
+    for _ in range(20):
+        t0 = time.time()
         N.check(L.lia_host_layer_forward(*args))
-    print(f"{label}: {(time.time() - t0) / 10 * 1e3:.2f} ms per layer step (threads={threads})")
+        ts.append(1e3 * (time.time() - t0))
+    ts.sort()
+    print(f"{label}: min {ts[0]:.2f}  median {ts[len(ts) // 2]:.2f}  mean {sum(ts) / len(ts):.2f} ms per layer step (threads={threads})")
 
 
 run(flat.ctypes.data, "pageable weights")
