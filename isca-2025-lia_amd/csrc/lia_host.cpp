@@ -72,6 +72,13 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
   if (n_threads <= 0) n_threads = omp_get_max_threads();
   const int run_bytes = G * d * (int)sizeof(lia_bf16);
   static const int PF = [] { const char* e = getenv("LIA_HOST_ATTN_PF"); return e ? atoi(e) : 8; }();   // rows of look-ahead (0 / 2 / 4 / 6 / 8 / 12 measured: 6.0 / 5.6 / 3.1 / 2.5 / 2.2 / 4.4 ms at 16 threads)
+  static const int HINT = [] { const char* e = getenv("LIA_HOST_ATTN_HINT"); return e ? atoi(e) : 2; }();   // prefetch into L1 (0), L2 (1), non-temporal (2): 2.22-2.26 / 1.90-2.25 / 1.99-2.11 ms at 16 threads (tools/dbg_hostattn.py, three interleaved rounds)
+#define LIA_ATTN_PREFETCH(p)                                         \
+  do {                                                                \
+    if (HINT == 1) _mm_prefetch((p), _MM_HINT_T1);                    \
+    else if (HINT == 2) _mm_prefetch((p), _MM_HINT_NTA);              \
+    else _mm_prefetch((p), _MM_HINT_T0);                              \
+  } while (0)
 
 #pragma omp parallel num_threads(n_threads)
   {
@@ -95,7 +102,7 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
             // not follow it, so every line of the run PF rows ahead is requested here (one line alone: 13 GB/s per thread)
             if (j + PF <= lim) {
               const char* pf = (const char*)(kcache + (long)(j + PF) * row + coff);
-              for (int c = 0; c < run_bytes; c += 64) _mm_prefetch(pf + c, _MM_HINT_T0);
+              for (int c = 0; c < run_bytes; c += 64) LIA_ATTN_PREFETCH(pf + c);
             }
             for (int hh = 0; hh < G; ++hh) {
               __m512 a = _mm512_setzero_ps();
@@ -123,7 +130,7 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
             const lia_bf16* vp = vcache + (long)j * row + coff;
             if (j + PF <= lim) {
               const char* pf = (const char*)(vcache + (long)(j + PF) * row + coff);
-              for (int c = 0; c < run_bytes; c += 64) _mm_prefetch(pf + c, _MM_HINT_T0);
+              for (int c = 0; c < run_bytes; c += 64) LIA_ATTN_PREFETCH(pf + c);
             }
             for (int hh = 0; hh < G; ++hh) {
               __m512 p = _mm512_set1_ps(sc[(size_t)hh * S + j]);
