@@ -233,6 +233,61 @@ def test_host_layer_forward_matches_oracle_policy1(native, oracle, B, T, pos0):
                                     smax, B, B, T, pos0, 0, 1) == native.LIA_ERR_MISSING
 
 
+_HOST_LINEAR_CASES = [(64, 1000, 2112, 1, 1, 0), (7, 77, 96, 1, 1, 1), (1, 50, 4096, 0, 0, 0), (130, 130, 320, 1, 0, 1), (64, 1536, 1024, 0, 1, 1),
+                      (5, 6, 64, 0, 1, 0), (300, 40, 64, 1, 1, 1)]
+
+
+def _host_linear_reference(x, w, b, r, relu):
+    """the CPU policy's linear in exact arithmetic + its two roundings (tpp_linear_bias: bias joins the fp32 accumulator before
+    the single rounding; `+ residual` is a second bf16 op) -- TPPGEMMKrnl.h:89-176 / decoder.py via DESIGN.md section 3"""
+    acc = synth.bf16_bits_to_f32(x).astype(np.float64) @ synth.bf16_bits_to_f32(w).astype(np.float64).T
+    if b is not None:
+        acc = acc + synth.bf16_bits_to_f32(b).astype(np.float64)
+    t = synth.bf16_bits_to_f32(synth.f32_to_bf16_bits(acc.astype(np.float32)))
+    if relu:
+        t = np.where(t < 0, np.float32(0), t)
+    if r is not None:
+        t = synth.bf16_bits_to_f32(synth.f32_to_bf16_bits(synth.bf16_bits_to_f32(r) + t))
+    return synth.f32_to_bf16_bits(t)
+
+
+@pytest.mark.parametrize("rn", ["4", "6"])
+def test_host_linear_edge_shapes_and_epilogue(native, rn, tmp_path):
+    """lia_host_linear, both register-block widths of the decode kernel (LIA_HOST_LINEAR_RN, read once per process -> a child
+    process per setting): N not a multiple of the block or of 16, M not a multiple of 4, K-chunk tails, M > 256 (the generic
+    kernel), bias / ReLU / residual in every combination that the layer uses.  Against exact arithmetic: <= 1 % of the outputs
+    may differ by one bf16 ulp (fp32 summation order), none by more."""
+    import subprocess
+    import sys
+    if not native.lib().lia_host_has_avx512_bf16():
+        pytest.skip("host without AVX-512-BF16")
+    code = f"""
+import sys
+sys.path[:0] = {[os.path.dirname(os.path.abspath(__file__)), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "isca-2025-lia_amd")]!r}
+import numpy as np, synth
+import test_abi_and_host as T
+from lia_amd import _native as N
+L = N.lib()
+rs = np.random.RandomState(1)
+for (M, n, k, relu, use_b, use_r) in T._HOST_LINEAR_CASES:
+    x = synth.f32_to_bf16_bits(rs.standard_normal((M, k)).astype(np.float32)); w = synth.f32_to_bf16_bits((0.02 * rs.standard_normal((n, k))).astype(np.float32))
+    b = synth.f32_to_bf16_bits((0.1 * rs.standard_normal(n)).astype(np.float32)) if use_b else None
+    r = synth.f32_to_bf16_bits(rs.standard_normal((M, n)).astype(np.float32)) if use_r else None
+    y = np.full((M + 1, n), 0x7fc1, np.uint16)                       # a guard row behind the output: must stay untouched
+    rc = L.lia_host_linear(x.ctypes.data, w.ctypes.data, b.ctypes.data if use_b else None, r.ctypes.data if use_r else None, y.ctypes.data, M, n, k, relu, 3)
+    assert rc == 0, L.lia_last_error()
+    assert (y[M] == 0x7fc1).all(), "wrote past the output"
+    ref = T._host_linear_reference(x, w, b, r, relu)
+    neq = (ref != y[:M])
+    ulp = np.abs(ref.astype(np.int32) - y[:M].astype(np.int32))
+    assert neq.mean() <= 0.01 and ulp.max() <= 1, (M, n, k, float(neq.mean()), int(ulp.max()))
+print("ok")
+"""
+    env = dict(os.environ, LIA_HOST_LINEAR_RN=rn)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_numa_alloc_tensor_wrappers(native):
     """numa_alloc_tensor / numa_free_tensor keep the reference's contract (lia/cxl/numa_alloc.py:28-55)."""
     import torch
