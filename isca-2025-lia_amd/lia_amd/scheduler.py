@@ -337,23 +337,25 @@ class CoopController:
     c_max only).  A step is max(link time of the streamed layers, host + GPU time): roughly a V in c, but on a shared box the
     bottom is flat to ~1 % with +10 % spikes on single steps, and the first version (a +-1 hill climb on the last sample) walked
     away from the minimum on a spike and stalled two counts below it (results/r03_final2_*).  So this is a pattern search:
-    measure the centre, then centre +- stride for stride 4, 2, 1 -- first on the side the copy engine's idle share points to (link
+    measure the centre, then centre +- stride for stride 3, then 1 -- first on the side the copy engine's idle share points to (link
     >= 97 % busy: more host layers shorten the link time; less: the host is the bottleneck) -- moving the centre whenever a
-    candidate beats it by > 0.5 % and carrying on in that direction; a count's value is the MINIMUM of its last `keep` samples
+    candidate beats it by > 0.5 % and carrying on in that direction, twice as far per move after two moves that paid (a seed far
+    off; the planner's seed is usually 0-3 counts off, and strides 4 / 2 / 1 spent two steps at a count 40 % slower plus 2 GB of
+    cache moves on the first probe: 3.2-3.9 % of a 31-step run in the synthetic box of tests/test_host_logic.py against 2.4-3.2 %); a count's value is the MINIMUM of its last `keep` samples
     (spikes only ever add time).  One settle step after every change (queued copies still reflect the old set).  Converged, it
     stays on the centre -- single slow steps move nothing -- and searches again from stride 2 after `expire` steps or when the
     centre's own recent steps are all > 5 % above the value it converged on (the box changed); every `probe_every` steps it
     re-measures centre +- 1 (a spike on a candidate's single sample can end the search one or two counts off; the second look
     costs five steps at a neighbouring count and repairs that)."""
 
-    STRIDES = (4, 2, 1)
+    STRIDES = (3, 1)
 
     def __init__(self, order, start, c_max, expire=96, keep=3, probe_every=16):
         self.order, self.c_max = list(order), min(int(c_max), len(order))
         self.c = max(0, min(int(start), self.c_max))
         self.expire, self.keep, self.probe_every = expire, keep, probe_every
         self.samples = {}             # c -> [(step, ms), ...] the last `keep`
-        self.centre, self.stride_i, self.pending, self.direction = self.c, 0, None, 0
+        self.centre, self.stride_i, self.pending, self.direction, self.run = self.c, 0, None, 0, 0
         self.converged_at, self.converged_ms, self.c_conv, self.last_probe, self.probing = None, None, None, 0, False
         self.settle, self.step, self.moves, self.searches = 1, 0, 0, 1
         self.trace = []               # (step, c, ms, link busy share)
@@ -397,7 +399,7 @@ class CoopController:
             if self.step - self.converged_at >= self.expire or drifted:
                 # search again around where we are: everything measured before is stale
                 self.samples = {self.c: self.samples[self.c][-1:]}
-                self.centre, self.stride_i, self.pending, self.direction = self.c, 1, None, 0
+                self.centre, self.stride_i, self.pending, self.direction, self.run = self.c, 0, None, 0, 0
                 self.converged_at, self.searches = None, self.searches + 1
             elif self.step - self.last_probe >= self.probe_every:
                 self.stride_i, self.probing = len(self.STRIDES) - 1, True
@@ -409,16 +411,19 @@ class CoopController:
         elif self.c != self.centre:                               # a candidate has just been measured
             if self.value(self.c) < 0.995 * self.value(self.centre):
                 d, s = self.direction, self.STRIDES[self.stride_i]
-                self.centre = self.c
-                nxt = self.centre + d * s                         # it paid: carry on the same way before looking back
-                self.pending = [(nxt, d)] if 0 <= nxt <= self.c_max and self.value(nxt) is None else []
+                self.centre, self.run = self.c, self.run + 1
+                nxt = self.centre + d * s * (2 if self.run >= 2 else 1)   # it paid: carry on the same way before looking back
+                nxt = max(0, min(self.c_max, nxt))
+                self.pending = [(nxt, d)] if nxt != self.centre and self.value(nxt) is None else []
+            else:
+                self.run = 0
         while not self.pending:
             if self.stride_i + 1 >= len(self.STRIDES):
                 if self.converged_at is None or self.centre != self.c_conv:
                     self.converged_at, self.converged_ms, self.c_conv = self.step, self.value(self.centre), self.centre
                 self.last_probe, self.probing = self.step, False
                 return self._go(self.centre)
-            self.stride_i += 1
+            self.stride_i, self.run = self.stride_i + 1, 0
             self.pending = self._candidates(busy_share)
         cand, self.direction = self.pending.pop(0)
         return self._go(cand)

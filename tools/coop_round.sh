@@ -9,11 +9,11 @@ mkdir -p "$out"
 run() { name=$1; shift; echo "== $name: bench.py $*"; timeout 900 python3 bench.py "$@" > "$out/$name.log" 2>&1; tail -1 "$out/$name.log" > "$out/$name.json"; cut -c1-160 "$out/$name.json"; echo; }
 X="--no-raw-leg --no-cpu-baseline --no-cooperative-leg"
 run p0p2_online_a --cpu-layers -1 $X
-for c in 15 17 19 21; do run p0p2_cpu$c --cpu-layers $c --steps 12 $X; done
+for c in 17 19 21 23; do run p0p2_cpu$c --cpu-layers $c --steps 12 $X; done
 run p0p2_online_b --cpu-layers -1 $X
 P="--prefill-policy 3 --decoding-policy 3"
 run p3p3_online_a $P --cpu-layers -1 $X
-for c in 17 19 21; do run p3p3_cpu$c $P --cpu-layers $c --steps 12 $X; done
+for c in 19 21 23 25; do run p3p3_cpu$c $P --cpu-layers $c --steps 12 $X; done
 run p3p3_online_b $P --cpu-layers -1 $X
 python3 - "$out" <<'PY'
 import glob, json, os, sys

@@ -14,9 +14,9 @@ run opt30b_gpu100_resident --gpu-percentage 100 --no-raw-leg --no-cpu-baseline
 # cooperative split: the online controller (-1) beside a scan of fixed counts on the SAME box (r03: within 5 % of the best fixed count)
 X="--no-raw-leg --no-cpu-baseline --no-cooperative-leg"
 run opt30b_gpu10_p0p2_pack10_cpu_online --cpu-layers -1 $X
-for c in 13 15 17 19; do run opt30b_gpu10_p0p2_pack10_cpu$c --cpu-layers $c --steps 12 $X; done
+for c in 17 19 21 23; do run opt30b_gpu10_p0p2_pack10_cpu$c --cpu-layers $c --steps 12 $X; done
 run opt30b_gpu10_p3p3_pack10_cpu_online --prefill-policy 3 --decoding-policy 3 --cpu-layers -1 $X
-for c in 17 19 21; do run opt30b_gpu10_p3p3_pack10_cpu$c --prefill-policy 3 --decoding-policy 3 --cpu-layers $c --steps 12 $X; done
+for c in 19 21 23 25; do run opt30b_gpu10_p3p3_pack10_cpu$c --prefill-policy 3 --decoding-policy 3 --cpu-layers $c --steps 12 $X; done
 run llama3_8b_gpu100_b128_t1024_n128 --model llama-3-8b --gpu-percentage 100 --batch 128 --prompt 1024 --steps 127
 run opt66b_gpu5_cxl_pack10 --model opt-66b --gpu-percentage 5 --enable-cxl --cxl-nodes 0,1 --batch 32 --no-raw-leg --no-cpu-baseline
 # data-parallel dry runs on the one GPU of the box: the line's schema for N > 1 (two ranks share the GPU over gloo), and real RCCL at world size 1
