@@ -610,7 +610,7 @@ def main(argv=None):
                 out["value_cooperative_kv_in_hbm"] = B / (sum(tail) / len(tail))
                 out["cooperative_kv_in_hbm_leg"] = {"planned_host_layers": c3, "controller": sched.coop_report(), "decode_steps": len(lat_kv) - 1,
                                                     "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail),
-                                                    "kv_moved_bytes": getattr(sched, "kv_moved_bytes", 0), "leg_s": time.time() - t0}
+                                                    "kv_moved_bytes": sched.kv_moved_bytes, "leg_s": time.time() - t0}
                 ids_check["cooperative_kv_in_hbm_vs_headline"] = first_divergence(out_ids, ids_kv, T, logits_kv)
                 del logits_kv
             except Exception as e:

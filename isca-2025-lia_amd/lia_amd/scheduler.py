@@ -465,6 +465,7 @@ class OffloadScheduler:
         self._outstanding = {}
         self._coop = None           # CoopController of the cooperative split (cpu_layers=-1), kept across generations
         self._coop_key = None
+        self.kv_moved_bytes = 0      # KV cache bytes moved between HBM and host by the online split (KVState.move_cache)
         self.kv_delivery = {"bytes": 0, "device_ms": None, "host_wait_ms": 0.0}   # of the last deferred delivery
 
     # -- resources -----------------------------------------------------------------------------------
@@ -751,7 +752,7 @@ class OffloadScheduler:
                 # KV in HBM: the cache of a layer that changes sides follows it (0.5 GB per layer at the headline shape, ~10 ms)
                 for li in sorted(after ^ before):
                     self._await_kv(kv_state, li)
-                    self.kv_moved_bytes = getattr(self, "kv_moved_bytes", 0) + kv_state.move_cache(ctx.lib, li, to_device=(li not in after))
+                    self.kv_moved_bytes += kv_state.move_cache(ctx.lib, li, to_device=(li not in after))
         return logits, nxt
 
     def _coop_controller(self, n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, start):
