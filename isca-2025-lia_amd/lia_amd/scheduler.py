@@ -366,6 +366,14 @@ class CoopController:
     def superset(self):
         return frozenset(self.order[:self.c_max])
 
+    def restrict(self, c_max):
+        """fewer candidates than planned (the container has no room for more raw host copies)"""
+        self.c_max = max(0, min(self.c_max, int(c_max)))
+        self.c, self.centre = min(self.c, self.c_max), min(self.centre, self.c_max)
+        self.samples = {k: v for k, v in self.samples.items() if k <= self.c_max}
+        if self.pending:
+            self.pending = [(c, d) for c, d in self.pending if c <= self.c_max]
+
     def new_sequence(self):
         """a new generation: its first decode step also waits for the prefill's K/V deliveries and loads layers on demand"""
         self.settle = max(self.settle, 1)
@@ -589,6 +597,7 @@ class OffloadScheduler:
         coop = None
         if cpu_layers and cpu_layers < 0 and decoding_policy in (2, 3) and self.dp is None and n_gpu < L - 1:
             coop = self._coop_controller(n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, cpu_layers_start)
+            self._fit_host_candidates(coop, enable_cxl and pin_weight)
             cpu_set = coop.superset()                                # layers that keep a raw host copy (and a host KV cache)
         else:
             cpu_set = self.cpu_layer_set(n_gpu, L, cpu_layers) if (cpu_layers and cpu_layers > 0 and decoding_policy in (2, 3) and self.dp is None) else frozenset()
@@ -768,6 +777,27 @@ class OffloadScheduler:
             self._coop = CoopController(order, start, min(len(order), int(start) + int(os.environ.get("LIA_COOP_HEADROOM", "10"))))
             self._coop_key = key
         return self._coop
+
+    def _fit_host_candidates(self, coop, in_numa_tier):
+        """Shrink the controller's candidate set to the raw host copies the container has room for (OPT-175B at gpu% = 5 in a
+        300 GiB container: the planner's count + 10 does not fit, and the per-allocation guard would refuse the placement halfway
+        through, in layer-index order -- a clustered host set).  A candidate in the NUMA tier swaps its packed copy for the raw
+        one (growth = the difference, guard ceiling 0.93); a pinned one keeps both (growth = the raw bytes, ceiling 0.85)."""
+        from . import hostinfo
+        mem = hostinfo.cgroup_memory()
+        layers = self.model.layers
+        need = [k for k, li in enumerate(coop.order[:coop.c_max]) if layers[li].raw_host_ptr() is None and layers[li].tier != "remote"]
+        if not need or mem["max"] is None or mem["current"] is None:
+            return
+        st = layers[coop.order[need[0]]]
+        grow = (st.nbytes - (st.stream_bytes if st.packed else 0)) if in_numa_tier else st.nbytes
+        room = (0.93 if in_numa_tier else 0.85) * mem["max"] - mem["current"] - st.nbytes          # (one layer of slack: the guard looks at the transient)
+        fit = max(0, int(room // max(grow, 1)))
+        if fit < len(need):
+            new_max = need[fit]                      # candidates before the first one that does not fit
+            if new_max <= 0:
+                raise MemoryError(f"cooperative split: no room for a raw host copy of one layer ({st.nbytes / 2**30:.2f} GiB) in this container")
+            coop.restrict(new_max)
 
     def coop_report(self):
         return self._coop.report() if self._coop is not None else None

@@ -240,6 +240,37 @@ def test_coop_controller_on_a_bumpy_measured_landscape():
     assert ms[ctl.centre] <= 1.04 * min(ms.values()) and ms[ctl.centre] <= ms[15] and ctl.report()["converged"], ctl.report()
 
 
+def test_coop_candidates_shrink_to_the_container(monkeypatch):
+    """OPT-175B at gpu% = 5 in a 300 GiB container: the planner's count + 10 raw host copies do not fit; the candidate set is cut
+    to a PREFIX of the nested order (still spread) before anything is placed, instead of a MemoryError halfway through"""
+    from types import SimpleNamespace
+    from lia_amd import hostinfo
+    from lia_amd.scheduler import CoopController, OffloadScheduler
+    GiB = 2**30
+    L, n_gpu = 96, 4
+    order = OffloadScheduler.cpu_layer_order(n_gpu, L)
+    layers = [SimpleNamespace(nbytes=int(3.38 * GiB), stream_bytes=int(2.25 * GiB), packed=10, tier="cxl", raw_host_ptr=lambda: None) for _ in range(L)]
+    me = SimpleNamespace(model=SimpleNamespace(layers=layers))
+    monkeypatch.setattr(hostinfo, "cgroup_memory", lambda: {"current": int(244 * GiB), "peak": None, "max": int(300.1 * GiB)})
+    ctl = CoopController(order, 40, 50)
+    OffloadScheduler._fit_host_candidates(me, ctl, True)
+    # 0.93 * 300.1 - 244 - 3.38 = 31.7 GiB of room, 1.13 GiB of growth per candidate (raw replaces packed in the tier)
+    assert ctl.c_max == 28 and ctl.c == 28 and len(ctl.superset()) == 28 and ctl.superset() == frozenset(order[:28])
+    ctl2 = CoopController(order, 10, 20)
+    OffloadScheduler._fit_host_candidates(me, ctl2, True)
+    assert ctl2.c_max == 20 and ctl2.c == 10                               # fits: untouched
+    ctl3 = CoopController(order, 10, 20)
+    OffloadScheduler._fit_host_candidates(me, ctl3, False)                 # pinned: raw + packed both stay, ceiling 0.85
+    assert ctl3.c_max == int((0.85 * 300.1 - 244 - 3.38) // 3.38) == 2
+    monkeypatch.setattr(hostinfo, "cgroup_memory", lambda: {"current": int(279 * GiB), "peak": None, "max": int(300.1 * GiB)})
+    with pytest.raises(MemoryError):
+        OffloadScheduler._fit_host_candidates(me, CoopController(order, 10, 20), True)
+    monkeypatch.setattr(hostinfo, "cgroup_memory", lambda: {"current": None, "peak": None, "max": None})
+    ctl4 = CoopController(order, 40, 50)
+    OffloadScheduler._fit_host_candidates(me, ctl4, True)                  # no cgroup limit readable: nothing to fit to
+    assert ctl4.c_max == 50
+
+
 def test_bench_first_divergence_reports_step_and_gap():
     """bench.py's ids_check: legs are compared over their common length; the first divergent step and the top-2 logit gap there"""
     import importlib.util
