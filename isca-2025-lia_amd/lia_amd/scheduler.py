@@ -778,11 +778,12 @@ class OffloadScheduler:
             self._coop_key = key
         return self._coop
 
-    def _fit_host_candidates(self, coop, in_numa_tier):
+    def _fit_host_candidates(self, coop, in_numa_tier, extra_per_layer=0):
         """Shrink the controller's candidate set to the raw host copies the container has room for (OPT-175B at gpu% = 5 in a
         300 GiB container: the planner's count + 10 does not fit, and the per-allocation guard would refuse the placement halfway
         through, in layer-index order -- a clustered host set).  A candidate in the NUMA tier swaps its packed copy for the raw
-        one (growth = the difference, guard ceiling 0.93); a pinned one keeps both (growth = the raw bytes, ceiling 0.85)."""
+        one (growth = the difference, guard ceiling 0.93); a pinned one keeps both (growth = the raw bytes, ceiling 0.85).
+        extra_per_layer: what else a candidate will pin (its host KV buffer when the caches otherwise live in HBM)."""
         from . import hostinfo
         mem = hostinfo.cgroup_memory()
         layers = self.model.layers
@@ -790,7 +791,7 @@ class OffloadScheduler:
         if not need or mem["max"] is None or mem["current"] is None:
             return
         st = layers[coop.order[need[0]]]
-        grow = (st.nbytes - (st.stream_bytes if st.packed else 0)) if in_numa_tier else st.nbytes
+        grow = ((st.nbytes - (st.stream_bytes if st.packed else 0)) if in_numa_tier else st.nbytes) + int(extra_per_layer)
         room = (0.93 if in_numa_tier else 0.85) * mem["max"] - mem["current"] - st.nbytes          # (one layer of slack: the guard looks at the transient)
         fit = max(0, int(room // max(grow, 1)))
         if fit < len(need):
