@@ -193,6 +193,38 @@ def test_online_cooperative_split_changes_host_set_mid_generation(fmt, pol, monk
     model.close()
 
 
+@pytest.mark.parametrize("pol", [(0, 2), (3, 3)], ids=["kv-on-host", "kv-in-hbm"])
+def test_online_cooperative_split_in_a_tight_container(pol, monkeypatch):
+    """The container has room for ONE more raw host copy: the controller's candidate set is cut to a prefix of its order before
+    anything is placed (scheduler._fit_host_candidates; OPT-175B in 300 GiB is the real case), the generation runs with what fits
+    and the ids are the golden ids."""
+    import torch
+    from lia_amd import hostinfo, scheduler as S
+    from lia_amd.generation import generate
+    monkeypatch.setenv("LIA_STREAM_FORMAT", "pack10")
+    z, m, ids, c = _load("generate_h256")
+    model = _model(m, c)
+    lb = model.layers[0].nbytes
+    kw = dict(max_new_tokens=c["new"], min_new_tokens=c["new"], prefill_policy=pol[0], decoding_policy=pol[1], gpu_percentage=0, pin_weight=True)
+    assert (generate(model, torch.from_numpy(ids), **kw).numpy() == z["ids_bf16"]).all()      # places every streamed layer pinned + packed, no raw copies
+    assert all(st.packed == 10 and st.raw_host_ptr() is None for st in model.layers)
+    real = hostinfo.cgroup_memory()
+    cur = real["current"] or (8 << 30)
+    # pinned candidates keep raw + packed: ceiling 0.85, growth = the raw bytes, one layer of slack -> room for exactly one
+    fake_max = int((cur + 2 * lb + lb // 2) / 0.85)
+    monkeypatch.setattr(hostinfo, "cgroup_memory", lambda: {"current": cur, "peak": cur, "max": fake_max})
+    monkeypatch.setattr(hostinfo, "guard_host_allocation", lambda *a, **k: None)       # (the fake limit is below what the process really holds)
+    monkeypatch.setattr(hostinfo, "check_host_allocation", lambda *a, **k: None)
+    out = generate(model, torch.from_numpy(ids), cpu_layers=-1, cpu_layers_start=3, **kw)
+    assert (out.numpy() == z["ids_bf16"]).all()
+    sched = model._lia_scheduler
+    rep = sched.coop_report()
+    assert rep["max_host_layers"] == 1 and rep["host_layers"] <= 1, rep
+    assert sum(1 for st in model.layers if st.raw_host_ptr() is not None and st.packed) == 1     # one raw copy beside its packed one, no more
+    sched.close()
+    model.close()
+
+
 @pytest.mark.parametrize("policy", [3, 0])
 @pytest.mark.parametrize("H,heads,F,B,T", [(256, 4, 1024, 4, 16), (512, 4, 2048, 3, 24), (7168, 56, 28672, 4, 256)])
 def test_layer_forward_last_equals_last_position_of_full_prefill(policy, H, heads, F, B, T, oracle):
