@@ -94,14 +94,27 @@ def auto_plan(args, out=print):
     pl = planner.plan(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, box, max_gpu_percentage=max_pct)
     args.gpu_percentage, args.prefill_policy, args.decoding_policy = pl.gpu_percentage, pl.prefill_policy, pl.decoding_policy
     args.num_minibatch, args.pin_weight, args.stream_format = pl.num_minibatch, True, fmt
-    if pl.n_gpu_layers < shape.layers and pl.decoding_policy == 2:
-        # the plan SEEDS the count; the scheduler's online controller (cpu_layers = -1) moves it with the measured decode steps
-        args.cpu_layers_start, _ = planner.plan_cpu_layers(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, pl.gpu_percentage, box)
+    coop_note = ""
+    if pl.n_gpu_layers < shape.layers and pl.decoding_policy in (2, 3):
+        # layers stream: the host cores take some of them (build-defined cooperative split).  The plan SEEDS the count; the
+        # scheduler's online controller (cpu_layers = -1) moves it with the measured decode steps.  With room in HBM for every
+        # layer's KV cache the other streamed layers attend on the GPU (policies 3/3): the host cores then run nothing but their
+        # own layers (OPT-30B gpu% = 10 on MI355X: 190-205 against 165-185 tokens/s)
+        B_, T_, new_ = args.batch_size, int(args.input_tokens), args.max_new_tokens
+        c2, ms2 = planner.plan_cpu_layers(shape, B_, T_, new_, pl.gpu_percentage, box)
+        c3, ms3 = planner.plan_cpu_layers(shape, B_, T_, new_, pl.gpu_percentage, box, kv_in_hbm=True)
+        hbm3 = planner.estimate(shape, B_, T_, new_, pl.gpu_percentage, 3, box)[2]
+        if c3 > 0 and ms3 < ms2 and hbm3 <= 0.92 * box.hbm_gb:
+            args.prefill_policy, args.decoding_policy, args.cpu_layers_start, ms = 3, 3, c3, ms3
+        else:
+            args.prefill_policy, args.decoding_policy, args.cpu_layers_start, ms = 0, 2, c2, ms2
         args.cpu_layers = -1 if args.cpu_layers_start > 0 else 0
+        if args.cpu_layers:
+            coop_note = f"; cooperative split predicted {1e3 * B_ / ms:.1f} tokens/s at {args.cpu_layers_start} host layers"
     out(f"auto-plan: calibrated {box.calibrated}")
-    out(f"auto-plan: gpu%={pl.gpu_percentage} ({pl.n_gpu_layers} resident layers) prefill policy {pl.prefill_policy} decode policy "
-        f"{pl.decoding_policy} cpu-layers {'online from ' + str(args.cpu_layers_start) if args.cpu_layers < 0 else args.cpu_layers} wire {fmt}; predicted prefill {pl.prefill_ms:.0f} ms, "
-        f"{pl.decode_tokens_per_s:.1f} tokens/s ({pl.note})")
+    out(f"auto-plan: gpu%={pl.gpu_percentage} ({pl.n_gpu_layers} resident layers) prefill policy {args.prefill_policy} decode policy "
+        f"{args.decoding_policy} cpu-layers {'online from ' + str(args.cpu_layers_start) if args.cpu_layers < 0 else args.cpu_layers} wire {fmt}; predicted prefill {pl.prefill_ms:.0f} ms, "
+        f"{pl.decode_tokens_per_s:.1f} tokens/s ({pl.note}){coop_note}")
     return pl
 
 
