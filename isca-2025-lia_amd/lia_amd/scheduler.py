@@ -784,11 +784,13 @@ class OffloadScheduler:
         through, in layer-index order -- a clustered host set).  A candidate in the NUMA tier swaps its packed copy for the raw
         one (growth = the difference, guard ceiling 0.93); a pinned one keeps both (growth = the raw bytes, ceiling 0.85).
         extra_per_layer: what else a candidate will pin (its host KV buffer when the caches otherwise live in HBM)."""
-        from . import hostinfo
-        mem = hostinfo.cgroup_memory()
         layers = self.model.layers
         need = [k for k, li in enumerate(coop.order[:coop.c_max]) if layers[li].raw_host_ptr() is None and layers[li].tier != "remote"]
-        if not need or mem["max"] is None or mem["current"] is None:
+        if not need:
+            return                                   # (every decode step comes through here: nothing to read once the copies exist)
+        from . import hostinfo
+        mem = hostinfo.cgroup_memory()
+        if mem["max"] is None or mem["current"] is None:
             return
         st = layers[coop.order[need[0]]]
         grow = ((st.nbytes - (st.stream_bytes if st.packed else 0)) if in_numa_tier else st.nbytes) + int(extra_per_layer)
