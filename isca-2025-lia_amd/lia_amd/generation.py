@@ -84,12 +84,11 @@ def _greedy_search(model, input_ids, max_new_tokens, min_new_tokens, eos_token_i
         elif on_dev and lia.get("cpu_layers", 0) < 0 and getattr(sched, "dp", None) is None and n_gpu < L - 1:
             # online count: every CANDIDATE host layer has a cache buffer on both sides; the cache lives where the layer is computed
             coop = sched._coop_controller(n_gpu, L, B, T, max_new_tokens, lia["gpu_percentage"], 3, lia.get("cpu_layers_start"))
-            # (before the caches are pinned: a candidate costs its raw weight copy AND its host cache buffer; the pooled blocks of
-            # an earlier generation with the caches on the host go back first -- with them in HBM only the candidates need one)
-            from .scheduler import PinnedPool
-            PinnedPool.trim()
+            # (before the caches are pinned: a candidate costs its raw weight copy AND its host cache buffer; while copies are
+            # missing, the pooled blocks of an earlier generation with the caches on the host go back first -- with them in HBM
+            # only the candidates need one)
             sched._fit_host_candidates(coop, bool(lia.get("enable_cxl") and lia.get("pin_weight")),
-                                       extra_per_layer=2 * (T + max_new_tokens) * B * model.shape.hidden * 2)
+                                       extra_per_layer=2 * (T + max_new_tokens) * B * model.shape.hidden * 2, trim_pool=True)
             host_layers, dual_layers = coop.host_set(), coop.superset()
         kv = KVState(model, n_gpu, B, T + max_new_tokens, all_on_device=on_dev, host_layers=host_layers, dual_layers=dual_layers)
     unfinished = torch.ones(B, dtype=torch.int64)

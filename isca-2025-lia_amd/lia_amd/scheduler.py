@@ -778,7 +778,7 @@ class OffloadScheduler:
             self._coop_key = key
         return self._coop
 
-    def _fit_host_candidates(self, coop, in_numa_tier, extra_per_layer=0):
+    def _fit_host_candidates(self, coop, in_numa_tier, extra_per_layer=0, trim_pool=False):
         """Shrink the controller's candidate set to the raw host copies the container has room for (OPT-175B at gpu% = 5 in a
         300 GiB container: the planner's count + 10 does not fit, and the per-allocation guard would refuse the placement halfway
         through, in layer-index order -- a clustered host set).  A candidate in the NUMA tier swaps its packed copy for the raw
@@ -788,6 +788,8 @@ class OffloadScheduler:
         need = [k for k, li in enumerate(coop.order[:coop.c_max]) if layers[li].raw_host_ptr() is None and layers[li].tier != "remote"]
         if not need:
             return                                   # (every decode step comes through here: nothing to read once the copies exist)
+        if trim_pool:
+            PinnedPool.trim()                        # idle cache blocks of earlier generations count against the room
         from . import hostinfo
         mem = hostinfo.cgroup_memory()
         if mem["max"] is None or mem["current"] is None:
