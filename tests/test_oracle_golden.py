@@ -100,6 +100,41 @@ def test_fullsize_opt30b_layer_oracle_vs_reference(oracle):
     quantum_bound(y2, z["p2_dec0_hidden"], "policy-2 decode hidden (reference: the bf16 pure-torch twin of the C++ kernel)", 0.2)
 
 
+def test_fullsize_opt30b_host_layer_vs_oracle_policy1(oracle):
+    """The PRODUCT's host layer (lia_host_layer_forward: 6 x 4 vdpbf16ps blocks, transposed reductions, 16-lane epilogue) at the
+    OPT-30B layer shape against the oracle's policy 1 on the same weights, hidden state and caches: the prefill of the fixture
+    (B x T rows: the generic M > 256 kernel is not reached, the decode kernel with M = 16) and one decode step (M = B).  Same
+    bound as every other full-size pair: one bf16 quantum of the largest output; the appended K/V rows (one GEMM deep) nearly all
+    identical.  No GPU: the host path is plain C++."""
+    import ctypes
+    from lia_amd import _native as N, ops
+    from parity_util import fullsize_opt30b_case, quantum_bound
+    L = N.lib()
+    if not L.lia_host_has_avx512_bf16():
+        pytest.skip("host without AVX-512-BF16")
+    c = fullsize_opt30b_case()
+    W, x, xs = c["W"], c["x"], c["xs"]
+    H, heads, F, B, T, new = c["cfg"]
+    d = H // heads
+    oracle.lib().lia_oracle_set_fast(0)
+    desc = ops.make_desc(H, heads, F)
+    ws = [np.ascontiguousarray(W[n]) for n in synth.LAYER_TENSORS]
+    arr = (ctypes.c_void_p * 16)(*[w.ctypes.data for w in ws])
+    kc_o = np.zeros((T + new, B, heads, d), np.uint16)
+    vc_o = np.zeros_like(kc_o)
+    kc_h, vc_h = kc_o.copy(), vc_o.copy()
+    for what, inp, TT, pos0 in (("prefill", x, T, 0), ("decode step", xs, 1, T)):
+        ref = oracle.layer_forward(1, W, inp, kc_o, vc_o, pos0, heads)
+        got = np.zeros_like(inp)
+        rc = L.lia_host_layer_forward(ctypes.byref(desc), ctypes.byref(arr), inp.ctypes.data, got.ctypes.data, kc_h.ctypes.data, vc_h.ctypes.data,
+                                      T + new, B, B, TT, pos0, 0, 8)
+        assert rc == 0, L.lia_last_error()
+        quantum_bound(got, ref, f"host layer vs oracle policy 1, {what} hidden", 0.25)
+        quantum_bound(kc_h[pos0:pos0 + TT], kc_o[pos0:pos0 + TT], f"{what}: appended K rows", 0.97, max_quanta=1.0)
+        quantum_bound(vc_h[pos0:pos0 + TT], vc_o[pos0:pos0 + TT], f"{what}: appended V rows", 0.97, max_quanta=1.0)
+        kc_h[:], vc_h[:] = kc_o, vc_o           # the next step starts from the same cache on both sides
+
+
 def test_tpp_blocking_roundtrip(oracle):
     w = np.arange(64 * 128, dtype=np.uint16).reshape(64, 128)
     wb = oracle.tpp_block(w)
