@@ -9,6 +9,8 @@
 #include <numa.h>
 #include <numaif.h>
 #include <omp.h>
+#include <atomic>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +22,49 @@
 #include "../../include/lia_hip.h"
 
 extern "C" void lia_set_error(const char* fmt, ...);
+
+// ------------------------------------------------------------------------------------------------
+// One OpenMP region per host layer.  The launchers park the OpenMP team between bursts (OMP_WAIT_POLICY=PASSIVE /
+// GOMP_SPINCOUNT=0 in bench.py and lia_amd/run.py: spinning workers would eat the CFS quota the copy-issuing main thread
+// needs -- the headline loses 1-2 % with a spinning team).  With a parked team every `parallel` region AND every OpenMP
+// barrier is a futex wake: nine regions per host layer cost ~0.45 ms of a 13 ms OPT-30B layer and 3 of the 4.3 ms an opt-125m
+// token takes at batch 1 (configs[0]: 213 -> 810 tokens/s with a spinning team).  So the ops below are written as TEAM
+// functions -- orphaned `omp for ... nowait` loops that bind to whatever region encloses them -- and a host layer runs them
+// in ONE region, separated by this spinning barrier (it yields after a while: an oversubscribed box must not live-lock).
+// ------------------------------------------------------------------------------------------------
+struct LiaTeamBarrier {
+  alignas(64) std::atomic<int> count{0};
+  alignas(64) std::atomic<int> sense{0};
+};
+static inline void team_barrier(LiaTeamBarrier& b, int& local_sense) {
+  const int n = omp_in_parallel() ? omp_get_num_threads() : 1;
+  if (n == 1) return;
+  local_sense ^= 1;
+  if (b.count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+    b.count.store(0, std::memory_order_relaxed);
+    b.sense.store(local_sense, std::memory_order_release);
+  } else {
+    int spins = 0;
+    while (b.sense.load(std::memory_order_acquire) != local_sense) {
+      _mm_pause();
+      if (++spins > 4096) { sched_yield(); spins = 0; }
+    }
+  }
+}
+static inline int team_size() { return omp_in_parallel() ? omp_get_num_threads() : omp_get_max_threads(); }
+
+// a scratch block per thread that only grows (fp32 tiles of the linears, score rows of the attention)
+static inline float* thread_scratch(size_t floats) {
+  struct Block { float* p = nullptr; size_t n = 0; ~Block() { free(p); } };
+  static thread_local Block blk;
+  if (blk.n < floats) {
+    free(blk.p);
+    const size_t bytes = ((floats * sizeof(float)) + 63) & ~(size_t)63;
+    blk.p = (float*)aligned_alloc(64, bytes);
+    blk.n = blk.p ? floats : 0;
+  }
+  return blk.p;
+}
 
 // ------------------------------------------------------------------------------------------------
 // host attention
@@ -43,23 +88,9 @@ static inline lia_bf16 f32_to_bf16(float f) {
 // the output (:826-828).  beam_idx is the identity under greedy search (:1393-1402) and is not
 // materialised.  Work is split over (batch row, group of heads) so that for each cached position a
 // thread streams one contiguous run of the [S][B][h][d] cache.
-extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const lia_bf16* v, lia_bf16* kcache,
-                                  lia_bf16* vcache, lia_bf16* out, int B, int T, int pos0, int heads, int head_dim,
-                                  int cache_batch, int b0, int n_threads) {
-  if (!q || !k || !v || !kcache || !vcache || !out) {
-    lia_set_error("lia_host_attention: NULL tensor");
-    return LIA_ERR_MISSING;
-  }
-  if (B <= 0 || T <= 0 || pos0 < 0 || heads <= 0 || head_dim <= 0 || (head_dim % 16) != 0 || b0 < 0 ||
-      b0 + B > cache_batch) {
-    lia_set_error("lia_host_attention: bad shape B=%d T=%d pos0=%d heads=%d d=%d cache_batch=%d b0=%d", B, T, pos0,
-                  heads, head_dim, cache_batch, b0);
-    return LIA_ERR_INVALID;
-  }
-  if (head_dim > 128) {   // the per-head accumulators are a fixed 8 x 8 zmm block (OPT / Llama heads are 64 or 128 wide)
-    lia_set_error("lia_host_attention: head_dim %d > 128 is not supported", head_dim);
-    return LIA_ERR_INVALID;
-  }
+// the attention of one layer as a TEAM function (see the note above): every thread of the enclosing region calls it
+static void host_attention_team(const lia_bf16* q, const lia_bf16* k, const lia_bf16* v, lia_bf16* kcache, lia_bf16* vcache,
+                                lia_bf16* out, int B, int T, int pos0, int heads, int head_dim, int cache_batch, int b0) {
   const int d = head_dim;
   const long hd = (long)heads * d;
   const long row = (long)cache_batch * hd;
@@ -69,7 +100,6 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
   int G = 8;
   while (heads % G) G >>= 1;
   const int ngroups = heads / G;
-  if (n_threads <= 0) n_threads = omp_get_max_threads();
   const int run_bytes = G * d * (int)sizeof(lia_bf16);
   static const int PF = [] { const char* e = getenv("LIA_HOST_ATTN_PF"); return e ? atoi(e) : 8; }();   // rows of look-ahead (0 / 2 / 4 / 6 / 8 / 12 measured: 6.0 / 5.6 / 3.1 / 2.5 / 2.2 / 4.4 ms at 16 threads)
   static const int HINT = [] { const char* e = getenv("LIA_HOST_ATTN_HINT"); return e ? atoi(e) : 2; }();   // prefetch into L1 (0), L2 (1), non-temporal (2): 2.22-2.26 / 1.90-2.25 / 1.99-2.11 ms at 16 threads (tools/dbg_hostattn.py, three interleaved rounds)
@@ -79,11 +109,9 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
     else if (HINT == 2) _mm_prefetch((p), _MM_HINT_NTA);              \
     else _mm_prefetch((p), _MM_HINT_T0);                              \
   } while (0)
-
-#pragma omp parallel num_threads(n_threads)
   {
-    std::vector<float> sc((size_t)G * S);
-#pragma omp for collapse(2) schedule(dynamic, 1)
+    float* sc = thread_scratch((size_t)G * S);
+#pragma omp for collapse(2) schedule(dynamic, 1) nowait
     for (int b = 0; b < B; ++b)
       for (int g = 0; g < ngroups; ++g) {
         const long coff = (long)(b0 + b) * hd + (long)g * G * d;
@@ -112,7 +140,7 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
             }
           }
           for (int hh = 0; hh < G; ++hh) {
-            float* s = &sc[(size_t)hh * S];
+            float* s = sc + (size_t)hh * S;
             float mx = -INFINITY;
             for (int j = 0; j <= lim; ++j) mx = s[j] > mx ? s[j] : mx;
             float sum = 0.f;
@@ -147,6 +175,28 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
         }
       }
   }
+}
+
+extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const lia_bf16* v, lia_bf16* kcache,
+                                  lia_bf16* vcache, lia_bf16* out, int B, int T, int pos0, int heads, int head_dim,
+                                  int cache_batch, int b0, int n_threads) {
+  if (!q || !k || !v || !kcache || !vcache || !out) {
+    lia_set_error("lia_host_attention: NULL tensor");
+    return LIA_ERR_MISSING;
+  }
+  if (B <= 0 || T <= 0 || pos0 < 0 || heads <= 0 || head_dim <= 0 || (head_dim % 16) != 0 || b0 < 0 ||
+      b0 + B > cache_batch) {
+    lia_set_error("lia_host_attention: bad shape B=%d T=%d pos0=%d heads=%d d=%d cache_batch=%d b0=%d", B, T, pos0,
+                  heads, head_dim, cache_batch, b0);
+    return LIA_ERR_INVALID;
+  }
+  if (head_dim > 128) {   // the per-head accumulators are a fixed 8 x 8 zmm block (OPT / Llama heads are 64 or 128 wide)
+    lia_set_error("lia_host_attention: head_dim %d > 128 is not supported", head_dim);
+    return LIA_ERR_INVALID;
+  }
+  if (n_threads <= 0) n_threads = omp_get_max_threads();
+#pragma omp parallel num_threads(n_threads)
+  host_attention_team(q, k, v, kcache, vcache, out, B, T, pos0, heads, head_dim, cache_batch, b0);
   return LIA_OK;
 }
 
@@ -304,8 +354,8 @@ static inline float bf16_to_f32(lia_bf16 v) {
 }
 static inline float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
-static void host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H, float eps) {
-#pragma omp parallel for schedule(static)
+static void host_layernorm_team(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H, float eps) {
+#pragma omp for schedule(static) nowait
   for (long r = 0; r < rows; ++r) {
     const lia_bf16* xr = x + r * (long)H;
     lia_bf16* yr = y + r * (long)H;
@@ -321,6 +371,10 @@ static void host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16*
     const float rstd = 1.0f / sqrtf(_mm512_reduce_add_ps(q) / (float)H + eps);
     for (int i = 0; i < H; ++i) yr[i] = f32_to_bf16((bf16_to_f32(xr[i]) - mean) * rstd * bf16_to_f32(g[i]) + bf16_to_f32(b[i]));
   }
+}
+static void host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H, float eps) {
+#pragma omp parallel
+  host_layernorm_team(x, g, b, y, rows, H, eps);
 }
 
 #if defined(__AVX512BF16__)
@@ -363,14 +417,14 @@ static inline __m512 load_bf16_x16(const lia_bf16* p, __mmask16 m) {
 }
 
 template <int RN>   // RN weight rows x 4 activation rows per register block: 4 (16 accumulators) or 6 (24 + 4 x rows + 1 w row = 29 zmm)
-static void host_linear_skinny_t(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
-                                 int M, int N, int K, int relu) {
+static void host_linear_skinny_team_t(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
+                                      int M, int N, int K, int relu) {
   constexpr int RB = 4;
   // rows per tile: 8 ... 16 register blocks, chosen so the tiles deal out evenly over the threads (N = 7168 in 96-row tiles is
   // 75 tiles = 4.7 rounds of 16 threads, the last one a third empty; in 90-row tiles it is 80 = 5 rounds exactly)
   int NT = 16 * RN;
   {
-    const int T = omp_get_max_threads(), blocks = (N + RN - 1) / RN;
+    const int T = team_size(), blocks = (N + RN - 1) / RN;
     long best = -1;
     for (int per = 16; per >= 8; --per) {
       const int tiles = (blocks + per - 1) / per;
@@ -386,10 +440,9 @@ static void host_linear_skinny_t(const lia_bf16* x, const lia_bf16* w, const lia
   const int ntiles = (N + NT - 1) / NT;
   const int mblocks = (M + RB - 1) / RB;
   const size_t crow = (size_t)NT + 8;                                      // C rows padded: an edge block's xmm stores stay inside
-#pragma omp parallel
   {
-    float* C = (float*)aligned_alloc(64, (((size_t)((M + 3) & ~3) * crow * sizeof(float)) + 63) & ~(size_t)63);
-#pragma omp for schedule(dynamic, 1)
+    float* C = thread_scratch((size_t)((M + 3) & ~3) * crow);
+#pragma omp for schedule(dynamic, 1) nowait
     for (int tile = 0; tile < ntiles; ++tile) {
       const int nt0 = tile * NT, ntn = N - nt0 < NT ? N - nt0 : NT;
       memset(C, 0, (size_t)((M + 3) & ~3) * crow * sizeof(float));
@@ -427,6 +480,19 @@ static void host_linear_skinny_t(const lia_bf16* x, const lia_bf16* w, const lia
 #pragma GCC unroll 4
                   for (int i = 0; i < RB; ++i) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
               }
+            } else if (nr == RN && mr == 1) {
+              // batch 1 (configs[0], opt-125m 1/1): a GEMV -- constant trip counts keep the RN accumulators in registers
+              for (int k = 0; k < kl; k += 32) {
+#pragma GCC unroll 8
+                for (int j = 0; j < RN; ++j) acc[0][j] = dp32(acc[0][j], xr + k, wr + j * (long)K + k);
+              }
+            } else if (nr == RN && mr == 2) {
+              for (int k = 0; k < kl; k += 32) {
+#pragma GCC unroll 8
+                for (int j = 0; j < RN; ++j)
+#pragma GCC unroll 2
+                  for (int i = 0; i < 2; ++i) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
+              }
             } else {
               for (int k = 0; k < kl; k += 32)
                 for (int i = 0; i < mr; ++i)
@@ -455,7 +521,6 @@ static void host_linear_skinny_t(const lia_bf16* x, const lia_bf16* w, const lia
           store_bf16_x16(y + (long)m * N + nt0 + j, t, msk);
         }
     }
-    free(C);
   }
 }
 
@@ -463,11 +528,16 @@ static void host_linear_skinny_t(const lia_bf16* x, const lia_bf16* w, const lia
 // to the core.  Tiles of 64 (96) weight rows x K-chunks of <= 2048: per chunk the x slice (M x 4 KB) and the tile's weight
 // slice (256 KB) both sit in L2, a 4 x 4 (4 x 6) zmm block runs over the chunk, and the chunk sums land in a thread-local
 // fp32 tile C[M][64] (L1).  With the whole K in one pass x overflows L2 and every 4 weight rows re-read it from L3.
+static void host_linear_skinny_team(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
+                                    int M, int N, int K, int relu) {
+  static const int RN = [] { const char* e = getenv("LIA_HOST_LINEAR_RN"); return e ? atoi(e) : 6; }();   // 14.8 -> 14.2 ms per OPT-30B decode layer
+  if (RN == 6) host_linear_skinny_team_t<6>(x, w, bias, residual, y, M, N, K, relu);
+  else host_linear_skinny_team_t<4>(x, w, bias, residual, y, M, N, K, relu);
+}
 static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                                int M, int N, int K, int relu) {
-  static const int RN = [] { const char* e = getenv("LIA_HOST_LINEAR_RN"); return e ? atoi(e) : 6; }();   // 14.8 -> 14.2 ms per OPT-30B decode layer
-  if (RN == 6) host_linear_skinny_t<6>(x, w, bias, residual, y, M, N, K, relu);
-  else host_linear_skinny_t<4>(x, w, bias, residual, y, M, N, K, relu);
+#pragma omp parallel
+  host_linear_skinny_team(x, w, bias, residual, y, M, N, K, relu);
 }
 
 // y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.
@@ -584,6 +654,33 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   }
   // (a prefill-sized call -- policy 1 over B * T rows -- gives its block back on return: see the end of the function)
   lia_bf16 *ln = scratch.p, *q = ln + mh, *k = q + mh, *v = k + mh, *ao = v + mh, *h1 = ao + mh, *f1 = h1 + mh;
+  static const bool one_region = [] { const char* e = getenv("LIA_HOST_LAYER_REGIONS"); return !(e && atoi(e) != 1); }();   // A/B: 9 = a region per op (r02)
+  if (M <= 256 && one_region) {
+    // decode: the whole layer in ONE parallel region, the ops separated by a spinning barrier (see LiaTeamBarrier)
+    LiaTeamBarrier bar;
+    const int eps_heads = heads;
+    const float eps = d->ln_eps;
+#pragma omp parallel
+    {
+      int sense = 0;
+      host_layernorm_team(x, W[0], W[1], ln, M, H, eps);
+      team_barrier(bar, sense);
+      host_linear_skinny_team(ln, W[4], W[5], nullptr, k, (int)M, H, H, 0);        // (nowait loops: the three projections overlap at their tails)
+      host_linear_skinny_team(ln, W[6], W[7], nullptr, v, (int)M, H, H, 0);
+      host_linear_skinny_team(ln, W[2], W[3], nullptr, q, (int)M, H, H, 0);
+      team_barrier(bar, sense);
+      host_attention_team(q, k, v, kcache, vcache, ao, B, T, pos0, eps_heads, H / eps_heads, cache_batch, b0);
+      team_barrier(bar, sense);
+      host_linear_skinny_team(ao, W[8], W[9], x, h1, (int)M, H, H, 0);
+      team_barrier(bar, sense);
+      host_layernorm_team(h1, W[10], W[11], ln, M, H, eps);
+      team_barrier(bar, sense);
+      host_linear_skinny_team(ln, W[12], W[13], nullptr, f1, (int)M, F, H, 1);
+      team_barrier(bar, sense);
+      host_linear_skinny_team(f1, W[14], W[15], h1, y, (int)M, H, F, 0);
+    }
+    return LIA_OK;
+  }
   host_layernorm(x, W[0], W[1], ln, M, H, d->ln_eps);
   host_linear(ln, W[4], W[5], nullptr, k, M, H, H, 0);
   host_linear(ln, W[6], W[7], nullptr, v, M, H, H, 0);
