@@ -215,6 +215,13 @@ int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const lia_bf16* v, 
 int lia_host_layer_forward(const lia_layer_desc* d, const void* const weights[16], const lia_bf16* x, lia_bf16* y,
                            lia_bf16* kcache, lia_bf16* vcache, int smax, int cache_batch, int B, int T, int pos0, int b0,
                            int n_threads);
+/* The decode step of policy 1 over n_layers CONSECUTIVE layers (the reference's loop over decoder layers with every layer on the
+ * CPU, modeling_opt.py:1545-1555) in one OpenMP region: weights = n_layers x 16 host pointers, kcaches / vcaches = n_layers host
+ * caches; the hidden state ping-pongs between x and y (both are written).  B * T <= 256.  Returns 0 if the result is in x,
+ * 1 if it is in y, a negative LIA_ERR_* code on error. */
+int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, const void* const* weights, lia_bf16* x, lia_bf16* y,
+                            void* const* kcaches, void* const* vcaches, int smax, int cache_batch, int B, int T, int pos0,
+                            int b0, int n_threads);
 int lia_host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, lia_bf16* y, long rows, int H, float eps,
                        int n_threads);
 int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y, long M,

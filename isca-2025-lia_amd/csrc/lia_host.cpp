@@ -622,6 +622,29 @@ extern "C" int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_b
   return LIA_OK;
 }
 
+// one decode-sized layer inside an enclosing parallel region (every thread calls it); sc: 6 * mh + M * F bf16 of scratch
+static void host_layer_team(const lia_layer_desc* d, const lia_bf16* const* W, const lia_bf16* x, lia_bf16* y, lia_bf16* kcache,
+                            lia_bf16* vcache, int cache_batch, int B, int T, int pos0, int b0, lia_bf16* sc, size_t mh,
+                            LiaTeamBarrier& bar, int& sense) {
+  const int H = d->hidden, F = d->ffn, heads = d->heads, M = B * T;
+  lia_bf16 *ln = sc, *q = ln + mh, *k = q + mh, *v = k + mh, *ao = v + mh, *h1 = ao + mh, *f1 = h1 + mh;
+  host_layernorm_team(x, W[0], W[1], ln, M, H, d->ln_eps);
+  team_barrier(bar, sense);
+  host_linear_skinny_team(ln, W[4], W[5], nullptr, k, M, H, H, 0);        // (nowait loops: the three projections overlap at their tails)
+  host_linear_skinny_team(ln, W[6], W[7], nullptr, v, M, H, H, 0);
+  host_linear_skinny_team(ln, W[2], W[3], nullptr, q, M, H, H, 0);
+  team_barrier(bar, sense);
+  host_attention_team(q, k, v, kcache, vcache, ao, B, T, pos0, heads, H / heads, cache_batch, b0);
+  team_barrier(bar, sense);
+  host_linear_skinny_team(ao, W[8], W[9], x, h1, M, H, H, 0);
+  team_barrier(bar, sense);
+  host_layernorm_team(h1, W[10], W[11], ln, M, H, d->ln_eps);
+  team_barrier(bar, sense);
+  host_linear_skinny_team(ln, W[12], W[13], nullptr, f1, M, F, H, 1);
+  team_barrier(bar, sense);
+  host_linear_skinny_team(f1, W[14], W[15], h1, y, M, H, F, 0);
+}
+
 // One decoder layer on the host: OPTDecoderLayer_forward with gpu_linear = gpu_attn = False (decoder.py:191-193,
 // 206, 248-250, 276, 286-287, 312-315; attentions.py:365-376, 401-440).  weights: 16 HOST pointers in create_buffer
 // order, row-major.  x, y: host [B,T,H]; cache: host [smax][cache_batch][h][d], rows pos0.. appended.
@@ -658,26 +681,11 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   if (M <= 256 && one_region) {
     // decode: the whole layer in ONE parallel region, the ops separated by a spinning barrier (see LiaTeamBarrier)
     LiaTeamBarrier bar;
-    const int eps_heads = heads;
-    const float eps = d->ln_eps;
+    lia_bf16* const sc = scratch.p;          // (thread_local: the workers must see the CALLER's block, not their own)
 #pragma omp parallel
     {
       int sense = 0;
-      host_layernorm_team(x, W[0], W[1], ln, M, H, eps);
-      team_barrier(bar, sense);
-      host_linear_skinny_team(ln, W[4], W[5], nullptr, k, (int)M, H, H, 0);        // (nowait loops: the three projections overlap at their tails)
-      host_linear_skinny_team(ln, W[6], W[7], nullptr, v, (int)M, H, H, 0);
-      host_linear_skinny_team(ln, W[2], W[3], nullptr, q, (int)M, H, H, 0);
-      team_barrier(bar, sense);
-      host_attention_team(q, k, v, kcache, vcache, ao, B, T, pos0, eps_heads, H / eps_heads, cache_batch, b0);
-      team_barrier(bar, sense);
-      host_linear_skinny_team(ao, W[8], W[9], x, h1, (int)M, H, H, 0);
-      team_barrier(bar, sense);
-      host_layernorm_team(h1, W[10], W[11], ln, M, H, eps);
-      team_barrier(bar, sense);
-      host_linear_skinny_team(ln, W[12], W[13], nullptr, f1, (int)M, F, H, 1);
-      team_barrier(bar, sense);
-      host_linear_skinny_team(f1, W[14], W[15], h1, y, (int)M, H, F, 0);
+      host_layer_team(d, W, x, y, kcache, vcache, cache_batch, B, T, pos0, b0, sc, mh, bar, sense);
     }
     return LIA_OK;
   }
@@ -693,6 +701,47 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   host_linear(f1, W[14], W[15], h1, y, M, H, F, 0);
   if (scratch.n * sizeof(lia_bf16) > ((size_t)64 << 20)) { free(scratch.p); scratch.p = nullptr; scratch.n = 0; }
   return LIA_OK;
+}
+
+// n_layers consecutive decode-sized layers (policy 1's decode step: every layer on the host) in ONE parallel region: the hidden
+// state ping-pongs between x and y (the result is in x when n_layers is even, in y when it is odd -- the return value says
+// which: 0 = x, 1 = y, negative = error).  With a parked OpenMP team every region costs a futex wake per thread; an opt-125m
+// token at batch 1 is twelve 0.1 ms layers (configs[0]).
+extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, const void* const* weights, lia_bf16* x, lia_bf16* y,
+                                       void* const* kcaches, void* const* vcaches, int smax, int cache_batch, int B, int T,
+                                       int pos0, int b0, int n_threads) {
+  if (!d || !weights || !x || !y || !kcaches || !vcaches || n_layers <= 0) { lia_set_error("lia_host_layers_forward: NULL argument"); return LIA_ERR_MISSING; }
+  for (long i = 0; i < 16L * n_layers; ++i)
+    if (!weights[i]) { lia_set_error("lia_host_layers_forward: weights[%ld][%ld] is NULL", i / 16, i % 16); return LIA_ERR_MISSING; }
+  for (int l = 0; l < n_layers; ++l)
+    if (!kcaches[l] || !vcaches[l]) { lia_set_error("lia_host_layers_forward: cache %d is NULL", l); return LIA_ERR_MISSING; }
+  const int H = d->hidden, F = d->ffn, heads = d->heads;
+  const long M = (long)B * T;
+  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || (H / heads) > 128 || H % 32 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
+      pos0 + T > smax || b0 < 0 || b0 + B > cache_batch || M > 256) {
+    lia_set_error("lia_host_layers_forward: bad shape H=%d heads=%d F=%d B=%d T=%d pos0=%d smax=%d (B * T <= 256: decode-sized steps only)",
+                  H, heads, F, B, T, pos0, smax);
+    return LIA_ERR_INVALID;
+  }
+  if (int rc = host_isa_ok("lia_host_layers_forward")) return rc;
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+  const size_t mh = ((size_t)M * H + 31) & ~(size_t)31, mf = ((size_t)M * F + 31) & ~(size_t)31;
+  lia_bf16* sc = (lia_bf16*)aligned_alloc(64, (6 * mh + mf) * sizeof(lia_bf16));
+  if (!sc) { lia_set_error("lia_host_layers_forward: out of host memory"); return LIA_ERR_MEMORY; }
+  LiaTeamBarrier bar;
+#pragma omp parallel
+  {
+    int sense = 0;
+    lia_bf16 *in = x, *out = y;
+    for (int l = 0; l < n_layers; ++l) {
+      host_layer_team(d, (const lia_bf16* const*)(weights + 16L * l), in, out, (lia_bf16*)kcaches[l], (lia_bf16*)vcaches[l], cache_batch, B, T,
+                      pos0, b0, sc, mh, bar, sense);
+      team_barrier(bar, sense);
+      lia_bf16* t = in; in = out; out = t;
+    }
+  }
+  free(sc);
+  return n_layers & 1;
 }
 
 // 1 when the vdpbf16ps inner loops are compiled in AND this CPU executes them

@@ -87,6 +87,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p]),
     "lia_host_layer_forward": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_void_p * 16), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "lia_host_layers_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "lia_host_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_int]),
     "lia_host_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int]),
     "lia_host_has_avx512_bf16": (c_int, []),

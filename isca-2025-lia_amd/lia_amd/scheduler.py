@@ -865,23 +865,49 @@ class OffloadScheduler:
             ctx.layer_forward(m.desc, 3, self._resident(idx), x, y, kv_state.kv[idx], B, T, pos0, 0)
             x, y = y, x
         ctx.synchronize()
-        hx = torch.empty((B, T, sh.hidden), dtype=torch.bfloat16, pin_memory=True)
-        hy = torch.empty_like(hx).pin_memory()
-        N.check(lib.lia_memcpy_d2h(ctypes.c_void_p(hx.data_ptr()), ctypes.c_void_p(x.data_ptr()), hx.numel() * 2), "lia_memcpy_d2h")
+        nbytes = B * T * sh.hidden * 2
+        if getattr(self, "_host_hidden", None) is None or self._host_hidden[2] < nbytes:      # two pinned hidden-state buffers, kept across steps
+            self._host_hidden = (PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes), nbytes)
+        hx, hy, _ = self._host_hidden
+        N.check(lib.lia_memcpy_d2h(ctypes.c_void_p(hx), ctypes.c_void_p(x.data_ptr()), nbytes), "lia_memcpy_d2h")
         from . import hostinfo
         threads = self.host_threads or hostinfo.default_host_threads(self.dp.world if self.dp else 1)
-        for idx in range(n_gpu, sh.layers):
-            st = m.layers[idx]
-            if st.packed:
+        host = list(range(n_gpu, sh.layers))
+        for idx in host:
+            if m.layers[idx].packed:
                 raise ValueError("policy 1 needs the raw bf16 host copy, but the streamed layers were pinned in the pack12 wire "
                                  "format by an earlier call; reload the model or set LIA_STREAM_FORMAT=raw")
-            w = ops.weight_ptr_array(st.host_ptr(), m.offsets)
-            kv = kv_state.kv[idx]
-            N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx.data_ptr()),
-                                               ctypes.c_void_p(hy.data_ptr()), ctypes.c_void_p(kv.k), ctypes.c_void_p(kv.v), kv.smax,
-                                               kv.batch, B, T, pos0, 0, threads), "lia_host_layer_forward")
-            hx, hy = hy, hx
-        N.check(lib.lia_memcpy_h2d(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(hx.data_ptr()), hx.numel() * 2), "lia_memcpy_h2d")
+        if host and B * T <= 256:
+            # a decode step: every host layer in ONE OpenMP region (lia_host_layers_forward); the pointer tables are rebuilt only
+            # when a layer's host copy or the caches moved
+            key = (tuple(m.layers[i].host_ptr() for i in host), tuple(kv_state.kv[i].k for i in host))
+            tab = getattr(self, "_host_tables", None)
+            if tab is None or tab[0] != key:
+                n = len(host)
+                wt = (ctypes.c_void_p * (16 * n))()
+                for j, i in enumerate(host):
+                    base = m.layers[i].host_ptr()
+                    for t in range(16):
+                        wt[16 * j + t] = base + m.offsets[t]
+                kt = (ctypes.c_void_p * n)(*[kv_state.kv[i].k for i in host])
+                vt = (ctypes.c_void_p * n)(*[kv_state.kv[i].v for i in host])
+                tab = self._host_tables = (key, wt, kt, vt)
+            kv0 = kv_state.kv[host[0]]
+            where = lib.lia_host_layers_forward(ctypes.byref(m.desc), len(host), tab[1], ctypes.c_void_p(hx), ctypes.c_void_p(hy), tab[2], tab[3],
+                                                kv0.smax, kv0.batch, B, T, pos0, 0, threads)
+            N.check(min(where, 0), "lia_host_layers_forward")
+            if where == 1:
+                hx, hy = hy, hx
+        else:
+            for idx in host:
+                st = m.layers[idx]
+                w = ops.weight_ptr_array(st.host_ptr(), m.offsets)
+                kv = kv_state.kv[idx]
+                N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx), ctypes.c_void_p(hy),
+                                                   ctypes.c_void_p(kv.k), ctypes.c_void_p(kv.v), kv.smax, kv.batch, B, T, pos0, 0, threads),
+                        "lia_host_layer_forward")
+                hx, hy = hy, hx
+        N.check(lib.lia_memcpy_h2d(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(hx), nbytes), "lia_memcpy_h2d")
         return x
 
     def stream_stats(self, reset=False):

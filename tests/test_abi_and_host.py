@@ -233,6 +233,48 @@ def test_host_layer_forward_matches_oracle_policy1(native, oracle, B, T, pos0):
                                     smax, B, B, T, pos0, 0, 1) == native.LIA_ERR_MISSING
 
 
+@pytest.mark.parametrize("n_layers", [1, 2, 3])
+def test_host_layers_forward_equals_layer_by_layer(native, n_layers):
+    """lia_host_layers_forward (the decode step of policy 1 over consecutive layers in ONE OpenMP region, hidden state ping-ponging
+    between two buffers) == lia_host_layer_forward called once per layer: hidden state and every cache bit for bit; the return
+    value names the buffer that holds the result; prefill-sized steps (B * T > 256) are refused."""
+    from lia_amd import ops
+    L = native.lib()
+    if not L.lia_host_has_avx512_bf16():
+        pytest.skip("host without AVX-512-BF16")
+    H, heads, F, B, T, pos0 = 256, 4, 1024, 3, 1, 5
+    d = H // heads
+    smax = pos0 + T + 1
+    desc = ops.make_desc(H, heads, F)
+    Ws = [synth.make_layer(30 + i, H, F, 0.08) for i in range(n_layers)]
+    flat = [[np.ascontiguousarray(W[n]) for n in synth.LAYER_TENSORS] for W in Ws]
+    rs = np.random.RandomState(11)
+    caches = [(synth.f32_to_bf16_bits(rs.standard_normal((smax, B, heads, d)).astype(np.float32)),
+               synth.f32_to_bf16_bits(rs.standard_normal((smax, B, heads, d)).astype(np.float32))) for _ in range(n_layers)]
+    x0 = synth.make_hidden(12, B, T, H)
+    # reference: one call per layer
+    ref_c = [(k.copy(), v.copy()) for k, v in caches]
+    a, b = x0.copy(), np.zeros_like(x0)
+    for i in range(n_layers):
+        arr = (ctypes.c_void_p * 16)(*[w.ctypes.data for w in flat[i]])
+        assert L.lia_host_layer_forward(ctypes.byref(desc), ctypes.byref(arr), a.ctypes.data, b.ctypes.data, ref_c[i][0].ctypes.data,
+                                        ref_c[i][1].ctypes.data, smax, B, B, T, pos0, 0, 3) == 0, L.lia_last_error()
+        a, b = b, a
+    wt = (ctypes.c_void_p * (16 * n_layers))(*[w.ctypes.data for fl in flat for w in fl])
+    kt = (ctypes.c_void_p * n_layers)(*[k.ctypes.data for k, _ in caches])
+    vt = (ctypes.c_void_p * n_layers)(*[v.ctypes.data for _, v in caches])
+    x, y = x0.copy(), np.zeros_like(x0)
+    where = L.lia_host_layers_forward(ctypes.byref(desc), n_layers, wt, x.ctypes.data, y.ctypes.data, kt, vt, smax, B, B, T, pos0, 0, 3)
+    assert where == n_layers % 2, (where, L.lia_last_error())
+    got = y if where == 1 else x
+    assert (got == a).all()
+    for (k, v), (rk, rv) in zip(caches, ref_c):
+        assert (k == rk).all() and (v == rv).all()
+    big = np.zeros((2, 200, H), np.uint16)          # B * T = 400 > 256: not a decode step
+    assert L.lia_host_layers_forward(ctypes.byref(desc), n_layers, wt, big.ctypes.data, big.copy().ctypes.data, kt, vt, 512, 2, 2, 200, 0, 0, 1) == native.LIA_ERR_INVALID
+    assert L.lia_host_layers_forward(ctypes.byref(desc), n_layers, None, x.ctypes.data, y.ctypes.data, kt, vt, smax, B, B, T, pos0, 0, 1) == native.LIA_ERR_MISSING
+
+
 _HOST_LINEAR_CASES = [(64, 1000, 2112, 1, 1, 0), (7, 77, 96, 1, 1, 1), (1, 50, 4096, 0, 0, 0), (130, 130, 320, 1, 0, 1), (64, 1536, 1024, 0, 1, 1),
                       (5, 6, 64, 0, 1, 0), (300, 40, 64, 1, 1, 1)]
 
