@@ -622,6 +622,18 @@ extern "C" int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_b
   return LIA_OK;
 }
 
+// the intermediates of a host layer (ln, q, k, v, attention output, h1: M x H each; f1: M x F), one growing block per CALLING thread
+struct LayerScratch { lia_bf16* p = nullptr; size_t n = 0; ~LayerScratch() { free(p); } };
+static LayerScratch& layer_scratch(size_t need) {
+  static thread_local LayerScratch scratch;
+  if (scratch.n < need) {
+    free(scratch.p);
+    scratch.p = (lia_bf16*)aligned_alloc(64, ((need * sizeof(lia_bf16)) + 63) & ~(size_t)63);
+    scratch.n = scratch.p ? need : 0;
+  }
+  return scratch;
+}
+
 // one decode-sized layer inside an enclosing parallel region (every thread calls it); sc: 6 * mh + M * F bf16 of scratch
 static void host_layer_team(const lia_layer_desc* d, const lia_bf16* const* W, const lia_bf16* x, lia_bf16* y, lia_bf16* kcache,
                             lia_bf16* vcache, int cache_batch, int B, int T, int pos0, int b0, lia_bf16* sc, size_t mh,
@@ -666,15 +678,9 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   const long M = (long)B * T;
   // the intermediates live in one scratch block per calling thread that only ever grows: std::vector zero-filled 9 MB per
   // decode call at the OPT-30B shape (single-threaded, ~3 % of the layer) and paid the page faults again after every free
-  struct Scratch { lia_bf16* p = nullptr; size_t n = 0; ~Scratch() { free(p); } };
-  static thread_local Scratch scratch;
   const size_t mh = ((size_t)M * H + 31) & ~(size_t)31, mf = ((size_t)M * F + 31) & ~(size_t)31, need = 6 * mh + mf;
-  if (scratch.n < need) {
-    free(scratch.p);
-    scratch.p = (lia_bf16*)aligned_alloc(64, need * sizeof(lia_bf16));
-    scratch.n = scratch.p ? need : 0;
-    if (!scratch.p) { lia_set_error("lia_host_layer_forward: out of host memory (%zu bytes of scratch)", need * sizeof(lia_bf16)); return LIA_ERR_MEMORY; }
-  }
+  LayerScratch& scratch = layer_scratch(need);
+  if (!scratch.p) { lia_set_error("lia_host_layer_forward: out of host memory (%zu bytes of scratch)", need * sizeof(lia_bf16)); return LIA_ERR_MEMORY; }
   // (a prefill-sized call -- policy 1 over B * T rows -- gives its block back on return: see the end of the function)
   lia_bf16 *ln = scratch.p, *q = ln + mh, *k = q + mh, *v = k + mh, *ao = v + mh, *h1 = ao + mh, *f1 = h1 + mh;
   static const bool one_region = [] { const char* e = getenv("LIA_HOST_LAYER_REGIONS"); return !(e && atoi(e) != 1); }();   // A/B: 9 = a region per op (r02)
@@ -726,7 +732,7 @@ extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, co
   if (int rc = host_isa_ok("lia_host_layers_forward")) return rc;
   if (n_threads > 0) omp_set_num_threads(n_threads);
   const size_t mh = ((size_t)M * H + 31) & ~(size_t)31, mf = ((size_t)M * F + 31) & ~(size_t)31;
-  lia_bf16* sc = (lia_bf16*)aligned_alloc(64, (6 * mh + mf) * sizeof(lia_bf16));
+  lia_bf16* const sc = layer_scratch(6 * mh + mf).p;     // (fetched by the caller: thread_local)
   if (!sc) { lia_set_error("lia_host_layers_forward: out of host memory"); return LIA_ERR_MEMORY; }
   LiaTeamBarrier bar;
 #pragma omp parallel
@@ -740,7 +746,6 @@ extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, co
       lia_bf16* t = in; in = out; out = t;
     }
   }
-  free(sc);
   return n_layers & 1;
 }
 
