@@ -1,3 +1,6 @@
+"""One opt-125m-shaped decode layer at batch 1 on the host cores (lia_host_layer_forward) over the thread count -- configs[0]'s unit of
+work.  Run it under the launchers' wait policy (OMP_WAIT_POLICY=PASSIVE GOMP_SPINCOUNT=0) to see what the product pays per OpenMP
+region; LIA_HOST_LAYER_REGIONS=9 restores one region per op."""
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, '/root/repo/isca-2025-lia_amd')
