@@ -225,6 +225,14 @@ def parity_sample(sched, model, shape, B, T, threads):
                     "by ~2*sqrt(p) per GEMM at K >= 7168, hence the lower whole-layer identity rate with a bounded error"}
 
 
+def throttle_delta(before):
+    """CFS quota stalls of the container since `before` (hostinfo.cgroup_cpu_throttle()): the host-computed legs run sixteen threads
+    against a sixteen-CPU quota, so a box whose neighbours or helper threads push it over shows up here, not in the kernels"""
+    from lia_amd import hostinfo
+    now = hostinfo.cgroup_cpu_throttle()
+    return {"periods": now[0] - before[0], "throttled_ms": (now[1] - before[1]) / 1e3}
+
+
 def first_divergence(ids_a, ids_b, T, logits_b=None):
     """compare the generated tokens of two legs over their common length -> {"ids_equal", "steps_compared", "first_divergent_step",
     "top2_logit_gap_at_divergence"} (the gap from leg b's logits of that step, row 0)"""
@@ -579,7 +587,7 @@ def main(argv=None):
             and n_gpu < shape.layers:
         try:
             from lia_amd import planner
-            t0 = time.time()
+            t0, thr_a = time.time(), hostinfo.cgroup_cpu_throttle()
             c0, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
                                             planner.Box(host_threads=host_threads,
                                                         wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]))
@@ -589,6 +597,7 @@ def main(argv=None):
             out["value_cooperative"] = B / (sum(tail) / len(tail))
             out["cooperative_leg"] = {"planned_host_layers": c0, "controller": sched.coop_report(), "decode_steps": len(lat_coop) - 1,
                                       "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail), "leg_s": time.time() - t0,
+                                      "cpu_throttle": throttle_delta(thr_a),
                                       "note": "decode layers computed on the host cores never cross the link (build-defined, SURVEY 8 f-3); "
                                               "the count is adjusted online from the measured copy-engine idle time"}
             ids_check["cooperative_vs_headline"] = first_divergence(out_ids, ids_coop, T, logits_coop)
@@ -599,7 +608,7 @@ def main(argv=None):
             # the same split with the other streamed layers' KV cache in HBM (policies 3/3, build-defined): no host attention for the
             # GPU-computed layers; a candidate layer's cache follows it between HBM and the host (KVState.move_cache)
             try:
-                t0 = time.time()
+                t0, thr_a = time.time(), hostinfo.cgroup_cpu_throttle()
                 c3, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
                                                 planner.Box(host_threads=host_threads,
                                                             wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
@@ -610,7 +619,8 @@ def main(argv=None):
                 out["value_cooperative_kv_in_hbm"] = B / (sum(tail) / len(tail))
                 out["cooperative_kv_in_hbm_leg"] = {"planned_host_layers": c3, "controller": sched.coop_report(), "decode_steps": len(lat_kv) - 1,
                                                     "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail),
-                                                    "kv_moved_bytes": sched.kv_moved_bytes, "leg_s": time.time() - t0}
+                                                    "kv_moved_bytes": sched.kv_moved_bytes, "leg_s": time.time() - t0,
+                                                    "cpu_throttle": throttle_delta(thr_a)}
                 ids_check["cooperative_kv_in_hbm_vs_headline"] = first_divergence(out_ids, ids_kv, T, logits_kv)
                 del logits_kv
             except Exception as e:
@@ -622,10 +632,10 @@ def main(argv=None):
         cpu_kwargs.pop("cpu_layers", None)
         product = None
         try:
-            t0 = time.time()
+            t0, thr_a = time.time(), hostinfo.cgroup_cpu_throttle()
             ids_cpu, lat_cpu, logits_cpu = generate(model, ids, max_steps=2 + a.cpu_steps, return_logits=True, **cpu_kwargs)
             product = {"decode_tokens_per_s": B / (sum(lat_cpu[2:]) / len(lat_cpu[2:])), "decode_steps_timed": len(lat_cpu[2:]),
-                       "ms_per_step": 1e3 * sum(lat_cpu[2:]) / len(lat_cpu[2:]), "leg_s": time.time() - t0,
+                       "ms_per_step": 1e3 * sum(lat_cpu[2:]) / len(lat_cpu[2:]), "leg_s": time.time() - t0, "cpu_throttle": throttle_delta(thr_a),
                        "sample": f"generate(prefill_policy=0, decoding_policy=1, gpu_percentage=0): {len(lat_cpu[2:])} full decode steps, every one of the "
                                  f"{shape.layers} layers on the host cores (lia_host_layer_forward: AVX-512-BF16 linears + fp32 attention over the host "
                                  "KV cache, weights read raw from pinned memory); embeddings / final LN / lm_head stay on the GPU; the prefill is the GPU's"}
