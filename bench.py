@@ -597,7 +597,7 @@ def main(argv=None):
             out["value_cooperative"] = B / (sum(tail) / len(tail))
             out["cooperative_leg"] = {"planned_host_layers": c0, "controller": sched.coop_report(), "decode_steps": len(lat_coop) - 1,
                                       "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail), "leg_s": time.time() - t0,
-                                      "cpu_throttle": throttle_delta(thr_a),
+                                      "cpu_throttle": throttle_delta(thr_a), "host_team": sched.host_team_report(),
                                       "note": "decode layers computed on the host cores never cross the link (build-defined, SURVEY 8 f-3); "
                                               "the count is adjusted online from the measured copy-engine idle time"}
             ids_check["cooperative_vs_headline"] = first_divergence(out_ids, ids_coop, T, logits_coop)
@@ -620,7 +620,7 @@ def main(argv=None):
                 out["cooperative_kv_in_hbm_leg"] = {"planned_host_layers": c3, "controller": sched.coop_report(), "decode_steps": len(lat_kv) - 1,
                                                     "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail),
                                                     "kv_moved_bytes": sched.kv_moved_bytes, "leg_s": time.time() - t0,
-                                                    "cpu_throttle": throttle_delta(thr_a)}
+                                                    "cpu_throttle": throttle_delta(thr_a), "host_team": sched.host_team_report()}
                 ids_check["cooperative_kv_in_hbm_vs_headline"] = first_divergence(out_ids, ids_kv, T, logits_kv)
                 del logits_kv
             except Exception as e:
@@ -645,7 +645,7 @@ def main(argv=None):
             product = {"error": f"{type(e).__name__}: {e}"}
         orc = cpu_oracle_sample(shape, B, T, host_threads)
         best = max(orc["decode_tokens_per_s"], product.get("decode_tokens_per_s", 0.0))
-        out["cpu_baseline"] = {"value": best, "unit": "tokens/s", "cores": host_threads, "kind": "port",
+        out["cpu_baseline"] = {"value": best, "unit": "tokens/s", "cores": ((sched.host_team_report() or {}).get("threads", host_threads) if best == product.get("decode_tokens_per_s") else host_threads), "kind": "port",
                                "implementation": ("product host path through generate()" if best == product.get("decode_tokens_per_s") else "oracle restatement, one-layer sample"),
                                "sample": product.get("sample", orc["sample"]),
                                "product_host_path": product, "oracle_port": orc, "prefill_ms": orc["prefill_ms"],

@@ -46,6 +46,33 @@ def default_host_threads(world=1):
     return max(1, n // max(1, world))
 
 
+class HostTeamGovernor:
+    """Threads of the team that computes WHOLE LAYERS back to back (the cooperative split's host layers, policy 1): the attention
+    team's count, or LIA_HOST_LAYER_THREADS.  Sixteen threads busy for hundreds of milliseconds plus the main thread's helpers
+    (HIP's event thread, the spinning stream synchronize) overshoot a sixteen-CPU CFS quota now and then, and the kernel stalls
+    the container for the rest of the period (bench.py reports it per leg: `cpu_throttle`).  With LIA_HOST_TEAM_GOVERNOR=1 the
+    count follows cpu.stat -- two consecutive steps with more than 2 % of their time throttled cost one thread, at most two in
+    all.  OFF by default: three boxes, OPT-30B cooperative legs interleaved -- 15 threads ahead by 6 % on one (174 / 181 vs
+    160 / 173 tokens/s, 320-780 ms throttled per 16-thread leg), 16 threads ahead by 3-5 % on the other two, one of them with
+    750-1100 ms throttled per leg; run-to-run spread is as large as the effect (LABNOTES.md)."""
+
+    def __init__(self, team):
+        env = os.environ.get("LIA_HOST_LAYER_THREADS")
+        self.pinned = bool(env) or os.environ.get("LIA_HOST_TEAM_GOVERNOR", "0") != "1"
+        self.threads = max(1, int(env)) if env else max(1, int(team))
+        self.floor = max(1, self.threads - 2) if self.threads >= 4 else self.threads
+        self.last, self.strikes, self.drops = cgroup_cpu_throttle(), 0, 0
+
+    def after_step(self, step_ms):
+        """one decode step with host-computed layers has ended -> the count for the next one"""
+        now = cgroup_cpu_throttle()
+        throttled_ms, self.last = (now[1] - self.last[1]) / 1e3, now
+        self.strikes = self.strikes + 1 if throttled_ms > 0.02 * step_ms else 0
+        if self.strikes >= 2 and not self.pinned and self.threads > self.floor:
+            self.threads, self.strikes, self.drops = self.threads - 1, 0, self.drops + 1
+        return self.threads
+
+
 def cap_torch_threads(n=None):
     """torch sizes its intra-op thread pool by the CPUs it SEES (128 on the GPU box) -- not by the cgroup quota (16 there).  The
     few CPU tensor ops of the token loop (torch.cat of the ids, greedy_search.py:408) then start a 128-thread team that the quota

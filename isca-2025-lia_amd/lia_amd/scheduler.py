@@ -648,8 +648,12 @@ class OffloadScheduler:
             self._await_all_deliveries()          # (host-blocking: afterwards nothing on the D2H stream reads the holding caches)
             hold = self._hold_caches(B, T, n_gpu)
         if policy == 1 and n_gpu < L:
+            import time
             self._await_kv(kv_state)
+            t_host = time.time()
             x = self._host_layers(x, kv_state, n_gpu, B, T, pos0)  # resident prefix on the GPU, the rest on the CPU
+            if not is_prefill:
+                self._host_team(self.dp.world if self.dp else 1).after_step(1e3 * (time.time() - t_host))
             logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
             ctx.synchronize()
             kv_state.len = pos0 + T
@@ -753,6 +757,8 @@ class OffloadScheduler:
             step_ms = 1e3 * (time.time() - t_fwd0)
             busy = (self.pipe.poll_stats()[1] - busy0) / max(step_ms, 1e-6) if self.pipe else 0.0
             before = coop.host_set()
+            if before:
+                self._host_team(1).after_step(step_ms)                # a throttled container gives a host thread back
             coop.observe(step_ms, min(busy, 1.0))
             after = coop.host_set()
             for li in after - before:                             # newly host-computed: a queued copy of it will never be used
@@ -804,6 +810,10 @@ class OffloadScheduler:
                 raise MemoryError(f"cooperative split: no room for a raw host copy of one layer ({st.nbytes / 2**30:.2f} GiB) in this container")
             coop.restrict(new_max)
 
+    def host_team_report(self):
+        g = getattr(self, "_host_gov", None)
+        return None if g is None else {"threads": g.threads, "dropped": g.drops, "pinned_by_env": g.pinned}
+
     def coop_report(self):
         return self._coop.report() if self._coop is not None else None
 
@@ -829,6 +839,13 @@ class OffloadScheduler:
             return frozenset()
         return frozenset(n_gpu + 1 + int((j + 0.5) * (n_str - 1) / count) for j in range(count))
 
+    def _host_team(self, world=1):
+        """the governor of the whole-layer host team (hostinfo.HostTeamGovernor), created with the attention team's count"""
+        if getattr(self, "_host_gov", None) is None:
+            from . import hostinfo
+            self._host_gov = hostinfo.HostTeamGovernor(getattr(self, "host_threads", None) or hostinfo.default_host_threads(world))
+        return self._host_gov
+
     def _host_decode_layer(self, idx, x, y, kv_state, B, T, pos0):
         """One decode step of layer idx on the host cores (policy 1 for this layer): hidden state GPU -> pinned host by a
         kernel blit, lia_host_layer_forward on the raw host copy of the weights and the host KV cache, result back."""
@@ -844,7 +861,7 @@ class OffloadScheduler:
         N.check(lib.lia_blit(ctypes.c_void_p(hx), ctypes.c_void_p(x.data_ptr()), nbytes, ctypes.c_void_p(ctx.stream)), "lia_blit")
         ctx.synchronize()
         from . import hostinfo
-        threads = getattr(self, "host_threads", None) or hostinfo.default_host_threads(1)
+        threads = self._host_team(1).threads
         w = ops.weight_ptr_array(raw, m.offsets)
         kv = kv_state.kv[idx]
         N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx), ctypes.c_void_p(hy),
@@ -871,7 +888,7 @@ class OffloadScheduler:
         hx, hy, _ = self._host_hidden
         N.check(lib.lia_memcpy_d2h(ctypes.c_void_p(hx), ctypes.c_void_p(x.data_ptr()), nbytes), "lia_memcpy_d2h")
         from . import hostinfo
-        threads = self.host_threads or hostinfo.default_host_threads(self.dp.world if self.dp else 1)
+        threads = self._host_team(self.dp.world if self.dp else 1).threads
         host = list(range(n_gpu, sh.layers))
         for idx in host:
             if m.layers[idx].packed:

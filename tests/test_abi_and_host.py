@@ -164,6 +164,39 @@ def test_hostinfo():
     assert isinstance(hostinfo.cpu_model(), str) and "avx512f" in hostinfo.isa_flags()
 
 
+def test_host_team_governor_gives_threads_back_under_throttling(monkeypatch):
+    """LIA_HOST_TEAM_GOVERNOR=1: the whole-layer host team keeps its count while the container is not throttled, loses one thread
+    after two consecutive steps with > 2 % of their time throttled, two at most; LIA_HOST_LAYER_THREADS pins the count; without
+    the switch the count never moves"""
+    from lia_amd import hostinfo
+    monkeypatch.delenv("LIA_HOST_LAYER_THREADS", raising=False)
+    monkeypatch.setenv("LIA_HOST_TEAM_GOVERNOR", "1")
+    clock = {"us": 0}
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_throttle", lambda: (0, clock["us"]))
+    g = hostinfo.HostTeamGovernor(16)
+    for _ in range(5):
+        assert g.after_step(350.0) == 16                       # quiet box
+    clock["us"] += 20000
+    assert g.after_step(350.0) == 16                           # one throttled step (20 ms of 350) is not a pattern
+    assert g.after_step(350.0) == 16                           # ... and a clean one resets the count
+    for want in (16, 15, 15, 14, 14, 14, 14):                  # two in a row cost a thread; the floor is team - 2
+        clock["us"] += 20000
+        assert g.after_step(350.0) == want
+    assert g.drops == 2
+    assert hostinfo.HostTeamGovernor(2).floor == 2             # tiny teams (a rank of an 8-GPU run) are left alone
+    monkeypatch.setenv("LIA_HOST_LAYER_THREADS", "12")
+    p = hostinfo.HostTeamGovernor(16)
+    for _ in range(4):
+        clock["us"] += 50000
+        assert p.after_step(350.0) == 12
+    monkeypatch.delenv("LIA_HOST_LAYER_THREADS")
+    monkeypatch.delenv("LIA_HOST_TEAM_GOVERNOR")
+    off = hostinfo.HostTeamGovernor(16)
+    for _ in range(4):
+        clock["us"] += 50000
+        assert off.after_step(350.0) == 16                     # the default: the count stays
+
+
 def test_shapes_and_flag_defaults():
     from lia_amd.model import SHAPES, resolve_shape
     s = resolve_shape("facebook/opt-30b")
