@@ -343,8 +343,8 @@ class CoopController:
     off; the planner's seed is usually 0-3 counts off, and strides 4 / 2 / 1 spent two steps at a count 40 % slower plus 2 GB of
     cache moves on the first probe: 3.2-3.9 % of a 31-step run in the synthetic box of tests/test_host_logic.py against 2.4-3.2 %); a count's value is the MINIMUM of its last `keep` samples
     (spikes only ever add time).  One settle step after every change (queued copies still reflect the old set).  Converged, it
-    stays on the centre -- single slow steps move nothing -- and searches again from stride 2 after `expire` steps or when the
-    centre's own recent steps are all > 5 % above the value it converged on (the box changed); every `probe_every` steps it
+    stays on the centre -- single slow steps move nothing -- and searches again (+-1 first) after `expire` steps or when six
+    steps in a row run > 5 % above the value it converged on (the box changed); every `probe_every` steps it
     re-measures centre +- 1 (a spike on a candidate's single sample can end the search one or two counts off; the second look
     costs five steps at a neighbouring count and repairs that)."""
 
@@ -356,7 +356,7 @@ class CoopController:
         self.expire, self.keep, self.probe_every = expire, keep, probe_every
         self.samples = {}             # c -> [(step, ms), ...] the last `keep`
         self.centre, self.stride_i, self.pending, self.direction, self.run = self.c, 0, None, 0, 0
-        self.converged_at, self.converged_ms, self.c_conv, self.last_probe, self.probing = None, None, None, 0, False
+        self.converged_at, self.converged_ms, self.c_conv, self.last_probe, self.probing, self.slow = None, None, None, 0, False, 0
         self.settle, self.step, self.moves, self.searches = 1, 0, 0, 1
         self.trace = []               # (step, c, ms, link busy share)
 
@@ -402,13 +402,14 @@ class CoopController:
             return self.c
         self.samples[self.c] = (self.samples.get(self.c, []) + [(self.step, step_ms)])[-self.keep:]
         if self.converged_at is not None and not self.probing:
-            recent = [ms for _, ms in self.samples[self.c]]
-            drifted = len(recent) >= self.keep and min(recent) > 1.05 * self.converged_ms
-            if self.step - self.converged_at >= self.expire or drifted:
-                # search again around where we are: everything measured before is stale
+            self.slow = self.slow + 1 if step_ms > 1.05 * self.converged_ms else 0
+            if self.step - self.converged_at >= self.expire or self.slow >= 2 * self.keep:
+                # search again around where we are, +-1 first (a move that pays carries on, twice as far after two): everything
+                # measured before is stale.  (Six slow steps in a row, not three: a noise episode of 3-4 steps restarted the
+                # search with a stride-3 probe 25 % off the optimum -- results/r03_final10_*.)
                 self.samples = {self.c: self.samples[self.c][-1:]}
-                self.centre, self.stride_i, self.pending, self.direction, self.run = self.c, 0, None, 0, 0
-                self.converged_at, self.searches = None, self.searches + 1
+                self.centre, self.stride_i, self.pending, self.direction, self.run = self.c, len(self.STRIDES) - 1, None, 0, 0
+                self.converged_at, self.searches, self.slow = None, self.searches + 1, 0
             elif self.step - self.last_probe >= self.probe_every:
                 self.stride_i, self.probing = len(self.STRIDES) - 1, True
                 self.pending = self._candidates(busy_share, again=True)
