@@ -72,6 +72,7 @@ struct lia_ctx {
   char* host_stage;          // pinned: q|k|v and attention output of the policy-2 round trip
   size_t host_stage_bytes;
   int host_threads;
+  hipEvent_t sync_ev[2] = {nullptr, nullptr};   // LIA_BLOCKING_SYNC=1: the host sleeps in lia_ctx_synchronize instead of spinning
   long last_rows, last_slab_rows;  // workspace layout of the previous layer call
   // live kernel timing for bench.py's roofline object (lia_prof_*)
   bool prof_on;
@@ -161,6 +162,8 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
   if (c->gemm_tickets) (void)hipFree(c->gemm_tickets);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->deliver_t0) { (void)hipEventDestroy(c->deliver_t0); (void)hipEventDestroy(c->deliver_t1); }
+  for (int i = 0; i < 2; ++i)
+    if (c->sync_ev[i]) (void)hipEventDestroy(c->sync_ev[i]);
   if (c->deliver_events) {
     for (hipEvent_t e : *c->deliver_events) (void)hipEventDestroy(e);
     delete c->deliver_events;
@@ -179,17 +182,26 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
 extern "C" void* lia_ctx_compute_stream(lia_ctx* c) { return c ? (void*)c->compute : nullptr; }
 extern "C" int lia_ctx_serialized(lia_ctx* c) { return c && c->serialized ? 1 : 0; }
 
+// A/B knob (LABNOTES.md r03): hipStreamSynchronize spins on this image, one CPU of the container's CFS quota for as long as the
+// GPU works; with LIA_BLOCKING_SYNC=1 the wait is a blocking event instead (the thread sleeps, +20-50 us to wake).
+static int ctx_wait(lia_ctx* c, int which, hipStream_t st) {
+  static const bool blocking = [] { const char* e = getenv("LIA_BLOCKING_SYNC"); return e && atoi(e) == 1; }();
+  if (!blocking) { HIP_TRY(hipStreamSynchronize(st)); return LIA_OK; }
+  if (!c->sync_ev[which]) HIP_TRY(hipEventCreateWithFlags(&c->sync_ev[which], hipEventBlockingSync | hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->sync_ev[which], st));
+  HIP_TRY(hipEventSynchronize(c->sync_ev[which]));
+  return LIA_OK;
+}
+
 extern "C" int lia_ctx_synchronize(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
-  HIP_TRY(hipStreamSynchronize(c->compute));
-  HIP_TRY(hipStreamSynchronize(c->d2h));
-  return LIA_OK;
+  if (int rc = ctx_wait(c, 0, c->compute)) return rc;
+  return ctx_wait(c, 1, c->d2h);
 }
 
 extern "C" int lia_ctx_synchronize_compute(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
-  HIP_TRY(hipStreamSynchronize(c->compute));
-  return LIA_OK;
+  return ctx_wait(c, 0, c->compute);
 }
 
 extern "C" int lia_ctx_set_host_threads(lia_ctx* c, int n) {
