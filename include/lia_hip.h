@@ -201,6 +201,31 @@ int lia_llama_embed(const int64_t* ids, const lia_bf16* tok, lia_bf16* y, int B,
 int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H, const lia_bf16* normw, const lia_bf16* lm,
                       int vocab, float eps, int suppress_token, lia_bf16* logits, int64_t* next_ids, void* stream);
 
+/* ---- decode step over a run of HBM-resident layers (build-defined fast path of the per-layer loop) ---------------------
+ * The reference runs its resident layers one torch op at a time (lia/modeling_opt.py:1246-1260 -> decoder.py:172-335,
+ * attentions.py:393-529: ~10 launches per layer).  These two entry points run n_layers CONSECUTIVE resident layers of one decode
+ * step (T == 1, KV cache in HBM = policy 3 arithmetic) as, per layer, ONE attention launch and ONE persistent "chain" launch
+ * (csrc/lia_chain.hip: out-proj, norm, MLP, the next layer's norm and q|k|v projection with their split-K combines inside one
+ * kernel that keeps its weight stream running across the steps).  Same arithmetic and rounding points as
+ * lia_layer_forward(policy 3) / lia_llama_layer_forward called layer by layer; shapes or weight layouts the chain does not
+ * cover (rows > 128, q|k|v or gate|up not adjacent) fall back to exactly those calls.
+ *   weights: n_layers x 16 (OPT) / n_layers x 9 (Llama) device pointers, layer-major;  kv: n_layers pointers to device caches
+ *   x: [B, 1, H] input (never written);  y: [B, 1, H] result;  B <= cache batch, rows [0, B) of the caches are served
+ * A grid barrier of a chain launch that cannot complete (bounded spins) makes the next lia_ctx_synchronize* fail with
+ * LIA_ERR_HIP instead of handing garbage on. */
+int lia_decode_layers(lia_ctx* ctx, const lia_layer_desc* d, int n_layers, const void* const* weights, const lia_bf16* x,
+                      lia_bf16* y, lia_kv* const* kv, int B, int pos0, void* stream);
+int lia_llama_decode_layers(lia_ctx* ctx, const lia_llama_desc* d, int n_layers, const void* const* weights, const lia_bf16* x,
+                            lia_bf16* y, lia_kv* const* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int pos0,
+                            void* stream);
+/* A/B and test switches.  lia_set_fused_decode(0): the two entry points above take the layer-by-layer route (also env
+ * LIA_FUSED_DECODE=0).  lia_gemm_set_split_policy(1): the per-op decode GEMMs cut K exactly as the chain does for the same
+ * shape, so that the two routes add the same products in the same order and agree bit for bit (also env
+ * LIA_GEMM_SPLIT_POLICY=1; 0 = the per-launch heuristics).  lia_chain_launch_count: chain launches since the library was loaded. */
+void lia_set_fused_decode(int on);
+void lia_gemm_set_split_policy(int policy);
+long lia_chain_launch_count(void);
+
 /* ---- host side of the cooperative policies -------------------------------------------------------
  * Indirect-access-KV masked MHA, csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp:513-842: fp32
  * scores / softmax / weighted sum over a host cache, new K/V rows written in place.  q,k,v: [B,T,h*d]

@@ -12,6 +12,7 @@
 
 #include "../../include/lia_hip.h"
 #include "lia_common.h"
+#include "lia_chain.h"
 
 // kernels' host launchers
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
@@ -101,7 +102,16 @@ struct lia_ctx {
   // on this context copies and decodes on it too, so every event handshake is trivially ordered.  Results must not change; if
   // they do, a cross-stream ordering is missing (the role torch.cuda.synchronize() plays at lia/modeling_opt.py:1339,1528).
   bool serialized;
+  // persistent decode chain (lia_chain.hip): barrier-counter blocks (one per launch, zeroed in bulk when the ring wraps), the
+  // host-mapped word a barrier that gave up sets, the CU count (= workgroups of a chain launch), a third hidden-state buffer
+  unsigned* chain_sync;
+  long chain_launches;
+  unsigned* chain_err_host;
+  int n_cu;
+  char* chain_tmp;
+  size_t chain_tmp_bytes;
 };
+#define LIA_CHAIN_SYNC_BLOCKS 256
 
 extern "C" int lia_ctx_chain_next_norm(lia_ctx* c, const lia_bf16* g, const lia_bf16* b) {
   if (!c || !g) return LIA_ERR_INVALID;
@@ -145,6 +155,11 @@ extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out)
   if (workspace_bytes) HIP_TRY(hipMalloc((void**)&c->ws, workspace_bytes));
   HIP_TRY(hipMalloc((void**)&c->gemm_tickets, 16384 * sizeof(unsigned)));
   HIP_TRY(hipMemset(c->gemm_tickets, 0, 16384 * sizeof(unsigned)));
+  HIP_TRY(hipMalloc((void**)&c->chain_sync, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES));
+  HIP_TRY(hipMemset(c->chain_sync, 0, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES));
+  HIP_TRY(hipHostMalloc((void**)&c->chain_err_host, 64, hipHostMallocMapped));
+  *c->chain_err_host = 0u;
+  c->n_cu = lia_chain_cu_count(device);
   *out = c;
   return LIA_OK;
 }
@@ -160,6 +175,9 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
   }
   if (c->ws) (void)hipFree(c->ws);
   if (c->gemm_tickets) (void)hipFree(c->gemm_tickets);
+  if (c->chain_sync) (void)hipFree(c->chain_sync);
+  if (c->chain_err_host) (void)hipHostFree(c->chain_err_host);
+  if (c->chain_tmp) (void)hipFree(c->chain_tmp);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->deliver_t0) { (void)hipEventDestroy(c->deliver_t0); (void)hipEventDestroy(c->deliver_t1); }
   for (int i = 0; i < 2; ++i)
@@ -193,15 +211,28 @@ static int ctx_wait(lia_ctx* c, int which, hipStream_t st) {
   return LIA_OK;
 }
 
+// a grid barrier of a persistent decode-chain launch gave up (lia_chain.hip: every spin is bounded): the step's results are
+// garbage -- fail loudly at the next synchronisation point instead of handing them on
+static int chain_check(lia_ctx* c) {
+  if (c->chain_err_host && *c->chain_err_host) {
+    lia_set_error("decode chain: grid barrier 0x%x timed out (a workgroup of the persistent launch was not resident?)", *c->chain_err_host);
+    *c->chain_err_host = 0u;
+    return LIA_ERR_HIP;
+  }
+  return LIA_OK;
+}
+
 extern "C" int lia_ctx_synchronize(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
   if (int rc = ctx_wait(c, 0, c->compute)) return rc;
-  return ctx_wait(c, 1, c->d2h);
+  if (int rc = ctx_wait(c, 1, c->d2h)) return rc;
+  return chain_check(c);
 }
 
 extern "C" int lia_ctx_synchronize_compute(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
-  return ctx_wait(c, 0, c->compute);
+  if (int rc = ctx_wait(c, 0, c->compute)) return rc;
+  return chain_check(c);
 }
 
 extern "C" int lia_ctx_set_host_threads(lia_ctx* c, int n) {
@@ -971,6 +1002,315 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
   if (rc) return rc;
   lia_argmax_launch(logits, next_ids, B, vocab, suppress_token, st);
   HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode step over a run of HBM-resident layers: per layer ONE attention launch and ONE persistent chain launch (lia_chain.hip)
+// ------------------------------------------------------------------------------------------------
+// A/B switch (tests, tools): LIA_FUSED_DECODE=0 or lia_set_fused_decode(0) runs the same layers through the per-layer entry points
+static int g_fused_decode = [] { const char* e = getenv("LIA_FUSED_DECODE"); return (e && !strcmp(e, "0")) ? 0 : 1; }();
+extern "C" void lia_set_fused_decode(int on) { g_fused_decode = on ? 1 : 0; }
+static long g_chain_launches = 0;      // chain launches since the library was loaded (tests assert the route was taken)
+extern "C" long lia_chain_launch_count(void) { return g_chain_launches; }
+
+static void ch_op_gemm(LiaChainOp& o, const LiaChainPlan& p, const bf16_t* x, long ldx, const bf16_t* W, int M, int N, int K, float* slab) {
+  memset(&o, 0, sizeof(o));
+  o.kind = LIA_CH_GEMM;
+  o.M = M; o.N = N; o.K = K;
+  o.x = x; o.ldx = ldx; o.W = W; o.ldw = K;
+  o.bn = p.bn; o.split = p.split; o.cps = p.cps; o.nchunks = K / 64;
+  o.n_items = ((N + p.bn - 1) / p.bn) * p.split;
+  o.direct = LIA_CH_DIRECT_NONE;
+  o.slab = slab; o.slices = p.split;
+}
+static void ch_op_reduce(LiaChainOp& o, int kind, const LiaChainOp& g, const LiaEpilogue& ep, const LiaOutMap& om, const LiaPost* post) {
+  memset(&o, 0, sizeof(o));
+  o.kind = kind;
+  o.M = g.M; o.N = g.N; o.K = g.K;
+  o.slab = g.slab; o.slices = g.slices;
+  o.ep = ep; o.om = om;
+  if (post) o.post = *post;
+}
+
+static int chain_submit(lia_ctx* ctx, const LiaChainProgram& prog, int M, int pos0, double w_bytes, double flops, hipStream_t st) {
+  const long n = ctx->chain_launches++;
+  const int blk = (int)(n % LIA_CHAIN_SYNC_BLOCKS);
+  if (n > 0 && blk == 0) HIP_TRY(hipMemsetAsync(ctx->chain_sync, 0, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES, st));   // every earlier launch is ahead of it on `st`
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool timed = ctx->prof_on && ctx->prof_recs->size() < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
+  if (timed) {
+    const size_t i = ctx->prof_recs->size();
+    e0 = (*ctx->prof_events)[2 * i];
+    e1 = (*ctx->prof_events)[2 * i + 1];
+    HIP_TRY(hipEventRecord(e0, st));
+  }
+  if (lia_chain_launch(&prog, M, ctx->chain_sync + (size_t)blk * (LIA_CHAIN_SYNC_BYTES / 4), ctx->chain_err_host, pos0, ctx->n_cu, st)) {
+    lia_set_error("decode chain: launch refused (M=%d, %d steps)", M, prog.n_ops);
+    return LIA_ERR_INVALID;
+  }
+  if (timed) {
+    HIP_TRY(hipEventRecord(e1, st));
+    ctx->prof_recs->push_back({1, w_bytes, flops});
+  }
+  ++g_chain_launches;
+  HIP_TRY(hipGetLastError());
+  return LIA_OK;
+}
+
+static int chain_tmp_buffer(lia_ctx* ctx, size_t bytes, bf16_t** out) {
+  if (ctx->chain_tmp_bytes < bytes) {
+    HIP_TRY(hipStreamSynchronize(ctx->compute));
+    if (ctx->chain_tmp) (void)hipFree(ctx->chain_tmp);
+    ctx->chain_tmp = nullptr; ctx->chain_tmp_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&ctx->chain_tmp, bytes));
+    ctx->chain_tmp_bytes = bytes;
+  }
+  *out = (bf16_t*)ctx->chain_tmp;
+  return LIA_OK;
+}
+
+// hidden state h_l (the input of layer l; h_n = the result): h_0 = x, never written; h_n = y; in between y and the context's
+// third buffer alternate so that a layer never writes the buffer it reads
+static inline bf16_t* hidden_of(int l, int n, const bf16_t* x, bf16_t* y, bf16_t* t) { return l == 0 ? (bf16_t*)x : (((n - l) & 1) ? t : y); }
+
+extern "C" int lia_llama_decode_layers(lia_ctx* ctx, const lia_llama_desc* d, int n_layers, const void* const* weights, const lia_bf16* x,
+                                       lia_bf16* y, lia_kv* const* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int pos0,
+                                       void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  int rc = check_llama_desc(d);
+  if (rc) return rc;
+  if (n_layers <= 0 || !weights || !x || !y || !kv || !cos_table || !sin_table) { lia_set_error("lia_llama_decode_layers: NULL argument"); return LIA_ERR_MISSING; }
+  for (int l = 0; l < n_layers; ++l) {
+    if (!kv[l] || !kv[l]->k || !kv[l]->v) { lia_set_error("lia_llama_decode_layers: kv[%d] is NULL", l); return LIA_ERR_MISSING; }
+    if (!kv[l]->on_device || B <= 0 || B > kv[l]->batch || pos0 < 0 || pos0 + 1 > kv[l]->smax) {
+      lia_set_error("lia_llama_decode_layers: B=%d pos0=%d vs cache %d batch=%d smax=%d on_device=%d", B, pos0, l, kv[l]->batch, kv[l]->smax, kv[l]->on_device);
+      return LIA_ERR_INVALID;
+    }
+    for (int i = 0; i < 9; ++i)
+      if (!weights[l * 9 + i]) { lia_set_error("lia_llama_decode_layers: weights[%d][%d] is NULL", l, i); return LIA_ERR_MISSING; }
+  }
+  const int H = d->hidden, F = d->ffn, hd = H / d->heads, KD = d->kv_heads * hd, G = d->heads / d->kv_heads, M = B;
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* tmp = nullptr;
+  rc = chain_tmp_buffer(ctx, (size_t)M * H * 2, &tmp);
+  if (rc) return rc;
+  const bf16_t* const* Wall = (const bf16_t* const*)weights;
+
+  // the fused route needs the packed layout of lia_llama_pack_offsets (q | k | v and gate | up adjacent, gate / up rows
+  // interleaved) and a geometry the chain kernels have; anything else runs layer by layer
+  bool fused = g_fused_decode && lia_chain_supported(M) == 0 && G + 2 <= LIA_OUT_SEGS && d->gu_block == LIA_GU_BLOCK && ctx->n_cu > 0;
+  for (int l = 0; fused && l < n_layers; ++l) {
+    const bf16_t* const* W = Wall + l * 9;
+    fused = W[2] == W[1] + (size_t)H * H && W[3] == W[2] + (size_t)KD * H && W[7] == W[6] + (size_t)F * H;
+  }
+  LiaChainPlan p_qkv, p_o, p_gu, p_down;
+  if (fused)
+    fused = !lia_chain_plan_gemm(M, H + 2 * KD, H, 0, ctx->n_cu, &p_qkv) && !lia_chain_plan_gemm(M, H, H, 0, ctx->n_cu, &p_o) &&
+            !lia_chain_plan_gemm(M, 2 * F, H, 1, ctx->n_cu, &p_gu) && !lia_chain_plan_gemm(M, H, F, 0, ctx->n_cu, &p_down);
+  if (!fused) {
+    for (int l = 0; l < n_layers; ++l) {
+      if (l + 1 < n_layers) lia_ctx_chain_next_norm(ctx, Wall[(l + 1) * 9], nullptr);
+      rc = llama_layer_forward_impl(ctx, d, (const void* const*)(Wall + l * 9), hidden_of(l, n_layers, x, y, tmp), hidden_of(l + 1, n_layers, x, y, tmp), kv[l],
+                                    cos_table, sin_table, B, 1, pos0, 0, stream, 0);
+      if (rc) return rc;
+    }
+    return LIA_OK;
+  }
+
+  const LlamaWs w = llama_ws(d, M);
+  if (w.total > ctx->ws_bytes) { lia_set_error("lia_llama_decode_layers: workspace %zu < %zu", ctx->ws_bytes, w.total); return LIA_ERR_MEMORY; }
+  char* ws = ctx->ws;
+  bf16_t *ln = (bf16_t*)(ws + w.ln), *qb = (bf16_t*)(ws + w.q), *ao = (bf16_t*)(ws + w.attn), *h1 = (bf16_t*)(ws + w.h1), *act = (bf16_t*)(ws + w.act);
+  float* slab = (float*)(ws + w.gemm);
+  ctx->normed_src = nullptr; ctx->chain_armed = false;
+  const LiaEpilogue none{nullptr, nullptr, 0, 0, 0};
+  const int NQ = H + 2 * KD;
+
+  auto qkv_steps = [&](LiaChainProgram& P, const bf16_t* const* W, lia_kv* c) {
+    // q | k | v projection of the layer with weights W from `ln`, RoPE on the q and k heads, k / v rows into the cache
+    LiaChainOp& g = P.op[P.n_ops++];
+    ch_op_gemm(g, p_qkv, ln, H, W[1], M, NQ, H, slab);
+    LiaOutMap om;
+    memset(&om, 0, sizeof(om));
+    for (int j = 0; j < G; ++j) { om.base[j] = qb + (size_t)j * KD; om.ld[j] = H; }
+    om.base[G] = c->k; om.base[G + 1] = c->v; om.ld[G] = om.ld[G + 1] = KD; om.cache_mode[G] = om.cache_mode[G + 1] = 1;
+    om.seg_n = KD; om.T = 1; om.Bc = c->batch; om.b0 = 0; om.pos0 = pos0;
+    LiaPost post{};
+    post.kind = LIA_POST_ROPE; post.cos_t = cos_table; post.sin_t = sin_table; post.rot_heads = d->heads + d->kv_heads; post.hd = hd;
+    post.pos0 = pos0; post.T = 1;
+    LiaChainOp& r = P.op[P.n_ops++];
+    ch_op_reduce(r, LIA_CH_REDUCE_MAP, g, none, om, &post);
+    r.use_pos0 = 1;
+  };
+  const double wb_qkv = 2.0 * NQ * H, wb_layer = 2.0 * ((double)H * H + 2.0 * F * H + (double)H * F);
+
+  // layer 0's input norm and q | k | v projection
+  lia_rmsnorm_launch(x, H, Wall[0], ln, H, M, H, d->rms_eps, st);
+  {
+    LiaChainProgram P;
+    memset(&P, 0, sizeof(P));
+    qkv_steps(P, Wall, kv[0]);
+    rc = chain_submit(ctx, P, M, pos0, wb_qkv, 2.0 * M * NQ * H, st);
+    if (rc) return rc;
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    const bf16_t* const* W = Wall + l * 9;
+    const bf16_t* hin = hidden_of(l, n_layers, x, y, tmp);
+    bf16_t* hout = hidden_of(l + 1, n_layers, x, y, tmp);
+    if (lia_attn_decode_launch(qb, H, kv[l]->k, kv[l]->v, ao, H, B, pos0 + 1, d->heads, d->kv_heads, hd, kv[l]->batch, 0, 1, st)) {
+      lia_set_error("llama attention: unsupported head_dim %d / S %d", hd, pos0 + 1);
+      return LIA_ERR_INVALID;
+    }
+    LiaChainProgram P;
+    memset(&P, 0, sizeof(P));
+    {  // o_proj + residual -> h1, post-attention RMSNorm -> ln
+      LiaChainOp& g = P.op[P.n_ops++];
+      ch_op_gemm(g, p_o, ao, H, W[4], M, H, H, slab);
+      LiaEpilogue ep{nullptr, hin, H, 0, 0};
+      LiaPost post{};
+      post.kind = LIA_POST_RMSNORM; post.g = W[5]; post.eps = d->rms_eps; post.out = ln; post.ldo = H;
+      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(h1, H, H), &post);
+    }
+    {  // gate | up in one slice, act = silu(gate) * up written by the tile's epilogue
+      LiaChainOp& g = P.op[P.n_ops++];
+      ch_op_gemm(g, p_gu, ln, H, W[6], M, 2 * F, H, nullptr);
+      g.direct = LIA_CH_DIRECT_GLU;
+      g.ep = none; g.ep.glu = 1;
+      g.om = plain_out(act, F, F);
+    }
+    {  // down_proj + residual -> the layer's output, and the NEXT layer's input RMSNorm -> ln
+      LiaChainOp& g = P.op[P.n_ops++];
+      ch_op_gemm(g, p_down, act, F, W[8], M, H, F, slab);
+      LiaEpilogue ep{nullptr, h1, H, 0, 0};
+      LiaPost post{};
+      if (l + 1 < n_layers) { post.kind = LIA_POST_RMSNORM; post.g = Wall[(l + 1) * 9]; post.eps = d->rms_eps; post.out = ln; post.ldo = H; }
+      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(hout, H, H), &post);
+    }
+    double wb = wb_layer, fl = 2.0 * M * ((double)H * H + 2.0 * F * H + (double)H * F);
+    if (l + 1 < n_layers) { qkv_steps(P, Wall + (l + 1) * 9, kv[l + 1]); wb += wb_qkv; fl += 2.0 * M * NQ * H; }
+    rc = chain_submit(ctx, P, M, pos0, wb, fl, st);
+    if (rc) return rc;
+  }
+  return LIA_OK;
+}
+
+// the OPT counterpart: policy 3 (everything on the GPU, KV cache in HBM) for n_layers consecutive resident layers, T == 1 --
+// the loop over resident layers of OPTDecoder.forward (lia/modeling_opt.py:1246-1260) with decoder.py:172-335 /
+// attentions.py:393-529 per layer
+extern "C" int lia_decode_layers(lia_ctx* ctx, const lia_layer_desc* d, int n_layers, const void* const* weights, const lia_bf16* x,
+                                 lia_bf16* y, lia_kv* const* kv, int B, int pos0, void* stream) {
+  if (!ctx) return LIA_ERR_INVALID;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (n_layers <= 0 || !weights || !x || !y || !kv) { lia_set_error("lia_decode_layers: NULL argument"); return LIA_ERR_MISSING; }
+  for (int l = 0; l < n_layers; ++l) {
+    if (!kv[l] || !kv[l]->k || !kv[l]->v) { lia_set_error("lia_decode_layers: kv[%d] is NULL", l); return LIA_ERR_MISSING; }
+    if (!kv[l]->on_device || B <= 0 || B > kv[l]->batch || pos0 < 0 || pos0 + 1 > kv[l]->smax) {
+      lia_set_error("lia_decode_layers: B=%d pos0=%d vs cache %d batch=%d smax=%d on_device=%d", B, pos0, l, kv[l]->batch, kv[l]->smax, kv[l]->on_device);
+      return LIA_ERR_INVALID;
+    }
+    for (int i = 0; i < 16; ++i)
+      if (!weights[l * 16 + i]) { lia_set_error("lia_decode_layers: weights[%d][%d] is NULL", l, i); return LIA_ERR_MISSING; }
+  }
+  const int H = d->hidden, F = d->ffn, hd = H / d->heads, M = B;
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* tmp = nullptr;
+  rc = chain_tmp_buffer(ctx, (size_t)M * H * 2, &tmp);
+  if (rc) return rc;
+  const bf16_t* const* Wall = (const bf16_t* const*)weights;
+  bool fused = g_fused_decode && lia_chain_supported(M) == 0 && ctx->n_cu > 0;
+  for (int l = 0; fused && l < n_layers; ++l) {
+    const bf16_t* const* W = Wall + l * 16;
+    fused = (W[4] == W[2] + (size_t)H * H) && (W[6] == W[4] + (size_t)H * H) && (W[5] == W[3] + H) && (W[7] == W[5] + H);
+  }
+  LiaChainPlan p_qkv, p_o, p_fc1, p_fc2;
+  if (fused)
+    fused = !lia_chain_plan_gemm(M, 3 * H, H, 0, ctx->n_cu, &p_qkv) && !lia_chain_plan_gemm(M, H, H, 0, ctx->n_cu, &p_o) &&
+            !lia_chain_plan_gemm(M, F, H, 0, ctx->n_cu, &p_fc1) && !lia_chain_plan_gemm(M, H, F, 0, ctx->n_cu, &p_fc2);
+  if (!fused) {
+    for (int l = 0; l < n_layers; ++l) {
+      if (l + 1 < n_layers) lia_ctx_chain_next_norm(ctx, Wall[(l + 1) * 16], Wall[(l + 1) * 16 + 1]);
+      rc = layer_forward_impl(ctx, d, 3, (const void* const*)(Wall + l * 16), hidden_of(l, n_layers, x, y, tmp), hidden_of(l + 1, n_layers, x, y, tmp), kv[l], B, 1,
+                              pos0, 0, stream, 0);
+      if (rc) return rc;
+    }
+    return LIA_OK;
+  }
+
+  const WsLayout w = ws_layout(d, M, M);
+  if (w.total > ctx->ws_bytes) { lia_set_error("lia_decode_layers: workspace %zu < %zu", ctx->ws_bytes, w.total); return LIA_ERR_MEMORY; }
+  for (int i = 0; i < 2; ++i)                       // a K/V delivery of an earlier (policy 0) call may still drain from the workspace
+    if (ctx->slab_used[i]) HIP_TRY(hipStreamWaitEvent(st, ctx->slab_done[i], 0));
+  ctx->last_rows = -1;
+  char* ws = ctx->ws;
+  bf16_t *ln = (bf16_t*)(ws + w.ln), *qb = (bf16_t*)(ws + w.q), *ao = (bf16_t*)(ws + w.attn), *h1 = (bf16_t*)(ws + w.h1), *f1 = (bf16_t*)(ws + w.f1);
+  float* slab = (float*)(ws + w.gemm);
+  ctx->normed_src = nullptr; ctx->chain_armed = false;
+  const float eps = d->ln_eps;
+
+  auto qkv_steps = [&](LiaChainProgram& P, const bf16_t* const* W, lia_kv* c) {
+    LiaChainOp& g = P.op[P.n_ops++];
+    ch_op_gemm(g, p_qkv, ln, H, W[2], M, 3 * H, H, slab);
+    LiaEpilogue ep{W[3], nullptr, 0, 0, 0};
+    LiaOutMap om;
+    memset(&om, 0, sizeof(om));
+    om.base[0] = qb; om.base[1] = c->k; om.base[2] = c->v;
+    om.ld[0] = om.ld[1] = om.ld[2] = H;
+    om.cache_mode[1] = om.cache_mode[2] = 1;
+    om.seg_n = H; om.T = 1; om.Bc = c->batch; om.b0 = 0; om.pos0 = pos0;
+    LiaChainOp& r = P.op[P.n_ops++];
+    ch_op_reduce(r, LIA_CH_REDUCE_MAP, g, ep, om, nullptr);
+    r.use_pos0 = 1;
+  };
+  const double wb_qkv = 2.0 * 3.0 * H * H, wb_layer = 2.0 * ((double)H * H + 2.0 * (double)F * H);
+
+  lia_layernorm_launch(x, H, Wall[0], Wall[1], ln, H, M, H, eps, st);
+  {
+    LiaChainProgram P;
+    memset(&P, 0, sizeof(P));
+    qkv_steps(P, Wall, kv[0]);
+    rc = chain_submit(ctx, P, M, pos0, wb_qkv, 2.0 * M * 3.0 * H * H, st);
+    if (rc) return rc;
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    const bf16_t* const* W = Wall + l * 16;
+    const bf16_t* hin = hidden_of(l, n_layers, x, y, tmp);
+    bf16_t* hout = hidden_of(l + 1, n_layers, x, y, tmp);
+    if (lia_attn_decode_launch(qb, H, kv[l]->k, kv[l]->v, ao, H, B, pos0 + 1, d->heads, d->heads, hd, kv[l]->batch, 0, 0, st)) {
+      lia_set_error("attention: unsupported head_dim %d / S %d", hd, pos0 + 1);
+      return LIA_ERR_INVALID;
+    }
+    LiaChainProgram P;
+    memset(&P, 0, sizeof(P));
+    {  // out-proj + bias, residual -> h1 (decoder.py:225-229); LN2 -> ln (:268-276)
+      LiaChainOp& g = P.op[P.n_ops++];
+      ch_op_gemm(g, p_o, ao, H, W[8], M, H, H, slab);
+      LiaEpilogue ep{W[9], hin, H, 0, 0};
+      LiaPost post{};
+      post.kind = LIA_POST_LAYERNORM; post.g = W[10]; post.b = W[11]; post.eps = eps; post.out = ln; post.ldo = H;
+      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(h1, H, H), &post);
+    }
+    {  // fc1 + bias + relu -> f1 (:282-285)
+      LiaChainOp& g = P.op[P.n_ops++];
+      ch_op_gemm(g, p_fc1, ln, H, W[12], M, F, H, slab);
+      LiaEpilogue ep{W[13], nullptr, 0, 1, 0};
+      if (p_fc1.split == 1) { g.direct = LIA_CH_DIRECT_PLAIN; g.slab = nullptr; g.ep = ep; g.om = plain_out(f1, F, F); }
+      else ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_MAP, g, ep, plain_out(f1, F, F), nullptr);
+    }
+    {  // fc2 + bias, residual -> the layer's output (:306-310); the NEXT layer's LN1 -> ln
+      LiaChainOp& g = P.op[P.n_ops++];
+      ch_op_gemm(g, p_fc2, f1, F, W[14], M, H, F, slab);
+      LiaEpilogue ep{W[15], h1, H, 0, 0};
+      LiaPost post{};
+      if (l + 1 < n_layers) { post.kind = LIA_POST_LAYERNORM; post.g = Wall[(l + 1) * 16]; post.b = Wall[(l + 1) * 16 + 1]; post.eps = eps; post.out = ln; post.ldo = H; }
+      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(hout, H, H), &post);
+    }
+    double wb = wb_layer, fl = 2.0 * M * ((double)H * H + 2.0 * (double)F * H);
+    if (l + 1 < n_layers) { qkv_steps(P, Wall + (l + 1) * 16, kv[l + 1]); wb += wb_qkv; fl += 2.0 * M * 3.0 * H * H; }
+    rc = chain_submit(ctx, P, M, pos0, wb, fl, st);
+    if (rc) return rc;
+  }
   return LIA_OK;
 }
 

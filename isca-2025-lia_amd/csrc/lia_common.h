@@ -107,96 +107,159 @@ struct LiaPost {
   int rot_heads, hd, pos0, T;
 };
 
-// sum over the LIA_ROW_THREADS threads of a workgroup, the same value in every thread (red: LIA_ROW_WAVES floats of LDS, used
-// once per call); the wave totals are added in wave order
+// One output row per workgroup (16 waves' worth of threads: the row ops of a decode step are pure latency, and a combine that
+// reads 8 slabs x 28 KB per row wants every load of the row in flight at once).  The row is cut into 8-value pieces (packed
+// bf16); VIRTUAL thread v of LIA_ROW_THREADS holds pieces v, v + LIA_ROW_THREADS, ...  A workgroup of LIA_ROW_THREADS / VT real
+// threads runs VT virtual threads per thread (real thread t = virtual threads t + h * LIA_ROW_THREADS / VT, h < VT): the
+// stand-alone row kernels and the split-K combines use VT = 1, the 512-thread persistent decode chain (lia_chain.hip) VT = 2 --
+// every sum is taken over the same values in the same order, so the two give the same bits.
 #define LIA_ROW_WAVES 16
 #define LIA_ROW_THREADS (64 * LIA_ROW_WAVES)
-__device__ __forceinline__ float block_sum_row(float v, float* red) {
-  v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+
+// 16-byte store; SC1: write-through, visible to other workgroups of the SAME launch without a release fence once the storing
+// wave has drained it (cdna_hip_programming.md Guideline 16, R1)
+template <bool SC1> __device__ __forceinline__ void lia_store16(void* p, const uint4& v) {
+  if constexpr (SC1) {
+    const u32x4 d{v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+  } else {
+    *(uint4*)p = v;
+  }
+}
+template <bool SC1> __device__ __forceinline__ void lia_store8(void* p, const uint2& v) {
+  if constexpr (SC1) {
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_;
+    const u32x2_ d{v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+  } else {
+    *(uint2*)p = v;
+  }
+}
+
+// sum over the virtual threads of a row workgroup, the same value in every thread (red: LIA_ROW_WAVES floats of LDS, used once
+// per call); the virtual waves' totals are added in wave order
+template <int VT> __device__ __forceinline__ float block_sum_row_vt(const float (&v)[VT], float* red) {
+  constexpr int RW = LIA_ROW_WAVES / VT;     // real waves
+#pragma unroll
+  for (int h = 0; h < VT; ++h) {
+    const float s = wave_sum(v[h]);
+    if ((threadIdx.x & 63) == 0) red[h * RW + (threadIdx.x >> 6)] = s;
+  }
   __syncthreads();
   float t = red[0];
 #pragma unroll
   for (int w = 1; w < LIA_ROW_WAVES; ++w) t += red[w];
   return t;
 }
+__device__ __forceinline__ float block_sum_row(float v, float* red) {
+  const float a[1] = {v};
+  return block_sum_row_vt<1>(a, red);
+}
 
-// One row per LIA_ROW_THREADS-thread workgroup (16 waves: the row ops of a decode step are pure latency, and a combine that
-// reads 8 slabs x 28 KB per row wants every load of the row in flight at once); thread t holds the 8-value pieces
-// t, t + LIA_ROW_THREADS, ... (packed bf16) of the row.
 // LayerNorm as torch.nn.functional.layer_norm on bf16: statistics in fp32 (two passes over the registers), one rounding.
-template <int NV>
-__device__ __forceinline__ void row_layernorm_block(const uint4 (&v)[NV], const uint4 (&gv)[NV], const uint4 (&bv)[NV], int nv, int H,
+template <int NV, int VT, bool SC1>
+__device__ __forceinline__ void row_layernorm_vt(const uint4 (&v)[VT][NV], const uint4 (&gv)[VT][NV], const uint4 (&bv)[VT][NV], int nv, int H,
                                                  float eps, bf16_t* __restrict__ yr, float* red /* 2 x LIA_ROW_WAVES floats */) {
+  constexpr int RTH = LIA_ROW_THREADS / VT;
   const int tid = threadIdx.x;
-  float s = 0.f;
+  float s[VT];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    if (tid + LIA_ROW_THREADS * k < nv) {
-      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+  for (int h = 0; h < VT; ++h) {
+    s[h] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += bf2f(w[j] & 0xffff) + bf2f(w[j] >> 16);
-    }
-  }
-  const float mean = block_sum_row(s, red) / (float)H;
-  float q = 0.f;
+    for (int k = 0; k < NV; ++k) {
+      if (tid + RTH * h + LIA_ROW_THREADS * k < nv) {
+        const uint32_t w[4] = {v[h][k].x, v[h][k].y, v[h][k].z, v[h][k].w};
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    if (tid + LIA_ROW_THREADS * k < nv) {
-      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float a = bf2f(w[j] & 0xffff) - mean, c = bf2f(w[j] >> 16) - mean;
-        q += a * a + c * c;
+        for (int j = 0; j < 4; ++j) s[h] += bf2f(w[j] & 0xffff) + bf2f(w[j] >> 16);
       }
     }
   }
-  const float rstd = 1.0f / sqrtf(block_sum_row(q, red + LIA_ROW_WAVES) / (float)H + eps);
+  const float mean = block_sum_row_vt<VT>(s, red) / (float)H;
+  float q[VT];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int i = tid + LIA_ROW_THREADS * k;
-    if (i < nv) {
-      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w},
-                     bw[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
-      uint32_t o[4];
+  for (int h = 0; h < VT; ++h) {
+    q[h] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float lo = (bf2f(w[j] & 0xffff) - mean) * rstd * bf2f(gw[j] & 0xffff) + bf2f(bw[j] & 0xffff);
-        float hi = (bf2f(w[j] >> 16) - mean) * rstd * bf2f(gw[j] >> 16) + bf2f(bw[j] >> 16);
-        o[j] = pack_bf16x2(lo, hi);
+    for (int k = 0; k < NV; ++k) {
+      if (tid + RTH * h + LIA_ROW_THREADS * k < nv) {
+        const uint32_t w[4] = {v[h][k].x, v[h][k].y, v[h][k].z, v[h][k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = bf2f(w[j] & 0xffff) - mean, c = bf2f(w[j] >> 16) - mean;
+          q[h] += a * a + c * c;
+        }
       }
-      *(uint4*)(yr + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
+    }
+  }
+  const float rstd = 1.0f / sqrtf(block_sum_row_vt<VT>(q, red + LIA_ROW_WAVES) / (float)H + eps);
+#pragma unroll
+  for (int h = 0; h < VT; ++h) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = tid + RTH * h + LIA_ROW_THREADS * k;
+      if (i < nv) {
+        const uint32_t w[4] = {v[h][k].x, v[h][k].y, v[h][k].z, v[h][k].w}, gw[4] = {gv[h][k].x, gv[h][k].y, gv[h][k].z, gv[h][k].w},
+                       bw[4] = {bv[h][k].x, bv[h][k].y, bv[h][k].z, bv[h][k].w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo = (bf2f(w[j] & 0xffff) - mean) * rstd * bf2f(gw[j] & 0xffff) + bf2f(bw[j] & 0xffff);
+          float hi = (bf2f(w[j] >> 16) - mean) * rstd * bf2f(gw[j] >> 16) + bf2f(bw[j] >> 16);
+          o[j] = pack_bf16x2(lo, hi);
+        }
+        lia_store16<SC1>(yr + 8 * i, uint4{o[0], o[1], o[2], o[3]});
+      }
     }
   }
 }
+template <int NV>
+__device__ __forceinline__ void row_layernorm_block(const uint4 (&v)[NV], const uint4 (&gv)[NV], const uint4 (&bv)[NV], int nv, int H,
+                                                 float eps, bf16_t* __restrict__ yr, float* red /* 2 x LIA_ROW_WAVES floats */) {
+  row_layernorm_vt<NV, 1, false>(reinterpret_cast<const uint4(&)[1][NV]>(v), reinterpret_cast<const uint4(&)[1][NV]>(gv),
+                                 reinterpret_cast<const uint4(&)[1][NV]>(bv), nv, H, eps, yr, red);
+}
 
 // LlamaRMSNorm.forward: y = bf16( w * bf16( x * rsqrt(mean(x^2) + eps) ) )
+template <int NV, int VT, bool SC1>
+__device__ __forceinline__ void row_rmsnorm_vt(const uint4 (&v)[VT][NV], const uint4 (&gv)[VT][NV], int nv, int H, float eps,
+                                               bf16_t* __restrict__ yr, float* red /* LIA_ROW_WAVES floats */) {
+  constexpr int RTH = LIA_ROW_THREADS / VT;
+  const int tid = threadIdx.x;
+  float ss[VT];
+#pragma unroll
+  for (int h = 0; h < VT; ++h) {
+    ss[h] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (tid + RTH * h + LIA_ROW_THREADS * k < nv) {
+        const uint32_t u[4] = {v[h][k].x, v[h][k].y, v[h][k].z, v[h][k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float a = bf2f(u[j] & 0xffff), c = bf2f(u[j] >> 16); ss[h] += a * a + c * c; }
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(block_sum_row_vt<VT>(ss, red) / (float)H + eps);
+#pragma unroll
+  for (int h = 0; h < VT; ++h) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = tid + RTH * h + LIA_ROW_THREADS * k;
+      if (i < nv) {
+        const uint32_t u[4] = {v[h][k].x, v[h][k].y, v[h][k].z, v[h][k].w}, gw[4] = {gv[h][k].x, gv[h][k].y, gv[h][k].z, gv[h][k].w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = pack_bf16x2(bf2f(gw[j] & 0xffff) * rbf(bf2f(u[j] & 0xffff) * rstd), bf2f(gw[j] >> 16) * rbf(bf2f(u[j] >> 16) * rstd));
+        lia_store16<SC1>(yr + 8 * i, uint4{o[0], o[1], o[2], o[3]});
+      }
+    }
+  }
+}
 template <int NV>
 __device__ __forceinline__ void row_rmsnorm_block(const uint4 (&v)[NV], const uint4 (&gv)[NV], int nv, int H, float eps,
                                                bf16_t* __restrict__ yr, float* red /* LIA_ROW_WAVES floats */) {
-  const int tid = threadIdx.x;
-  float ss = 0.f;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    if (tid + LIA_ROW_THREADS * k < nv) {
-      const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { float a = bf2f(u[j] & 0xffff), c = bf2f(u[j] >> 16); ss += a * a + c * c; }
-    }
-  }
-  const float rstd = 1.0f / sqrtf(block_sum_row(ss, red) / (float)H + eps);
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int i = tid + LIA_ROW_THREADS * k;
-    if (i < nv) {
-      const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
-      uint32_t o[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        o[j] = pack_bf16x2(bf2f(gw[j] & 0xffff) * rbf(bf2f(u[j] & 0xffff) * rstd), bf2f(gw[j] >> 16) * rbf(bf2f(u[j] >> 16) * rstd));
-      *(uint4*)(yr + 8 * i) = uint4{o[0], o[1], o[2], o[3]};
-    }
-  }
+  row_rmsnorm_vt<NV, 1, false>(reinterpret_cast<const uint4(&)[1][NV]>(v), reinterpret_cast<const uint4(&)[1][NV]>(gv), nv, H, eps, yr, red);
 }
 
 // LlamaMLP act_fn(gate) * up on two packed bf16 pairs: bf16( bf16(silu(g)) * u ); silu in fp32 through the hardware exp2 /

@@ -17,49 +17,11 @@
 #include <cstdio>
 #include <cstring>
 #include "lia_common.h"
+#include "lia_epilogue.h"
+#include "lia_chain.h"
 
 #define GL_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
-
-// ---------------------------------------------------------------------------------------------
-// shared epilogue: 4 consecutive columns n..n+3 of row m
-// ---------------------------------------------------------------------------------------------
-// the four finished values (every reference rounding point applied: they are bf16-representable)
-__device__ __forceinline__ f32x4 epilogue_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep) {
-  float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
-  if (hb) {
-    uint2 bb = *(const uint2*)(ep.bias + n);
-    b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
-  }
-  if (hr) {
-    uint2 rr = *(const uint2*)(ep.residual + (long)m * ep.ldr + n);
-    r[0] = bf2f(rr.x & 0xffff); r[1] = bf2f(rr.x >> 16); r[2] = bf2f(rr.y & 0xffff); r[3] = bf2f(rr.y >> 16);
-  }
-  return f32x4{lia_epilogue_apply(v[0], b[0], hb, ep.relu, r[0], hr), lia_epilogue_apply(v[1], b[1], hb, ep.relu, r[1], hr),
-               lia_epilogue_apply(v[2], b[2], hb, ep.relu, r[2], hr), lia_epilogue_apply(v[3], b[3], hb, ep.relu, r[3], hr)};
-}
-
-__device__ __forceinline__ void store_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep, const LiaOutMap& om) {
-  float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
-  if (hb) {
-    uint2 bb = *(const uint2*)(ep.bias + n);
-    b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
-  }
-  if (hr) {
-    uint2 rr = *(const uint2*)(ep.residual + (long)m * ep.ldr + n);
-    r[0] = bf2f(rr.x & 0xffff); r[1] = bf2f(rr.x >> 16); r[2] = bf2f(rr.y & 0xffff); r[3] = bf2f(rr.y >> 16);
-  }
-  float t0 = lia_epilogue_apply(v[0], b[0], hb, ep.relu, r[0], hr);
-  float t1 = lia_epilogue_apply(v[1], b[1], hb, ep.relu, r[1], hr);
-  float t2 = lia_epilogue_apply(v[2], b[2], hb, ep.relu, r[2], hr);
-  float t3 = lia_epilogue_apply(v[3], b[3], hb, ep.relu, r[3], hr);
-  uint2 o;
-  o.x = pack_bf16x2(t0, t1);
-  o.y = pack_bf16x2(t2, t3);
-  *(uint2*)lia_out_ptr(om, m, n) = o;
-}
 
 // Combine split-K slabs [S][M][N] fp32 and apply the epilogue; one thread per 4 columns.
 __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
@@ -75,12 +37,6 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __r
     a += b;
   }
   store_quad(a, m, n, ep, om);
-}
-
-__device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ partial, int S, int M, int N, int m, int n) {
-  f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
-  for (int s = 1; s < S; ++s) a += *(const f32x4*)(partial + ((long)s * M + m) * N + n);     // slice 0, 1, ...: the order of the plain combine
-  return a;
 }
 
 // ---- split-K combines that also do the next op of the decode layer (LiaPost, lia_common.h) ----
@@ -1218,6 +1174,12 @@ static bool launch_fused_combine(const float* ws, int split, int M, int N, const
 static int g_skinny_variant = 0;
 extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
 
+// Test / A-B knob: 1 = cut K into the slices the persistent decode chain uses for the same shape (lia_chain_plan_gemm).  The two
+// routes then add the same products in the same order and must agree bit for bit (tests/test_gpu_chain.py); 0 (default) = the
+// per-launch heuristics below.
+static int g_split_policy = [] { const char* e = getenv("LIA_GEMM_SPLIT_POLICY"); return e ? atoi(e) : 0; }();
+extern "C" void lia_gemm_set_split_policy(int v) { g_split_policy = v; }
+
 // Returns 0 on success, -1 on unsupported shape.  workspace is only touched when split-K is chosen.
 // tickets: LIA_GEMM_MAX_TICKETS zero-initialised counters owned by the caller's context (one per output tile of a split-K
 // launch; the kernel leaves them zero again).  NULL: the slabs are combined by a second kernel as in r01.
@@ -1236,6 +1198,12 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   if (M <= 256 && (K % (2 * S2_BK)) == 0) {
     constexpr int WAVES = 8;
     const int nchunks = K / S2_BK;
+    if (g_split_policy == 1 && force_split <= 0 && M <= 128) {
+      static const int n_cu = [] { int dev = 0; (void)hipGetDevice(&dev); return lia_chain_cu_count(dev); }();
+      LiaChainPlan cp;
+      const int glu = post && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK;
+      if (n_cu > 0 && lia_chain_plan_gemm(M, N, K, glu, n_cu, &cp) == 0) force_split = cp.split;
+    }
     // Two workgroup shapes.  RT = 1: 128 weight rows, LDS-DMA moves (128 + 16 MT)/128 bytes per weight byte, two
     // workgroups per CU up to M = 64.  RT = 2 (32 < M <= 128): 256 weight rows per workgroup halve the x share of
     // the LDS-DMA traffic (OPT-30B fc1 at M = 64: 4.9 -> 5.5 TB/s) but leave a quarter as many workgroups, so it is

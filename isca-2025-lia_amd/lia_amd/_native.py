@@ -85,6 +85,12 @@ SIGNATURES = {
     "lia_llama_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lia_llama_lm_head": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p,
                                   c_void_p, c_void_p]),
+    "lia_decode_layers": (c_int, [c_void_p, ctypes.POINTER(LayerDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lia_llama_decode_layers": (c_int, [c_void_p, ctypes.POINTER(LlamaDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_void_p]),
+    "lia_set_fused_decode": (None, [c_int]),
+    "lia_gemm_set_split_policy": (None, [c_int]),
+    "lia_chain_launch_count": (c_long, []),
     "lia_host_layer_forward": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_void_p * 16), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "lia_host_layers_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -232,6 +232,7 @@ class LlamaScheduler:
             if self.pipe is not None:
                 self.pipe.drain()          # copies in flight read the host buffers a re-placement frees
             self.resident.clear()
+            self._run_key = None
         m.place(n_gpu, pin_weight, enable_cxl, self.pack)
         x, y = self._ensure(mini * T, B, T, n_gpu, kv_state.smax)
         ctx, pipe = self.ctx, self.pipe
@@ -249,7 +250,23 @@ class LlamaScheduler:
             return self.resident[i]
 
         xlast = None
-        for idx in range(L):
+        first = 0
+        if T == 1 and n_gpu > 0 and mini == B:
+            # decode: the resident run in ONE call -- per layer an attention launch and a persistent chain launch (lia_chain.hip);
+            # LIA_FUSED_DECODE=0 / shapes the chain does not cover take the layer-by-layer route inside the library
+            key = (n_gpu, id(kv_state), kv_state.kv[0].k, resident(0)[0])
+            if getattr(self, "_run_key", None) != key:
+                ptrs = []
+                for i in range(n_gpu):
+                    ptrs.extend(resident(i))
+                self._run = ((ctypes.c_void_p * (9 * n_gpu))(*ptrs), (ctypes.POINTER(N.KV) * n_gpu)(*[ctypes.pointer(kv_state.kv[i]) for i in range(n_gpu)]))
+                self._run_key = key
+            N.check(lib.lia_llama_decode_layers(ctx.handle, ctypes.byref(m.desc), n_gpu, ctypes.cast(self._run[0], ctypes.c_void_p),
+                                                ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.cast(self._run[1], ctypes.c_void_p),
+                                                ctypes.c_void_p(cos.data_ptr()), ctypes.c_void_p(sin.data_ptr()), B, pos0, st), "lia_llama_decode_layers")
+            x, y = y, x
+            first = n_gpu
+        for idx in range(first, L):
             if idx < n_gpu:
                 w = resident(idx)
                 if T == 1 and idx + 1 < n_gpu:

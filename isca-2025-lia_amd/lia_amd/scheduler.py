@@ -622,6 +622,7 @@ class OffloadScheduler:
             if self.pipe is not None:
                 self.pipe.drain()
             self.resident_ptrs.clear()
+            self._run_key = None
         m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=cpu_set, shard=shard)
         if coop is not None and is_prefill:
             coop.new_sequence()                                      # the first decode step is not a sample of the steady state
@@ -673,7 +674,24 @@ class OffloadScheduler:
         # the prefill's last layer: only hidden[:, -1, :] feeds lm_head (models.py:424-431), its K/V of every position feed decode
         tail_last = self.prefill_tail and is_prefill and T > 1 and pos0 == 0 and (policy in (0, 3) or n_gpu == L) and (L - 1) not in host_now
         xlast = None
-        for idx in range(L):
+        first = 0
+        if not is_prefill and n_gpu > 0:
+            # decode: the resident run (whole batch, everything on the GPU incl. KV -- policy 3; :1246-1260) in ONE call: per layer an
+            # attention launch and a persistent chain launch (lia_chain.hip); LIA_FUSED_DECODE=0 and shapes the chain does not cover
+            # take the layer-by-layer route inside the library
+            key = (n_gpu, id(kv_state), kv_state.kv[0].k, self._resident(0)[0])
+            if getattr(self, "_run_key", None) != key:
+                ptrs = []
+                for i in range(n_gpu):
+                    ptrs.extend(self._resident(i))
+                self._run = ((ctypes.c_void_p * (16 * n_gpu))(*ptrs), (ctypes.POINTER(N.KV) * n_gpu)(*[ctypes.pointer(kv_state.kv[i]) for i in range(n_gpu)]))
+                self._run_key = key
+            N.check(ctx.lib.lia_decode_layers(ctx.handle, ctypes.byref(m.desc), n_gpu, ctypes.cast(self._run[0], ctypes.c_void_p),
+                                              ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.cast(self._run[1], ctypes.c_void_p),
+                                              B, pos0, ctypes.c_void_p(ctx.stream)), "lia_decode_layers")
+            x, y = y, x
+            first = n_gpu
+        for idx in range(first, L):
             if idx < n_gpu:
                 # resident layer: whole batch, everything on the GPU incl. KV (policy 3; :1246-1260)
                 if not is_prefill and idx + 1 < n_gpu:
