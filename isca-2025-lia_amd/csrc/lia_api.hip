@@ -110,6 +110,7 @@ struct lia_ctx {
   int n_cu;
   char* chain_tmp;
   size_t chain_tmp_bytes;
+  unsigned long long* chain_gran;     // row statistics that cross workgroups inside a chain launch (tagged, never zeroed)
 };
 #define LIA_CHAIN_SYNC_BLOCKS 256
 
@@ -157,6 +158,8 @@ extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out)
   HIP_TRY(hipMemset(c->gemm_tickets, 0, 16384 * sizeof(unsigned)));
   HIP_TRY(hipMalloc((void**)&c->chain_sync, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES));
   HIP_TRY(hipMemset(c->chain_sync, 0, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES));
+  HIP_TRY(hipMalloc((void**)&c->chain_gran, LIA_CHAIN_GRAN_BYTES));
+  HIP_TRY(hipMemset(c->chain_gran, 0, LIA_CHAIN_GRAN_BYTES));
   HIP_TRY(hipHostMalloc((void**)&c->chain_err_host, 64, hipHostMallocMapped));
   *c->chain_err_host = 0u;
   c->n_cu = lia_chain_cu_count(device);
@@ -176,6 +179,7 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
   if (c->ws) (void)hipFree(c->ws);
   if (c->gemm_tickets) (void)hipFree(c->gemm_tickets);
   if (c->chain_sync) (void)hipFree(c->chain_sync);
+  if (c->chain_gran) (void)hipFree(c->chain_gran);
   if (c->chain_err_host) (void)hipHostFree(c->chain_err_host);
   if (c->chain_tmp) (void)hipFree(c->chain_tmp);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
@@ -1045,7 +1049,8 @@ static int chain_submit(lia_ctx* ctx, const LiaChainProgram& prog, int M, int po
     e1 = (*ctx->prof_events)[2 * i + 1];
     HIP_TRY(hipEventRecord(e0, st));
   }
-  if (lia_chain_launch(&prog, M, ctx->chain_sync + (size_t)blk * (LIA_CHAIN_SYNC_BYTES / 4), ctx->chain_err_host, pos0, ctx->n_cu, st)) {
+  if (lia_chain_launch(&prog, M, ctx->chain_sync + (size_t)blk * (LIA_CHAIN_SYNC_BYTES / 4), ctx->chain_err_host, pos0, ctx->n_cu, ctx->chain_gran,
+                       (unsigned)((n + 1) & 0x3ffffff), st)) {
     lia_set_error("decode chain: launch refused (M=%d, %d steps)", M, prog.n_ops);
     return LIA_ERR_INVALID;
   }

@@ -462,6 +462,13 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
 // read from HBM once.  LPK = D/8 lanes share one key row (16 bytes each); scores are parked in LDS, then every
 // thread accumulates its 8 output dims over its share of the keys and the shares are combined through LDS.
 // ---------------------------------------------------------------------------------------------
+// a 16-byte load of cache rows that are read once per step: non-temporal, so the stream does not push q, the scores' neighbours
+// and the next kernel's operands out of L2 (tools/stream_bench: a once-read stream runs 6.7 TB/s with nt against 6.0 without)
+__device__ __forceinline__ uint4 lia_ldg_stream(const bf16_t* p) {
+  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = min(j0 + u * KPP + kslot, S - 1);
-      kv[u] = *(const uint4*)(kbase + (long)j * kv_row + 8 * sub);
+      kv[u] = lia_ldg_stream(kbase + (long)j * kv_row + 8 * sub);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   for (int j0 = kslot; j0 < S; j0 += U * KPP) {
     uint4 vv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) vv[u] = *(const uint4*)(vbase + (long)min(j0 + u * KPP, S - 1) * kv_row + 8 * sub);
+    for (int u = 0; u < U; ++u) vv[u] = lia_ldg_stream(vbase + (long)min(j0 + u * KPP, S - 1) * kv_row + 8 * sub);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = j0 + u * KPP;

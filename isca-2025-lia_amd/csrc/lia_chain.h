@@ -47,9 +47,12 @@ int lia_chain_plan_gemm(int M, int N, int K, int glu, int n_cu, LiaChainPlan* ou
 int lia_chain_supported(int M);
 // launch a program (host memory; copied into the kernel arguments); sync_block: 4 KB of zeroed device memory this
 // launch owns exclusively (barrier counters + timeout word at word 17 * 32); err_host: host-mapped word that a barrier which
-// gave up sets (nullable)
-int lia_chain_launch(const LiaChainProgram* prog, int M, unsigned* sync_block, unsigned* err_host, int pos0, int n_cu, hipStream_t st);
+// gave up sets (nullable); gran: LIA_CHAIN_GRAN_BYTES of device memory for the row statistics that cross workgroups (nullable: one
+// workgroup per row then), never zeroed -- epoch must differ from launch to launch (a counter)
+int lia_chain_launch(const LiaChainProgram* prog, int M, unsigned* sync_block, unsigned* err_host, int pos0, int n_cu, unsigned long long* gran,
+                     unsigned epoch, hipStream_t st);
 int lia_chain_cu_count(int device);
 }
 #define LIA_CHAIN_SYNC_BYTES 4096
+#define LIA_CHAIN_GRAN_BYTES (2 * 128 * 16 * 8)
 #define LIA_CHAIN_ERR_WORD (17 * 32)

@@ -22,6 +22,16 @@ __device__ __forceinline__ f32x4 epilogue_quad(const f32x4& v, int m, int n, con
                lia_epilogue_apply(v[2], b[2], hb, ep.relu, r[2], hr), lia_epilogue_apply(v[3], b[3], hb, ep.relu, r[3], hr)};
 }
 
+// the same with the bias / residual values already in registers (packed bf16 x 4 each): for callers that request them together
+// with everything else they load, ahead of the arithmetic
+__device__ __forceinline__ f32x4 epilogue_quad_pre(const f32x4& v, const uint2& bb, const uint2& rr, bool hb, int relu, bool hr) {
+  float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+  if (hb) { b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16); }
+  if (hr) { r[0] = bf2f(rr.x & 0xffff); r[1] = bf2f(rr.x >> 16); r[2] = bf2f(rr.y & 0xffff); r[3] = bf2f(rr.y >> 16); }
+  return f32x4{lia_epilogue_apply(v[0], b[0], hb, relu, r[0], hr), lia_epilogue_apply(v[1], b[1], hb, relu, r[1], hr),
+               lia_epilogue_apply(v[2], b[2], hb, relu, r[2], hr), lia_epilogue_apply(v[3], b[3], hb, relu, r[3], hr)};
+}
+
 __device__ __forceinline__ void store_quad(const f32x4& v, int m, int n, const LiaEpilogue& ep, const LiaOutMap& om) {
   float b[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
   const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;

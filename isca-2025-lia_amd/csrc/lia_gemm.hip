@@ -381,22 +381,31 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
       if (i + S - 1 < n) issue(c_begin + i + S - 1, (i + S - 1) % S);
       const char* wt = smem + (i % S) * STAGE;
       const char* xt = wt + WTILE;
+      // every fragment read of the chunk first, then the MFMAs (r04): left to itself hipcc alternates ds_read_b128 / s_waitcnt
+      // lgkmcnt(0) / MFMA -- a dependent LDS round trip in front of every MFMA, ~1 us per chunk whatever the memory system does
+      // (same products into the same accumulators in the same order: bit-identical)
+      bf16x8 a[2][RT], bq[2][MT];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
           const int row = wrow + 16 * t;
-          a[t] = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
+          a[ks][t] = __builtin_bit_cast(bf16x8, *(const uint4*)(wt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
         }
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
           int row = 16 * p + l15;
-          bf16x8 b = __builtin_bit_cast(bf16x8, *(const uint4*)(xt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
-#pragma unroll
-          for (int t = 0; t < RT; ++t) acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][p], 0, 0, 0);
+          bq[ks][p] = __builtin_bit_cast(bf16x8, *(const uint4*)(xt + row * 128 + (((4 * ks + lq) ^ tl_swz(row)) << 4)));
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < MT; ++p)
+#pragma unroll
+          for (int t = 0; t < RT; ++t) acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][t], bq[ks][p], acc[t][p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // keep the last MFMA well clear of the accumulator reads below (see the note in v1)

@@ -30,11 +30,11 @@ int main(int argc, char** argv) {
   if (getenv("SHAPE")) { int n_, k_; sscanf(getenv("SHAPE"), "%d,%d", &n_, &k_); shapes = {{"custom", n_, k_}, {"dummy", 16, 128}}; }
   if (getenv("KSWEEP")) shapes = {{"k1792", 7168, 1792}, {"k3584", 7168, 3584}, {"k7168", 7168, 7168}, {"k14336", 7168, 14336}, {"k28672", 7168, 28672}, {"dummy", 16, 128}};
   const int NBUF = 4;
-  size_t maxw = (size_t)128256 * 4096;
+  size_t maxw = (size_t)128256 * (4096 + 1024);
   uint16_t* w[NBUF];
   for (int i = 0; i < NBUF; ++i) { CK(hipMalloc(&w[i], maxw * 2)); fill_kernel<<<2048, 256>>>(w[i], maxw, 17 + i); }
   uint16_t *x, *y, *bias, *res; float* ws;
-  CK(hipMalloc(&x, (size_t)M * 28672 * 2)); fill_kernel<<<2048, 256>>>(x, (size_t)M * 28672, 3);
+  CK(hipMalloc(&x, (size_t)M * (28672 + 1024) * 2)); fill_kernel<<<2048, 256>>>(x, (size_t)M * (28672 + 1024), 3);
   CK(hipMalloc(&y, (size_t)M * 128256 * 2)); CK(hipMalloc(&bias, 128256 * 2)); CK(hipMalloc(&res, (size_t)M * 128256 * 2));
   fill_kernel<<<256, 256>>>(bias, 128256, 5); fill_kernel<<<2048, 256>>>(res, (size_t)M * 128256, 7);
   if (M > 256) shapes.pop_back();  // no lm_head in prefill (last position only)
