@@ -225,6 +225,11 @@ int lia_llama_decode_layers(lia_ctx* ctx, const lia_llama_desc* d, int n_layers,
 void lia_set_fused_decode(int on);
 void lia_gemm_set_split_policy(int policy);
 long lia_chain_launch_count(void);
+/* Which kernel runs the decode GEMMs of the per-op route (M <= 128): 1 (default) = the chain kernel as a one-step program, its
+ * slabs combined by the per-op combine kernels; 0 = lia_gemm_skinny2_kernel (also env LIA_GEMM_ENGINE=skinny2).  Same bits under
+ * lia_gemm_set_split_policy(1).  lia_gemm_chain_engine_count: GEMMs the chain engine has run since the library was loaded. */
+void lia_gemm_set_engine(int engine);
+long lia_gemm_chain_engine_count(void);
 
 /* ---- host side of the cooperative policies -------------------------------------------------------
  * Indirect-access-KV masked MHA, csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp:513-842: fp32

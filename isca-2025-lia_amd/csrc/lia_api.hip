@@ -1012,8 +1012,10 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
 // ------------------------------------------------------------------------------------------------
 // decode step over a run of HBM-resident layers: per layer ONE attention launch and ONE persistent chain launch (lia_chain.hip)
 // ------------------------------------------------------------------------------------------------
-// A/B switch (tests, tools): LIA_FUSED_DECODE=0 or lia_set_fused_decode(0) runs the same layers through the per-layer entry points
-static int g_fused_decode = [] { const char* e = getenv("LIA_FUSED_DECODE"); return (e && !strcmp(e, "0")) ? 0 : 1; }();
+// Route switch: LIA_FUSED_DECODE=1 or lia_set_fused_decode(1) takes the persistent-chain route; the default (0) runs the same layers
+// through the per-layer entry points -- measured 3-6 % faster per step (r04, LABNOTES.md: a seam inside the launch costs what a
+// kernel boundary costs, and the per-op kernels need no 160 KB ring started cold)
+static int g_fused_decode = [] { const char* e = getenv("LIA_FUSED_DECODE"); return (e && !strcmp(e, "1")) ? 1 : 0; }();
 extern "C" void lia_set_fused_decode(int on) { g_fused_decode = on ? 1 : 0; }
 static long g_chain_launches = 0;      // chain launches since the library was loaded (tests assert the route was taken)
 extern "C" long lia_chain_launch_count(void) { return g_chain_launches; }

@@ -763,9 +763,9 @@ __global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P,
         // round's bookkeeping is ~25 scalar branches, which paced the first version of this loop at ~1 us per chunk.
         int c = c0;
         while (c < c1) {
-          const int L = min(w_cend - w_c, x_cend - x_c) - 1;      // requests that stay inside the cursors' items
+          const int L = min(min(w_cend - w_c, x_cend - x_c) - 1, c1 - c);   // requests that stay inside the cursors' items, rounds that stay inside this one
           const int d = loads_w ? w_rounds() : XJ;
-          const bool steady = L > 0 && w_valid && x_valid && nw == DW - 1 && nx == DX - 1 &&
+          const bool steady = L > 0 && !(dbg & 8) && w_valid && x_valid && nw == DW - 1 && nx == DX - 1 &&
                               (ch_fifo_behind(fifo, issued) == (loads_w ? DW - 2 : DX - 2) * d || (dbg & (loads_w ? 2 : 4)));
           if (steady && (!loads_w || d >= WJ - 1)) {
 #define CH_LEAN_ROUNDS(WAIT_N, LOADS)                                                                              \

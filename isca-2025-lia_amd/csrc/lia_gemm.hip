@@ -1189,6 +1189,18 @@ extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
 static int g_split_policy = [] { const char* e = getenv("LIA_GEMM_SPLIT_POLICY"); return e ? atoi(e) : 0; }();
 extern "C" void lia_gemm_set_split_policy(int v) { g_split_policy = v; }
 
+// Which kernel runs a decode GEMM with M <= 128: 0 (default) = lia_gemm_skinny2_kernel; 1 (LIA_GEMM_ENGINE=chain) = the persistent
+// chain kernel as a one-step program (lia_chain.hip), its split-K slabs combined by the same kernels as before.  Measured (r04,
+// LABNOTES.md): the chain's steady-state loop is the faster one (7.0 TB/s on OPT-30B's fc1 at M = 64 against 6.0, 52 against 60 us
+// on Llama-3-8B's gate|up at M = 128), but as a launch of its own it pays a cold 160 KB ring and ~1 us rounds at every item
+// boundary: q|k|v / o 19-23 us against 16.7, lm_head 306 against 246 -- whole steps 3-6 % slower.  Kept for A/B runs and as a
+// second implementation to compare bits with: same products in the same order per K slice, so with
+// lia_gemm_set_split_policy(1) the two engines agree bit for bit.
+static int g_gemm_engine = [] { const char* e = getenv("LIA_GEMM_ENGINE"); return (e && !strcmp(e, "chain")) ? 1 : 0; }();
+extern "C" void lia_gemm_set_engine(int v) { g_gemm_engine = v ? 1 : 0; }
+static long g_chain_gemms = 0;
+extern "C" long lia_gemm_chain_engine_count(void) { return g_chain_gemms; }
+
 // Returns 0 on success, -1 on unsupported shape.  workspace is only touched when split-K is chosen.
 // tickets: LIA_GEMM_MAX_TICKETS zero-initialised counters owned by the caller's context (one per output tile of a split-K
 // launch; the kernel leaves them zero again).  NULL: the slabs are combined by a second kernel as in r01.
@@ -1207,6 +1219,7 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   if (M <= 256 && (K % (2 * S2_BK)) == 0) {
     constexpr int WAVES = 8;
     const int nchunks = K / S2_BK;
+    const int caller_split = force_split;                      // (the split policy below may set force_split; the engine choice looks at the caller's)
     if (g_split_policy == 1 && force_split <= 0 && M <= 128) {
       static const int n_cu = [] { int dev = 0; (void)hipGetDevice(&dev); return lia_chain_cu_count(dev); }();
       LiaChainPlan cp;
@@ -1279,6 +1292,59 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
       }
       ep = &ep_s;
       om = &om_s;
+    }
+    // ---- the chain kernel as the GEMM engine (see g_gemm_engine) ----
+    if (g_gemm_engine == 1 && M <= 128 && caller_split <= 0 && lia_chain_supported(M) == 0) {
+      static const int n_cu = [] { int dev = 0; (void)hipGetDevice(&dev); return lia_chain_cu_count(dev); }();
+      static unsigned* dummy_sync = nullptr;                      // a one-step program has no barrier; the kernel still wants a pointer
+      if (!dummy_sync && hipMalloc((void**)&dummy_sync, LIA_CHAIN_SYNC_BYTES) == hipSuccess) (void)hipMemset(dummy_sync, 0, LIA_CHAIN_SYNC_BYTES);
+      const bool want_glu = post && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK && (N % (2 * LIA_GU_BLOCK)) == 0 && post_done &&
+                            g_fuse_combine && post->out && (post->ldo & 3) == 0 && !ep->residual && !ep->bias && !ep->relu;
+      LiaChainPlan cp;
+      bool ok = n_cu > 0 && dummy_sync != nullptr;
+      bool glu_direct = false;
+      if (ok && want_glu && lia_chain_plan_gemm(M, N, K, 1, n_cu, &cp) == 0) glu_direct = true;
+      else if (ok) ok = lia_chain_plan_gemm(M, N, K, 0, n_cu, &cp) == 0;
+      if (ok && cp.split > 1 && (size_t)cp.split * M * N * sizeof(float) > workspace_bytes) ok = false;
+      if (ok && ep->glu && !glu_direct) ok = false;             // (the one-slice gate|up route above already redirected the output: skinny2 finishes it)
+      const bool glu_counted = ep->glu != 0;
+      if (ok) {
+        LiaChainProgram prog;
+        memset(&prog, 0, sizeof(prog));
+        prog.n_ops = 1;
+        LiaChainOp& o = prog.op[0];
+        o.kind = LIA_CH_GEMM;
+        o.M = M; o.N = N; o.K = K;
+        o.x = x; o.ldx = ldx; o.W = W; o.ldw = ldw;
+        o.bn = cp.bn; o.split = cp.split; o.cps = cp.cps; o.nchunks = nchunks;
+        o.n_items = ((N + cp.bn - 1) / cp.bn) * cp.split;
+        o.slices = cp.split;
+        if (glu_direct) {
+          o.direct = LIA_CH_DIRECT_GLU;
+          o.ep = *ep; o.ep.glu = 1;
+          memset(&o.om, 0, sizeof(o.om));
+          o.om.base[0] = post->out; o.om.ld[0] = post->ldo; o.om.seg_n = N / 2; o.om.T = 1;
+        } else if (cp.split == 1) {
+          o.direct = LIA_CH_DIRECT_PLAIN;
+          o.ep = *ep; o.om = *om;
+        } else {
+          o.direct = LIA_CH_DIRECT_NONE;
+          o.slab = workspace;
+        }
+        if (regime) *regime = 1;
+        if (ev0) (void)hipEventRecord(ev0, st);
+        if (lia_chain_launch(&prog, M, dummy_sync, nullptr, 0, n_cu, nullptr, 0u, st) == 0) {
+          if (ev1) (void)hipEventRecord(ev1, st);
+          ++g_chain_gemms;
+          if (glu_direct) { *post_done = 1; if (!glu_counted) ++g_fused_combines[LIA_POST_SILU_MUL]; return 0; }
+          if (cp.split > 1) {
+            if (post && post_done && launch_fused_combine(workspace, cp.split, M, N, *ep, *om, *post, st)) { *post_done = 1; return 0; }
+            long nq = (long)M * (N / 4);
+            hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace, cp.split, M, N, *ep, *om);
+          }
+          return 0;
+        }
+      }
     }
     if (split > nchunks) split = nchunks;
     if (split > 1 && (size_t)split * M * N * sizeof(float) > workspace_bytes) split = 1;

@@ -91,6 +91,8 @@ SIGNATURES = {
     "lia_set_fused_decode": (None, [c_int]),
     "lia_gemm_set_split_policy": (None, [c_int]),
     "lia_chain_launch_count": (c_long, []),
+    "lia_gemm_set_engine": (None, [c_int]),
+    "lia_gemm_chain_engine_count": (c_long, []),
     "lia_host_layer_forward": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_void_p * 16), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "lia_host_layers_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -26,6 +26,7 @@ def _llama_run(shape, B, T, steps, fused, seed=3):
     lib = N.lib()
     lib.lia_set_fused_decode(int(fused))
     lib.lia_gemm_set_split_policy(1)
+    lib.lia_gemm_set_engine(0)                  # the per-op side on lia_gemm_skinny2_kernel: a kernel of its own to compare with
     n0 = lib.lia_chain_launch_count()
     try:
         model = LiaLlamaModel.random_init(shape, seed=seed)
@@ -43,8 +44,9 @@ def _llama_run(shape, B, T, steps, fused, seed=3):
         model.close()
         return outs, caches, lib.lia_chain_launch_count() - n0
     finally:
-        lib.lia_set_fused_decode(1)
+        lib.lia_set_fused_decode(0)
         lib.lia_gemm_set_split_policy(0)
+        lib.lia_gemm_set_engine(0)
 
 
 def _opt_run(shape, B, T, steps, fused, seed=5):
@@ -55,6 +57,7 @@ def _opt_run(shape, B, T, steps, fused, seed=5):
     lib = N.lib()
     lib.lia_set_fused_decode(int(fused))
     lib.lia_gemm_set_split_policy(1)
+    lib.lia_gemm_set_engine(0)
     n0 = lib.lia_chain_launch_count()
     try:
         model = LiaOPTModel.random_init(shape, seed=seed, n_gpu_layers=shape.layers)
@@ -85,8 +88,9 @@ def _opt_run(shape, B, T, steps, fused, seed=5):
         model.close()
         return outs, caches, lib.lia_chain_launch_count() - n0
     finally:
-        lib.lia_set_fused_decode(1)
+        lib.lia_set_fused_decode(0)
         lib.lia_gemm_set_split_policy(0)
+        lib.lia_gemm_set_engine(0)
 
 
 def _same(a, b, what):
@@ -138,6 +142,37 @@ def test_opt_chain_bit_identical_to_per_op(case):
     _same(a, b, f"opt {case}")
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 128256, 4096), (64, 50272, 7168), (128, 32768, 1024), (20, 4096, 512)])
+def test_chain_engine_many_items_per_workgroup(M, N, K):
+    """one GEMM with more work items than CUs (lm_head-sized N: a workgroup walks several items, its rings running on across
+    them) through the chain kernel as GEMM engine, against lia_gemm_skinny2_kernel with the same K slices: same bits"""
+    import torch
+    from lia_amd import _native as N_, ops
+    lib = N_.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = (torch.randn((M, K), generator=g, device="cuda")).to(torch.bfloat16)
+    w = (0.02 * torch.randn((N, K), generator=g, device="cuda")).to(torch.bfloat16)
+    bias = (0.1 * torch.randn((N,), generator=g, device="cuda")).to(torch.bfloat16)
+    torch.cuda.synchronize()          # torch fills the inputs on ITS stream; the context's stream is not ordered behind it
+    ctx = ops.Context(0, 8 * M * N * 4 + (1 << 20))
+    try:
+        lib.lia_gemm_set_split_policy(1)
+        outs = []
+        for engine in (1, 0):
+            lib.lia_gemm_set_engine(engine)
+            n0 = lib.lia_gemm_chain_engine_count()
+            y = ctx.linear(x, w, bias=bias, relu=True)
+            ctx.synchronize()
+            assert (lib.lia_gemm_chain_engine_count() - n0 > 0) == (engine == 1)
+            outs.append(_bits(y))
+        bad = int((outs[0] != outs[1]).sum())
+        assert bad == 0, f"{bad} / {outs[0].size} values differ between the chain engine and skinny2"
+    finally:
+        lib.lia_gemm_set_split_policy(0)
+        lib.lia_gemm_set_engine(0)
+        ctx.close()
+
+
 def test_chain_repeatable_under_many_launches():
     """the same decode step 300 times over (> the 256 barrier-counter blocks of a context: the ring wraps and is re-zeroed in
     stream order): every repetition gives the bits of the first"""
@@ -145,6 +180,7 @@ def test_chain_repeatable_under_many_launches():
     from lia_amd import _native as N
     from lia_amd.llama import LiaLlamaModel, LlamaKVState, LlamaScheduler, LlamaShape
     shape = LlamaShape("rep", 512, 4, 2, 1024, 2, 1024, max_pos=64)
+    N.lib().lia_set_fused_decode(1)
     model = LiaLlamaModel.random_init(shape, seed=9)
     sched = LlamaScheduler(model)
     B, T = 128, 8
@@ -160,6 +196,7 @@ def test_chain_repeatable_under_many_launches():
         if first is None:
             first = bits
         assert (bits == first).all()
+    N.lib().lia_set_fused_decode(0)
     assert N.lib().lia_chain_launch_count() - n0 >= 300 * 3
     sched.close()
     model.close()
