@@ -204,11 +204,14 @@ int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H,
 /* ---- decode step over a run of HBM-resident layers (build-defined fast path of the per-layer loop) ---------------------
  * The reference runs its resident layers one torch op at a time (lia/modeling_opt.py:1246-1260 -> decoder.py:172-335,
  * attentions.py:393-529: ~10 launches per layer).  These two entry points run n_layers CONSECUTIVE resident layers of one decode
- * step (T == 1, KV cache in HBM = policy 3 arithmetic) as, per layer, ONE attention launch and ONE persistent "chain" launch
- * (csrc/lia_chain.hip: out-proj, norm, MLP, the next layer's norm and q|k|v projection with their split-K combines inside one
- * kernel that keeps its weight stream running across the steps).  Same arithmetic and rounding points as
- * lia_layer_forward(policy 3) / lia_llama_layer_forward called layer by layer; shapes or weight layouts the chain does not
- * cover (rows > 128, q|k|v or gate|up not adjacent) fall back to exactly those calls.
+ * step (T == 1, KV cache in HBM = policy 3 arithmetic) in ONE library call.  By default (lia_set_fused_decode(0)) that is the
+ * per-op route -- lia_layer_forward(policy 3) / lia_llama_layer_forward layer by layer, every layer's closing norm chained into
+ * the next -- which is the faster one as measured (results/r04_ab_*: 16.1 vs 16.9 ms per OPT-30B step, 7.7 vs 8.4 ms per
+ * Llama-3-8B step).  With lia_set_fused_decode(1) / LIA_FUSED_DECODE=1 a layer is ONE attention launch and ONE persistent
+ * "chain" launch (csrc/lia_chain.hip: out-proj, norm, MLP, the next layer's norm and q|k|v projection with their split-K
+ * combines inside one kernel that keeps its weight stream running across the steps): same arithmetic and rounding points, bit
+ * for bit (tests/test_gpu_chain.py); shapes or weight layouts the chain does not cover (rows > 128, q|k|v or gate|up not
+ * adjacent) take the per-op route.
  *   weights: n_layers x 16 (OPT) / n_layers x 9 (Llama) device pointers, layer-major;  kv: n_layers pointers to device caches
  *   x: [B, 1, H] input (never written);  y: [B, 1, H] result;  B <= cache batch, rows [0, B) of the caches are served
  * A grid barrier of a chain launch that cannot complete (bounded spins) makes the next lia_ctx_synchronize* fail with
@@ -218,16 +221,18 @@ int lia_decode_layers(lia_ctx* ctx, const lia_layer_desc* d, int n_layers, const
 int lia_llama_decode_layers(lia_ctx* ctx, const lia_llama_desc* d, int n_layers, const void* const* weights, const lia_bf16* x,
                             lia_bf16* y, lia_kv* const* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int pos0,
                             void* stream);
-/* A/B and test switches.  lia_set_fused_decode(0): the two entry points above take the layer-by-layer route (also env
- * LIA_FUSED_DECODE=0).  lia_gemm_set_split_policy(1): the per-op decode GEMMs cut K exactly as the chain does for the same
+/* A/B and test switches.  lia_set_fused_decode(1): the two entry points above take the persistent-chain route (also env
+ * LIA_FUSED_DECODE=1; default 0).  lia_gemm_set_split_policy(1): the per-op decode GEMMs cut K exactly as the chain does for the same
  * shape, so that the two routes add the same products in the same order and agree bit for bit (also env
  * LIA_GEMM_SPLIT_POLICY=1; 0 = the per-launch heuristics).  lia_chain_launch_count: chain launches since the library was loaded. */
 void lia_set_fused_decode(int on);
 void lia_gemm_set_split_policy(int policy);
 long lia_chain_launch_count(void);
-/* Which kernel runs the decode GEMMs of the per-op route (M <= 128): 1 (default) = the chain kernel as a one-step program, its
- * slabs combined by the per-op combine kernels; 0 = lia_gemm_skinny2_kernel (also env LIA_GEMM_ENGINE=skinny2).  Same bits under
- * lia_gemm_set_split_policy(1).  lia_gemm_chain_engine_count: GEMMs the chain engine has run since the library was loaded. */
+/* Which kernel runs the decode GEMMs of the per-op route (M <= 128): 0 (default) = lia_gemm_skinny2_kernel; 1 (also env
+ * LIA_GEMM_ENGINE=chain) = the chain kernel as a one-step program, its slabs combined by the per-op combine kernels (measured 3-6 %
+ * slower per decode step than skinny2 at the OPT-30B / Llama-3-8B shapes, results/r04_ab_*: kept as the A/B leg and for the
+ * bit-identity tests).  Same bits under lia_gemm_set_split_policy(1).  lia_gemm_chain_engine_count: GEMMs the chain engine has
+ * run since the library was loaded. */
 void lia_gemm_set_engine(int engine);
 long lia_gemm_chain_engine_count(void);
 
@@ -257,6 +262,10 @@ int lia_host_layernorm(const lia_bf16* x, const lia_bf16* g, const lia_bf16* b, 
 int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y, long M,
                     int N, int K, int relu, int n_threads);
 int lia_host_has_avx512_bf16(void);
+/* Per-thread scratch of the host kernels (fp32 C tiles of the linears, score rows of the attention) is refused above this many
+ * bytes (0 = no limit, the default): the call that needed it returns LIA_ERR_MEMORY -- as it does when the allocation itself
+ * fails in a worker thread -- instead of running the box out of memory. */
+void lia_host_set_scratch_limit(size_t bytes_per_thread);
 
 /* ---- weight streamer ------------------------------------------------------------------------------
  * Replaces load_layer / layer_copy under torch.cuda.stream(load_weight_stream) + device-wide syncs

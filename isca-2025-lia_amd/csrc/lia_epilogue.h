@@ -54,8 +54,15 @@ __device__ __forceinline__ void store_quad(const f32x4& v, int m, int n, const L
 }
 
 __device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ partial, int S, int M, int N, int m, int n) {
+  // slice 0, 1, ...: the order of the plain combine; four slices' loads in flight at a time
   f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
-  for (int s = 1; s < S; ++s) a += *(const f32x4*)(partial + ((long)s * M + m) * N + n);     // slice 0, 1, ...: the order of the plain combine
+  for (int s0 = 1; s0 < S; s0 += 4) {
+    f32x4 t[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) t[g] = *(const f32x4*)(partial + ((long)min(s0 + g, S - 1) * M + m) * N + n);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (s0 + g < S) a += t[g];
+  }
   return a;
 }
-

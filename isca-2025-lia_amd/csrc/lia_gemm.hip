@@ -31,12 +31,22 @@ __global__ __launch_bounds__(256) void lia_splitk_reduce_kernel(const float* __r
   if (q >= nq) return;
   int m = (int)(q / (N / 4));
   int n = (int)(q - (long)m * (N / 4)) * 4;
+  // the epilogue's operands and every slab value requested before the first add (r04: a slice per loop trip was S dependent
+  // round trips, the bias / residual loads one more behind them); the sum is still slice 0 + 1 + ...
+  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+  const uint2 bb = hb ? *(const uint2*)(ep.bias + n) : uint2{0u, 0u};
+  const uint2 rr = hr ? *(const uint2*)(ep.residual + (long)m * ep.ldr + n) : uint2{0u, 0u};
   f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
-  for (int s = 1; s < S; ++s) {
-    f32x4 b = *(const f32x4*)(partial + ((long)s * M + m) * N + n);
-    a += b;
+  for (int s0 = 1; s0 < S; s0 += 4) {
+    f32x4 t[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) t[g] = *(const f32x4*)(partial + ((long)min(s0 + g, S - 1) * M + m) * N + n);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (s0 + g < S) a += t[g];
   }
-  store_quad(a, m, n, ep, om);
+  const f32x4 r = epilogue_quad_pre(a, bb, rr, hb, ep.relu, hr);
+  *(uint2*)lia_out_ptr(om, m, n) = uint2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
 }
 
 // ---- split-K combines that also do the next op of the decode layer (LiaPost, lia_common.h) ----
@@ -48,9 +58,10 @@ __global__ __launch_bounds__(LIA_ROW_THREADS) void lia_splitk_reduce_norm_kernel
   __shared__ float red[2 * LIA_ROW_WAVES];
   const int m = blockIdx.x, tid = threadIdx.x;
   const int nv = N >> 3;
-  uint4 v[NV], gv[NV], bv[NV];
-  // slice-outer: the 2 NV loads of one slice are in flight together, S round trips in all (a per-piece loop over the slices
-  // waits 2 NV x S times: 16 us for the 64 rows of OPT-30B's fc2); the sum per element is still slice 0 + 1 + ...
+  uint4 v[NV], gv[NV], bv[NV], eb[NV], er[NV];
+  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+  // every slice's loads of this thread's pieces in flight together, GS slices at a time (r04: a slice per round trip is S
+  // dependent L2 round trips -- 8 us for the 8 slabs of an OPT-30B fc2 row); the sum per element is still slice 0 + 1 + ...
   f32x4 acc[NV][2];
   const float* prow = partial + (long)m * N;
 #pragma unroll
@@ -60,26 +71,37 @@ __global__ __launch_bounds__(LIA_ROW_THREADS) void lia_splitk_reduce_norm_kernel
     if (KIND == LIA_POST_LAYERNORM) bv[k] = *(const uint4*)(post.b + 8 * i);
     acc[k][0] = *(const f32x4*)(prow + 8 * i);
     acc[k][1] = *(const f32x4*)(prow + 8 * i + 4);
+    eb[k] = hb ? *(const uint4*)(ep.bias + 8 * i) : uint4{0u, 0u, 0u, 0u};          // the epilogue's operands travel with the slabs
+    er[k] = hr ? *(const uint4*)(ep.residual + (long)m * ep.ldr + 8 * i) : uint4{0u, 0u, 0u, 0u};
   }
-  for (int s = 1; s < S; ++s) {
-    const float* ps = prow + (long)s * M * N;
-    f32x4 t[NV][2];
+  constexpr int GS = NV == 1 ? 7 : 4;
+  for (int s0 = 1; s0 < S; s0 += GS) {
+    f32x4 t[GS][NV][2];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int i = min(tid + LIA_ROW_THREADS * k, nv - 1);
-      t[k][0] = *(const f32x4*)(ps + 8 * i);
-      t[k][1] = *(const f32x4*)(ps + 8 * i + 4);
+    for (int g = 0; g < GS; ++g) {
+      const float* ps = prow + (long)min(s0 + g, S - 1) * M * N;  // (clamped: a slice beyond the last is loaded again and dropped)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = min(tid + LIA_ROW_THREADS * k, nv - 1);
+        t[g][k][0] = *(const f32x4*)(ps + 8 * i);
+        t[g][k][1] = *(const f32x4*)(ps + 8 * i + 4);
+      }
     }
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { acc[k][0] += t[k][0]; acc[k][1] += t[k][1]; }
+    for (int g = 0; g < GS; ++g) {
+      if (s0 + g < S) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { acc[k][0] += t[g][k][0]; acc[k][1] += t[g][k][1]; }
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int i = tid + LIA_ROW_THREADS * k;
     v[k] = uint4{0u, 0u, 0u, 0u};
     if (i < nv) {
-      const f32x4 lo = epilogue_quad(acc[k][0], m, 8 * i, ep);
-      const f32x4 hi = epilogue_quad(acc[k][1], m, 8 * i + 4, ep);
+      const f32x4 lo = epilogue_quad_pre(acc[k][0], uint2{eb[k].x, eb[k].y}, uint2{er[k].x, er[k].y}, hb, ep.relu, hr);
+      const f32x4 hi = epilogue_quad_pre(acc[k][1], uint2{eb[k].z, eb[k].w}, uint2{er[k].z, er[k].w}, hb, ep.relu, hr);
       v[k] = uint4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
       *(uint4*)(om.base[0] + (long)m * om.ld[0] + 8 * i) = v[k];
     }

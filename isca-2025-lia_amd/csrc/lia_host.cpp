@@ -54,17 +54,32 @@ static inline void team_barrier(LiaTeamBarrier& b, int& local_sense) {
 static inline int team_size() { return omp_in_parallel() ? omp_get_num_threads() : omp_get_max_threads(); }
 
 // a scratch block per thread that only grows (fp32 tiles of the linears, score rows of the attention)
+// A worker whose block cannot grow gets nullptr: it raises g_scratch_failed and SKIPS its share of the loop (every thread
+// still meets every worksharing construct and team barrier, so the region ends normally); the entry point that opened the region
+// returns LIA_ERR_MEMORY afterwards (scratch_failed()).  g_scratch_limit: bytes per thread above which a request is refused
+// (lia_host_set_scratch_limit; 0 = no limit) -- a cap for memory-tight containers, and how the tests reach this path.
+static std::atomic<int> g_scratch_failed{0};
+static std::atomic<size_t> g_scratch_limit{0};
 static inline float* thread_scratch(size_t floats) {
   struct Block { float* p = nullptr; size_t n = 0; ~Block() { free(p); } };
   static thread_local Block blk;
+  const size_t bytes = ((floats * sizeof(float)) + 63) & ~(size_t)63;
+  const size_t limit = g_scratch_limit.load(std::memory_order_relaxed);
+  if (limit && bytes > limit) { g_scratch_failed.store(1, std::memory_order_relaxed); return nullptr; }
   if (blk.n < floats) {
     free(blk.p);
-    const size_t bytes = ((floats * sizeof(float)) + 63) & ~(size_t)63;
     blk.p = (float*)aligned_alloc(64, bytes);
     blk.n = blk.p ? floats : 0;
+    if (!blk.p) { g_scratch_failed.store(1, std::memory_order_relaxed); return nullptr; }
   }
   return blk.p;
 }
+static inline int scratch_failed(const char* who) {
+  if (!g_scratch_failed.exchange(0, std::memory_order_acq_rel)) return LIA_OK;
+  lia_set_error("%s: out of host memory (a worker thread could not get its scratch block)", who);
+  return LIA_ERR_MEMORY;
+}
+extern "C" void lia_host_set_scratch_limit(size_t bytes_per_thread) { g_scratch_limit.store(bytes_per_thread, std::memory_order_relaxed); }
 
 // ------------------------------------------------------------------------------------------------
 // host attention
@@ -114,6 +129,7 @@ static void host_attention_team(const lia_bf16* q, const lia_bf16* k, const lia_
 #pragma omp for collapse(2) schedule(dynamic, 1) nowait
     for (int b = 0; b < B; ++b)
       for (int g = 0; g < ngroups; ++g) {
+        if (!sc) continue;                     // no scratch: thread_scratch raised the flag, the caller reports LIA_ERR_MEMORY
         const long coff = (long)(b0 + b) * hd + (long)g * G * d;
         // append the fresh rows of this (batch row, head group)
         for (int t = 0; t < T; ++t) {
@@ -197,7 +213,7 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
   if (n_threads <= 0) n_threads = omp_get_max_threads();
 #pragma omp parallel num_threads(n_threads)
   host_attention_team(q, k, v, kcache, vcache, out, B, T, pos0, heads, head_dim, cache_batch, b0);
-  return LIA_OK;
+  return scratch_failed("lia_host_attention");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -444,6 +460,7 @@ static void host_linear_skinny_team_t(const lia_bf16* x, const lia_bf16* w, cons
     float* C = thread_scratch((size_t)((M + 3) & ~3) * crow);
 #pragma omp for schedule(dynamic, 1) nowait
     for (int tile = 0; tile < ntiles; ++tile) {
+      if (!C) continue;                        // no scratch: see thread_scratch
       const int nt0 = tile * NT, ntn = N - nt0 < NT ? N - nt0 : NT;
       memset(C, 0, (size_t)((M + 3) & ~3) * crow * sizeof(float));
       for (int k0 = 0; k0 < K; k0 += KC) {
@@ -619,7 +636,7 @@ extern "C" int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_b
   if (int rc = host_isa_ok("lia_host_linear")) return rc;
   if (n_threads > 0) omp_set_num_threads(n_threads);
   host_linear(x, w, bias, residual, y, M, N, K, relu);
-  return LIA_OK;
+  return scratch_failed("lia_host_linear");
 }
 
 // the intermediates of a host layer (ln, q, k, v, attention output, h1: M x H each; f1: M x F), one growing block per CALLING thread
@@ -667,7 +684,7 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   for (int i = 0; i < 16; ++i)
     if (!weights[i]) { lia_set_error("lia_host_layer_forward: weights[%d] is NULL", i); return LIA_ERR_MISSING; }
   const int H = d->hidden, F = d->ffn, heads = d->heads;
-  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || (H / heads) > 128 || H % 32 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
+  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || (H / heads) > 128 || H % 32 || F <= 0 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
       pos0 + T > smax || b0 < 0 || b0 + B > cache_batch) {
     lia_set_error("lia_host_layer_forward: bad shape H=%d heads=%d F=%d B=%d T=%d pos0=%d smax=%d", H, heads, F, B, T, pos0, smax);
     return LIA_ERR_INVALID;
@@ -693,7 +710,7 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
       int sense = 0;
       host_layer_team(d, W, x, y, kcache, vcache, cache_batch, B, T, pos0, b0, sc, mh, bar, sense);
     }
-    return LIA_OK;
+    return scratch_failed("lia_host_layer_forward");
   }
   host_layernorm(x, W[0], W[1], ln, M, H, d->ln_eps);
   host_linear(ln, W[4], W[5], nullptr, k, M, H, H, 0);
@@ -706,7 +723,7 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   host_linear(ln, W[12], W[13], nullptr, f1, M, F, H, 1);
   host_linear(f1, W[14], W[15], h1, y, M, H, F, 0);
   if (scratch.n * sizeof(lia_bf16) > ((size_t)64 << 20)) { free(scratch.p); scratch.p = nullptr; scratch.n = 0; }
-  return LIA_OK;
+  return scratch_failed("lia_host_layer_forward");
 }
 
 // n_layers consecutive decode-sized layers (policy 1's decode step: every layer on the host) in ONE parallel region: the hidden
@@ -723,7 +740,7 @@ extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, co
     if (!kcaches[l] || !vcaches[l]) { lia_set_error("lia_host_layers_forward: cache %d is NULL", l); return LIA_ERR_MISSING; }
   const int H = d->hidden, F = d->ffn, heads = d->heads;
   const long M = (long)B * T;
-  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || (H / heads) > 128 || H % 32 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
+  if (H <= 0 || heads <= 0 || H % heads || (H / heads) % 16 || (H / heads) > 128 || H % 32 || F <= 0 || F % 32 || B <= 0 || T <= 0 || pos0 < 0 ||
       pos0 + T > smax || b0 < 0 || b0 + B > cache_batch || M > 256) {
     lia_set_error("lia_host_layers_forward: bad shape H=%d heads=%d F=%d B=%d T=%d pos0=%d smax=%d (B * T <= 256: decode-sized steps only)",
                   H, heads, F, B, T, pos0, smax);
@@ -746,6 +763,7 @@ extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, co
       lia_bf16* t = in; in = out; out = t;
     }
   }
+  if (int rc = scratch_failed("lia_host_layers_forward")) return rc;
   return n_layers & 1;
 }
 

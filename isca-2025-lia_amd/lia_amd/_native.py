@@ -98,6 +98,7 @@ SIGNATURES = {
     "lia_host_layers_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "lia_host_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_int]),
+    "lia_host_set_scratch_limit": (None, [ctypes.c_size_t]),
     "lia_host_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int]),
     "lia_host_has_avx512_bf16": (c_int, []),
     "lia_stream_create": (c_int, [c_void_p, c_int, c_size_t, ctypes.POINTER(c_void_p)]),

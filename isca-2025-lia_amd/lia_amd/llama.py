@@ -15,7 +15,7 @@ import torch
 from . import _native as N
 from . import ops
 from .model import LayerStore
-from .scheduler import WeightPipeline
+from .scheduler import WeightPipeline, _KV_SERIAL
 
 LLAMA_TENSORS = ("in_norm_w", "q_w", "k_w", "v_w", "o_w", "post_norm_w", "gate_w", "up_w", "down_w")
 
@@ -171,6 +171,7 @@ class LlamaKVState:
     def __init__(self, model, B, smax):
         sh = model.shape
         self.B, self.smax, self.len = B, smax, 0
+        self.serial, self.version = next(_KV_SERIAL), 0
         self.tensors, self.kv = [], []
         for _ in range(sh.layers):
             k = torch.empty((smax, B, sh.kv_heads, sh.head_dim), dtype=torch.bfloat16, device="cuda")
@@ -254,7 +255,7 @@ class LlamaScheduler:
         if T == 1 and n_gpu > 0 and mini == B:
             # decode: the resident run in ONE call -- per layer an attention launch and a persistent chain launch (lia_chain.hip);
             # LIA_FUSED_DECODE=0 / shapes the chain does not cover take the layer-by-layer route inside the library
-            key = (n_gpu, id(kv_state), kv_state.kv[0].k, resident(0)[0])
+            key = (n_gpu, kv_state.serial, kv_state.version, resident(0)[0])
             if getattr(self, "_run_key", None) != key:
                 ptrs = []
                 for i in range(n_gpu):

@@ -23,6 +23,7 @@ run the phase's policy: prefill 0 (minibatched, K/V delivered to the host cache)
 and is not scheduled here.
 """
 import ctypes
+import itertools
 import os
 
 import torch
@@ -252,6 +253,9 @@ class PinnedPool:
         return torch.frombuffer(buf, dtype=torch.int16).view(torch.bfloat16).view(*shape)
 
 
+_KV_SERIAL = itertools.count(1)      # KVState / LlamaKVState objects, numbered: id() values come back after a free
+
+
 class KVState:
     """Per-layer KV caches of one generation: seq-major [Smax,B,h,d] (attentions.py:462-476), in HBM for
     resident layers and in pinned host memory for streamed ones (lia/modeling_opt.py:1270-1281)."""
@@ -263,6 +267,7 @@ class KVState:
         them at a time (host_layers says where it starts) and moved by `move_cache` when the controller changes the host set."""
         sh = model.shape
         self.B, self.smax, self.len = B, smax, 0
+        self.serial, self.version = next(_KV_SERIAL), 0      # (serial, version) names one set of kv[] entries: cached pointer tables key on it
         self.pending = {}          # layer -> ticket of a deferred K/V delivery (scheduler.forward, lia_kv_deliver)
         self.all_on_device = all_on_device
         host_layers = frozenset(host_layers) if all_on_device else frozenset()
@@ -310,6 +315,7 @@ class KVState:
                 N.check(fn(ctypes.c_void_p(d_t.data_ptr()), ctypes.c_void_p(s_t.data_ptr()), ctypes.c_size_t(nbytes)), "lia_memcpy (KV cache move)")
         self.tensors[i] = dst
         self.kv[i] = N.KV(dst[0].data_ptr(), dst[1].data_ptr(), self.smax, self.B, to_device)
+        self.version += 1
         return 2 * nbytes
 
     def close(self):
@@ -317,6 +323,7 @@ class KVState:
         if self._pinned and torch.cuda.is_available():
             torch.cuda.synchronize()      # policy-0 K/V deliveries may still be landing in these blocks
         self.tensors, self.kv, self.dual = [], [], {}
+        self.version += 1
         for ptr, nbytes in self._pinned:
             PinnedPool.release(ptr, nbytes)
         self._pinned = []
@@ -326,6 +333,54 @@ class KVState:
             self.close()
         except Exception:
             pass
+
+
+class CoopStore:
+    """The converged host-layer count of a (model, batch, placement, wire format, host team) configuration, kept in a small JSON file
+    next to the box calibration (LIA_STATE_DIR, default ~/.cache/lia_amd): the next process starts its search ON that count with
+    +-1 probes (a handful of decode steps to `converged`) instead of at the planner's estimate with stride 3.  Best effort: an
+    unreadable / unwritable file only means the search starts from the planner's seed."""
+
+    FILE = "coop_counts.json"
+
+    @staticmethod
+    def path():
+        d = os.environ.get("LIA_STATE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "lia_amd")
+        return os.path.join(d, CoopStore.FILE)
+
+    @staticmethod
+    def load(key):
+        if key is None:
+            return None
+        try:
+            import json
+            with open(CoopStore.path()) as f:
+                e = json.load(f).get(key)
+            return (int(e["count"]), float(e["ms"])) if e else None
+        except (OSError, ValueError, KeyError, TypeError):
+            return None
+
+    @staticmethod
+    def save(key, count, ms):
+        if key is None or ms is None:
+            return False
+        try:
+            import json
+            p = CoopStore.path()
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            try:
+                with open(p) as f:
+                    all_ = json.load(f)
+            except (OSError, ValueError):
+                all_ = {}
+            all_[key] = {"count": int(count), "ms": round(float(ms), 3)}
+            tmp = f"{p}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump(all_, f, indent=1, sort_keys=True)
+            os.replace(tmp, p)                    # whole-file swap: a reader never sees half a file
+            return True
+        except OSError:
+            return False
 
 
 class CoopController:
@@ -349,16 +404,20 @@ class CoopController:
     costs five steps at a neighbouring count and repairs that)."""
 
     STRIDES = (3, 1)
+    UP_MIN_BUSY = 0.9             # below this copy-engine busy share no count ABOVE the centre is probed
 
     def __init__(self, order, start, c_max, expire=96, keep=3, probe_every=16):
         self.order, self.c_max = list(order), min(int(c_max), len(order))
         self.c = max(0, min(int(start), self.c_max))
         self.expire, self.keep, self.probe_every = expire, keep, probe_every
         self.samples = {}             # c -> [(step, ms), ...] the last `keep`
+        self.busy_at = {}             # c -> copy-engine busy share of the last sampled step at c
         self.centre, self.stride_i, self.pending, self.direction, self.run = self.c, 0, None, 0, 0
         self.converged_at, self.converged_ms, self.c_conv, self.last_probe, self.probing, self.slow = None, None, None, 0, False, 0
         self.settle, self.step, self.moves, self.searches = 1, 0, 0, 1
+        self.bracketed = False        # a minimum has been found once: from then on the search moves by +-1 only
         self.trace = []               # (step, c, ms, link busy share)
+        self.store_key, self.seeded = None, False        # (CoopStore) where the converged count is kept across processes
 
     def host_set(self, c=None):
         return frozenset(self.order[:self.c if c is None else c])
@@ -369,10 +428,18 @@ class CoopController:
     def restrict(self, c_max):
         """fewer candidates than planned (the container has no room for more raw host copies)"""
         self.c_max = max(0, min(self.c_max, int(c_max)))
+        clipped = self.c > self.c_max or self.centre > self.c_max
         self.c, self.centre = min(self.c, self.c_max), min(self.centre, self.c_max)
         self.samples = {k: v for k, v in self.samples.items() if k <= self.c_max}
         if self.pending:
             self.pending = [(c, d) for c, d in self.pending if c <= self.c_max]
+        if clipped or self.centre not in self.samples:
+            # the point the search stood on is gone (or was never measured): start over from the clipped centre -- a half-finished
+            # comparison against a centre without samples would compare with None
+            self.c = self.centre
+            self.pending, self.direction, self.run, self.stride_i = None, 0, 0, (len(self.STRIDES) - 1 if self.bracketed else 0)
+            self.converged_at, self.converged_ms, self.c_conv, self.probing, self.slow = None, None, None, False, 0
+            self.settle = max(self.settle, 1)
 
     def new_sequence(self):
         """a new generation: its first decode step also waits for the prefill's K/V deliveries and loads layers on demand"""
@@ -389,7 +456,10 @@ class CoopController:
 
     def _candidates(self, busy, again=False):
         s = self.STRIDES[self.stride_i]
+        busy = self.busy_at.get(self.centre, busy)      # the copy engine's share AT THE CENTRE (the last step may have run at a candidate)
         side = (1, -1) if busy >= 0.97 else (-1, 1)
+        if busy < self.UP_MIN_BUSY:
+            side = (-1,)                # the link idles > 10 % of the step: the host side is the bottleneck, one more host layer cannot pay
         return [(self.centre + d * s, d) for d in side
                 if 0 <= self.centre + d * s <= self.c_max and (again or self.value(self.centre + d * s) is None)]
 
@@ -401,6 +471,7 @@ class CoopController:
             self.settle -= 1
             return self.c
         self.samples[self.c] = (self.samples.get(self.c, []) + [(self.step, step_ms)])[-self.keep:]
+        self.busy_at[self.c] = busy_share
         if self.converged_at is not None and not self.probing:
             self.slow = self.slow + 1 if step_ms > 1.05 * self.converged_ms else 0
             if self.step - self.converged_at >= self.expire or self.slow >= 2 * self.keep:
@@ -418,10 +489,17 @@ class CoopController:
         if self.pending is None:                                  # the centre has just been measured: open this stride
             self.pending = self._candidates(busy_share)
         elif self.c != self.centre:                               # a candidate has just been measured
+            if self.value(self.centre) is None:                   # the centre's samples expired / were dropped: measure it again first
+                self.pending = [(self.c, self.direction)] + list(self.pending or [])
+                self.direction = 0
+                return self._go(self.centre)
             if self.value(self.c) < 0.995 * self.value(self.centre):
                 d, s = self.direction, self.STRIDES[self.stride_i]
                 self.centre, self.run = self.c, self.run + 1
-                nxt = self.centre + d * s * (2 if self.run >= 2 else 1)   # it paid: carry on the same way before looking back
+                far = 2 if (self.run >= 2 and not self.bracketed) else 1
+                nxt = self.centre + d * s * far                   # it paid: carry on the same way before looking back
+                if d > 0 and busy_share < self.UP_MIN_BUSY:
+                    nxt = self.centre
                 nxt = max(0, min(self.c_max, nxt))
                 self.pending = [(nxt, d)] if nxt != self.centre and self.value(nxt) is None else []
             else:
@@ -430,7 +508,8 @@ class CoopController:
             if self.stride_i + 1 >= len(self.STRIDES):
                 if self.converged_at is None or self.centre != self.c_conv:
                     self.converged_at, self.converged_ms, self.c_conv = self.step, self.value(self.centre), self.centre
-                self.last_probe, self.probing = self.step, False
+                    CoopStore.save(self.store_key, self.centre, self.converged_ms)
+                self.last_probe, self.probing, self.bracketed = self.step, False, True
                 return self._go(self.centre)
             self.stride_i, self.run = self.stride_i + 1, 0
             self.pending = self._candidates(busy_share)
@@ -439,6 +518,7 @@ class CoopController:
 
     def report(self):
         return {"host_layers": self.c, "centre": self.centre, "converged": self.converged_at is not None, "max_host_layers": self.c_max,
+                "seeded_from_store": self.seeded,
                 "moves": self.moves, "searches": self.searches, "steps_observed": self.step,
                 "ms_by_count": {str(k): round(self.value(k), 2) for k in sorted(self.samples) if self.value(k) is not None},
                 "trace_tail": self.trace[-12:]}
@@ -679,7 +759,7 @@ class OffloadScheduler:
             # decode: the resident run (whole batch, everything on the GPU incl. KV -- policy 3; :1246-1260) in ONE call: per layer an
             # attention launch and a persistent chain launch (lia_chain.hip); LIA_FUSED_DECODE=0 and shapes the chain does not cover
             # take the layer-by-layer route inside the library
-            key = (n_gpu, id(kv_state), kv_state.kv[0].k, self._resident(0)[0])
+            key = (n_gpu, kv_state.serial, kv_state.version, self._resident(0)[0])
             if getattr(self, "_run_key", None) != key:
                 ptrs = []
                 for i in range(n_gpu):
@@ -792,6 +872,7 @@ class OffloadScheduler:
     def _coop_controller(self, n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, start):
         key = (n_gpu, L, B, decoding_policy)
         if self._coop is None or self._coop_key != key:
+            seeded_ok = start is None            # an explicit start (tests, LIA_COOP_START) is taken as given
             if start is None:
                 from . import hostinfo, planner
                 start, _ = planner.plan_cpu_layers(self.model.shape, B, T, max_new_tokens or 32, gpu_percentage,
@@ -799,7 +880,17 @@ class OffloadScheduler:
                                                                wire_ratio={0: 1.0, 12: 0.751, 11: 0.696, 10: 0.675}[self.pack12]),
                                                    kv_in_hbm=(decoding_policy == 3))
             order = self.cpu_layer_order(n_gpu, L)
+            sh = self.model.shape
+            from . import hostinfo
+            store_key = "|".join(str(v) for v in (sh.name, sh.hidden, sh.ffn, L, n_gpu, B, decoding_policy, self.pack12,
+                                                  self.host_threads or hostinfo.default_host_threads(1)))
+            kept = CoopStore.load(store_key) if seeded_ok else None
+            if kept is not None:
+                start = max(0, min(kept[0], len(order)))
             self._coop = CoopController(order, start, min(len(order), int(start) + int(os.environ.get("LIA_COOP_HEADROOM", "10"))))
+            self._coop.store_key = store_key
+            if kept is not None:                 # a count this box converged on before: look one to each side, nothing further
+                self._coop.seeded, self._coop.bracketed, self._coop.stride_i = True, True, len(CoopController.STRIDES) - 1
             self._coop_key = key
         return self._coop
 
@@ -826,8 +917,13 @@ class OffloadScheduler:
         if fit < len(need):
             new_max = need[fit]                      # candidates before the first one that does not fit
             if new_max <= 0:
-                raise MemoryError(f"cooperative split: no room for a raw host copy of one layer ({st.nbytes / 2**30:.2f} GiB) in this container")
-            coop.restrict(new_max)
+                # cpu_layers = -1 asks for "as many as pay": with no room for even one raw copy that is zero host layers -- the plain
+                # streamed configuration -- not an aborted generation (a fixed cpu_layers > 0 never comes through here; its
+                # placement fails in the allocation guard, loudly)
+                import warnings
+                warnings.warn(f"cooperative split: no room for a raw host copy of one layer ({st.nbytes / 2**30:.2f} GiB) in this "
+                              "container; running with zero host-computed layers", RuntimeWarning, stacklevel=2)
+            coop.restrict(max(new_max, 0))
 
     def host_team_report(self):
         g = getattr(self, "_host_gov", None)
@@ -865,6 +961,23 @@ class OffloadScheduler:
             self._host_gov = hostinfo.HostTeamGovernor(getattr(self, "host_threads", None) or hostinfo.default_host_threads(world))
         return self._host_gov
 
+    def _hidden_pair(self, nbytes):
+        """Two pinned hidden-state buffers for the host-computed layers, kept across steps; a larger request hands the old
+        pair back to the pool first, close() hands back the last one."""
+        cur = getattr(self, "_host_hidden", None)
+        if cur is None or cur[2] < nbytes:
+            self._release_hidden_pair()
+            self._host_hidden = cur = (PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes), nbytes)
+        return cur[0], cur[1]
+
+    def _release_hidden_pair(self):
+        cur = getattr(self, "_host_hidden", None)
+        if cur is not None:
+            self.ctx.synchronize()                 # a blit into / out of the pair may still be in flight
+            PinnedPool.release(cur[0], cur[2])
+            PinnedPool.release(cur[1], cur[2])
+            self._host_hidden = None
+
     def _host_decode_layer(self, idx, x, y, kv_state, B, T, pos0):
         """One decode step of layer idx on the host cores (policy 1 for this layer): hidden state GPU -> pinned host by a
         kernel blit, lia_host_layer_forward on the raw host copy of the weights and the host KV cache, result back."""
@@ -874,9 +987,7 @@ class OffloadScheduler:
         if raw is None:
             raise ValueError(f"layer {idx} is to run on the host but has no raw bf16 host copy")
         nbytes = B * T * sh.hidden * 2
-        if getattr(self, "_host_hidden", None) is None or self._host_hidden[2] < nbytes:
-            self._host_hidden = (PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes), nbytes)
-        hx, hy, _ = self._host_hidden
+        hx, hy = self._hidden_pair(nbytes)
         N.check(lib.lia_blit(ctypes.c_void_p(hx), ctypes.c_void_p(x.data_ptr()), nbytes, ctypes.c_void_p(ctx.stream)), "lia_blit")
         ctx.synchronize()
         from . import hostinfo
@@ -902,9 +1013,7 @@ class OffloadScheduler:
             x, y = y, x
         ctx.synchronize()
         nbytes = B * T * sh.hidden * 2
-        if getattr(self, "_host_hidden", None) is None or self._host_hidden[2] < nbytes:      # two pinned hidden-state buffers, kept across steps
-            self._host_hidden = (PinnedPool.acquire(nbytes), PinnedPool.acquire(nbytes), nbytes)
-        hx, hy, _ = self._host_hidden
+        hx, hy = self._hidden_pair(nbytes)
         N.check(lib.lia_memcpy_d2h(ctypes.c_void_p(hx), ctypes.c_void_p(x.data_ptr()), nbytes), "lia_memcpy_d2h")
         from . import hostinfo
         threads = self._host_team(self.dp.world if self.dp else 1).threads
@@ -916,7 +1025,8 @@ class OffloadScheduler:
         if host and B * T <= 256:
             # a decode step: every host layer in ONE OpenMP region (lia_host_layers_forward); the pointer tables are rebuilt only
             # when a layer's host copy or the caches moved
-            key = (tuple(m.layers[i].host_ptr() for i in host), tuple(kv_state.kv[i].k for i in host))
+            key = (tuple(m.layers[i].host_ptr() for i in host), kv_state.serial, kv_state.version,
+                   tuple(kv_state.kv[i].k for i in host), tuple(kv_state.kv[i].v for i in host))
             tab = getattr(self, "_host_tables", None)
             if tab is None or tab[0] != key:
                 n = len(host)
@@ -955,5 +1065,6 @@ class OffloadScheduler:
             self.pipe = None
         if self.ctx:
             self._await_all_deliveries()
+            self._release_hidden_pair()
             self.ctx.close()
             self.ctx = None

@@ -308,6 +308,59 @@ def test_host_layers_forward_equals_layer_by_layer(native, n_layers):
     assert L.lia_host_layers_forward(ctypes.byref(desc), n_layers, None, x.ctypes.data, y.ctypes.data, kt, vt, smax, B, B, T, pos0, 0, 1) == native.LIA_ERR_MISSING
 
 
+def test_host_kernels_report_scratch_failure_instead_of_crashing(native):
+    """a worker thread that cannot get its scratch block (refused here by lia_host_set_scratch_limit; the same path as a failed
+    aligned_alloc): the call returns LIA_ERR_MEMORY with a message, the team leaves its region in step, and the next call with
+    the limit lifted computes as before; F <= 0 is a shape error"""
+    from lia_amd import ops
+    L = native.lib()
+    if not L.lia_host_has_avx512_bf16():
+        pytest.skip("host without AVX-512-BF16")
+    H, heads, F, B, T, pos0 = 256, 4, 1024, 3, 1, 5
+    d = H // heads
+    smax = pos0 + T + 1
+    desc = ops.make_desc(H, heads, F)
+    W = synth.make_layer(30, H, F, 0.08)
+    flat = [np.ascontiguousarray(W[n]) for n in synth.LAYER_TENSORS]
+    arr = (ctypes.c_void_p * 16)(*[w.ctypes.data for w in flat])
+    rs = np.random.RandomState(11)
+    k0 = synth.f32_to_bf16_bits(rs.standard_normal((smax, B, heads, d)).astype(np.float32))
+    v0 = synth.f32_to_bf16_bits(rs.standard_normal((smax, B, heads, d)).astype(np.float32))
+    x = synth.make_hidden(12, B, T, H)
+
+    def layer(limit):
+        L.lia_host_set_scratch_limit(limit)
+        try:
+            k, v, y = k0.copy(), v0.copy(), np.zeros_like(x)
+            rc = L.lia_host_layer_forward(ctypes.byref(desc), ctypes.byref(arr), x.ctypes.data, y.ctypes.data, k.ctypes.data, v.ctypes.data,
+                                          smax, B, B, T, pos0, 0, 3)
+            return rc, y
+        finally:
+            L.lia_host_set_scratch_limit(0)
+
+    rc0, y0 = layer(0)
+    assert rc0 == 0
+    rc1, _ = layer(64)                                       # 64 bytes per thread: every linear tile and score row is refused
+    assert rc1 == native.LIA_ERR_MEMORY and b"scratch" in L.lia_last_error()
+    rc2, y2 = layer(0)
+    assert rc2 == 0 and (y2 == y0).all()                     # the flag does not leak into the next call
+    L.lia_host_set_scratch_limit(64)
+    try:
+        xs = np.zeros((4, 64), np.uint16)
+        ws = np.zeros((32, 64), np.uint16)
+        ys = np.zeros((4, 32), np.uint16)
+        assert L.lia_host_linear(xs.ctypes.data, ws.ctypes.data, None, None, ys.ctypes.data, 4, 32, 64, 0, 2) == native.LIA_ERR_MEMORY
+        wt = (ctypes.c_void_p * 16)(*[w.ctypes.data for w in flat])
+        kt, vt = (ctypes.c_void_p * 1)(k0.ctypes.data), (ctypes.c_void_p * 1)(v0.ctypes.data)
+        assert L.lia_host_layers_forward(ctypes.byref(desc), 1, wt, x.copy().ctypes.data, np.zeros_like(x).ctypes.data, kt, vt, smax, B, B, T,
+                                         pos0, 0, 3) == native.LIA_ERR_MEMORY
+    finally:
+        L.lia_host_set_scratch_limit(0)
+    bad = ops.make_desc(H, heads, 0)
+    assert L.lia_host_layer_forward(ctypes.byref(bad), ctypes.byref(arr), x.ctypes.data, np.zeros_like(x).ctypes.data, k0.copy().ctypes.data,
+                                    v0.copy().ctypes.data, smax, B, B, T, pos0, 0, 3) == native.LIA_ERR_INVALID
+
+
 _HOST_LINEAR_CASES = [(64, 1000, 2112, 1, 1, 0), (7, 77, 96, 1, 1, 1), (1, 50, 4096, 0, 0, 0), (130, 130, 320, 1, 0, 1), (64, 1536, 1024, 0, 1, 1),
                       (5, 6, 64, 0, 1, 0), (300, 40, 64, 1, 1, 1)]
 

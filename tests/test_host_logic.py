@@ -263,12 +263,124 @@ def test_coop_candidates_shrink_to_the_container(monkeypatch):
     OffloadScheduler._fit_host_candidates(me, ctl3, False)                 # pinned: raw + packed both stay, ceiling 0.85
     assert ctl3.c_max == int((0.85 * 300.1 - 244 - 3.38) // 3.38) == 2
     monkeypatch.setattr(hostinfo, "cgroup_memory", lambda: {"current": int(279 * GiB), "peak": None, "max": int(300.1 * GiB)})
-    with pytest.raises(MemoryError):
-        OffloadScheduler._fit_host_candidates(me, CoopController(order, 10, 20), True)
+    ctl0 = CoopController(order, 10, 20)
+    with pytest.warns(RuntimeWarning, match="zero host-computed layers"):      # not even one copy fits: the plain streamed configuration
+        OffloadScheduler._fit_host_candidates(me, ctl0, True)
+    assert ctl0.c_max == 0 and ctl0.c == 0 and ctl0.host_set() == frozenset() and ctl0.superset() == frozenset()
+    assert ctl0.observe(400.0, 1.0) == 0 and ctl0.observe(400.0, 1.0) == 0 and ctl0.observe(401.0, 1.0) == 0
     monkeypatch.setattr(hostinfo, "cgroup_memory", lambda: {"current": None, "peak": None, "max": None})
     ctl4 = CoopController(order, 40, 50)
     OffloadScheduler._fit_host_candidates(me, ctl4, True)                  # no cgroup limit readable: nothing to fit to
     assert ctl4.c_max == 50
+
+
+def test_coop_controller_survives_restrict_at_any_point():
+    """restrict() in the middle of a search (the raw copies of the upper candidates were lost on a re-placement): the search
+    starts over from the clipped centre instead of comparing against a count that has no samples left"""
+    import random
+    from lia_amd.scheduler import CoopController, OffloadScheduler
+    order = OffloadScheduler.cpu_layer_order(4, 48)
+
+    def box(c):
+        link, host = (44 - c) * 14.7, 110 + c * 15.5
+        return max(link, host), link
+
+    for seed in range(400):
+        rnd = random.Random(seed)
+        ctl = CoopController(order, rnd.randrange(8, 24), 30)
+        for i in range(90):
+            if rnd.random() < 0.08:
+                ctl.restrict(rnd.randrange(0, 31))
+            t, link = box(ctl.c)
+            c = ctl.observe(t * (1 + rnd.uniform(-0.01, 0.01)), min(1.0, link / t))
+            assert 0 <= c <= ctl.c_max and ctl.centre <= ctl.c_max
+        rep = ctl.report()
+        assert rep["host_layers"] <= rep["max_host_layers"]
+    # a comparison against a centre whose samples are gone re-measures the centre first
+    ctl = CoopController(order, 12, 22)
+    for _ in range(4):
+        t, link = box(ctl.c)
+        ctl.observe(t, 1.0)
+    assert ctl.c != ctl.centre
+    ctl.samples.pop(ctl.centre)
+    cand = ctl.c
+    assert ctl.observe(box(cand)[0], 1.0) == cand                       # (the settle step after the move)
+    assert ctl.observe(box(cand)[0], 1.0) == ctl.centre                 # the candidate's sample has nothing to be compared with yet
+    ctl.observe(box(ctl.c)[0], 1.0)
+    assert ctl.observe(box(ctl.c)[0], 1.0) == cand and ctl.value(ctl.centre) is not None   # centre measured: back to the candidate
+
+
+def test_coop_controller_never_probes_upward_while_the_link_idles():
+    """copy engine < 90 % busy = the host side is the bottleneck: counts above the centre are not tried (each such probe is a step
+    at a slower count plus a cache move); and once a minimum has been bracketed the search moves by one count at a time"""
+    from lia_amd.scheduler import CoopController, OffloadScheduler
+    order = OffloadScheduler.cpu_layer_order(4, 48)
+    ctl = CoopController(order, 20, 30)
+    seen = []
+    for _ in range(40):
+        c = ctl.c
+        seen.append(c)
+        link, host = (44 - c) * 14.7, 110 + c * 15.5
+        ctl.observe(max(link, host), min(1.0, link / max(link, host)) * 0.85)       # never above 0.85
+    assert max(seen) == 20 and ctl.report()["converged"], (seen, ctl.report())
+    # bracketed: after the first convergence every move is +-1
+    ctl = CoopController(order, 12, 24)
+    visited = []
+    for i in range(200):
+        c = ctl.c
+        visited.append(c)
+        host_ms = 15.5 if i < 60 else 22.0
+        link, host = (44 - c) * 14.7, 110 + c * host_ms
+        ctl.observe(max(link, host), min(1.0, link / max(link, host)))
+        if ctl.bracketed and "first" not in locals():
+            first = i
+    after = visited[first + 1:]
+    assert ctl.bracketed and all(abs(b - a) <= 2 for a, b in zip(after, after[1:])), (first, visited)   # centre-1 -> centre+1 is a jump of 2
+
+
+def test_coop_store_seeds_the_next_process(tmp_path, monkeypatch):
+    """the converged count is written next to the calibration (LIA_STATE_DIR) and the next controller for the same key starts ON
+    it with +-1 probes: converged within a handful of steps"""
+    from types import SimpleNamespace
+    from lia_amd.scheduler import CoopController, CoopStore, OffloadScheduler
+    monkeypatch.setenv("LIA_STATE_DIR", str(tmp_path))
+    assert CoopStore.load("k") is None and CoopStore.save(None, 3, 1.0) is False
+    assert CoopStore.save("k", 18, 401.234) and CoopStore.load("k") == (18, 401.234)
+    assert CoopStore.save("other", 3, 9.0) and CoopStore.load("k") == (18, 401.234) and CoopStore.load("other") == (3, 9.0)
+    (tmp_path / CoopStore.FILE).write_text("{ not json")
+    assert CoopStore.load("k") is None and CoopStore.save("k", 17, 400.0) and CoopStore.load("k") == (17, 400.0)   # a broken file is replaced
+
+    def box(c):
+        link, host = (44 - c) * 14.7, 110 + c * 15.5
+        return max(link, host), link
+
+    me = SimpleNamespace(model=SimpleNamespace(shape=SimpleNamespace(name="opt-x", hidden=7168, ffn=28672)), pack12=10, host_threads=16,
+                         _coop=None, _coop_key=None, cpu_layer_order=OffloadScheduler.cpu_layer_order)
+    monkeypatch.setattr("lia_amd.planner.plan_cpu_layers", lambda *a, **k: (12, 0.0))
+    ctl = OffloadScheduler._coop_controller(me, 4, 48, 64, 1, 32, 10, 3, None)
+    assert ctl.c == 12 and not ctl.seeded
+    n1 = 0
+    while not ctl.report()["converged"]:
+        t, link = box(ctl.c)
+        ctl.observe(t, min(1.0, link / t))
+        n1 += 1
+    assert ctl.centre == 18 and CoopStore.load(ctl.store_key)[0] == 18
+    me._coop = None                                                          # "the next process"
+    ctl2 = OffloadScheduler._coop_controller(me, 4, 48, 64, 1, 32, 10, 3, None)
+    assert ctl2.seeded and ctl2.c == 18 and ctl2.c_max == 28
+    n2, seen = 0, []
+    while not ctl2.report()["converged"]:
+        seen.append(ctl2.c)
+        t, link = box(ctl2.c)
+        ctl2.observe(t, min(1.0, link / t))
+        n2 += 1
+    assert ctl2.centre == 18 and n2 <= 6 < n1 and set(seen) <= {17, 18, 19}, (n1, n2, seen)
+    me._coop = None
+    ctl3 = OffloadScheduler._coop_controller(me, 4, 48, 64, 1, 32, 10, 3, 9)   # an explicit start is taken as given
+    assert ctl3.c == 9 and not ctl3.seeded
+    me._coop = None
+    ctl4 = OffloadScheduler._coop_controller(me, 4, 48, 32, 1, 32, 10, 3, None)  # another batch size: another key
+    assert not ctl4.seeded and ctl4.c == 12
 
 
 def test_bench_first_divergence_reports_step_and_gap():
