@@ -61,6 +61,7 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raw-leg", action="store_true", help="skip the second, shorter leg with raw bf16 on the wire")
     ap.add_argument("--raw-steps", type=int, default=6)
+    ap.add_argument("--no-defer-kv-leg", action="store_true", help="skip the two extra prefills with LIA_DEFER_KV=0 (prefill_ms_defer_kv_0)")
     ap.add_argument("--no-cooperative-leg", action="store_true", help="skip the build-defined cooperative-split leg (value_cooperative)")
     ap.add_argument("--no-cooperative-kv-leg", action="store_true", help="skip the cooperative split's KV-in-HBM variant (value_cooperative_kv_in_hbm)")
     ap.add_argument("--coop-steps", type=int, default=28, help="decode steps of the cooperative leg (the controller's search takes 12-20; value_cooperative = the last 8)")
@@ -71,8 +72,9 @@ def build_parser():
     ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
     ap.add_argument("--cxl-nodes", default=None, help="NUMA nodes of the CXL tier, e.g. 2,3 (default LIA_CXL_NODES or 2,3)")
     ap.add_argument("--init", default="normal", choices=["normal", "uniform01"])
-    ap.add_argument("--stream-format", default=os.environ.get("LIA_STREAM_FORMAT", "pack10"), choices=sorted(WIRE),
-                    help="wire format of the streamed layers: raw bf16, or a lossless packed encoding")
+    ap.add_argument("--stream-format", default=None, choices=sorted(WIRE),
+                    help="wire format of the streamed layers: raw bf16, or a lossless packed encoding (default: lia_amd.scheduler."
+                         "default_stream_format() = $LIA_STREAM_FORMAT or pack10 -- the same default as run.py / OffloadScheduler)")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--bracket-stride", type=int, default=8, help="HIP-event bracket around every Nth decode GEMM launch (a bracket "
                     "costs two ~6 us idle gaps on the stream; 8 is co-prime to the 193 / 129 launches of an OPT-30B / Llama-3-8B step)")
@@ -225,6 +227,42 @@ def parity_sample(sched, model, shape, B, T, threads):
                     "by ~2*sqrt(p) per GEMM at K >= 7168, hence the lower whole-layer identity rate with a bounded error"}
 
 
+def wire_stats(model, n_gpu):
+    """bits per bf16 value the streamed layers ship, layer by layer: a layer the lossless packing does not shrink (or whose values fall
+    outside the format's window too often) is pinned raw by itself -- LayerStore._encode_packed -- and counts 16 bits here"""
+    per = [16.0 * st.stream_bytes / st.nbytes for st in model.layers[n_gpu:] if st.tier not in ("device", "remote", None) and not st.shard]
+    if not per:
+        return None
+    return {"layers": len(per), "min": min(per), "mean": sum(per) / len(per), "max": max(per),
+            "layers_shipped_raw": sum(1 for st in model.layers[n_gpu:] if st.tier not in ("device", "remote", None) and not st.shard and not st.packed)}
+
+
+def promote_scalars(out):
+    """The driver keeps the standard keys of the line only (metric, value, ..., config, roofline, cpu_baseline): the few scalars a
+    reader needs from the other objects ride inside `roofline` and `config` as well."""
+    r, c = out.get("roofline"), out.get("config")
+    if not isinstance(r, dict) or not isinstance(c, dict):
+        return out
+    dk = r.get("dominant_kernel") if isinstance(r.get("dominant_kernel"), dict) else (r if r.get("kernel") else {})
+    scal = {"prefill_ms": out.get("prefill_ms"), "prefill_ms_defer_kv_0": (out.get("prefill_defer_kv_0_leg") or {}).get("prefill_ms"),
+            "value_raw_format": out.get("value_raw_format"), "value_cooperative": out.get("value_cooperative"),
+            "value_cooperative_kv_in_hbm": out.get("value_cooperative_kv_in_hbm"),
+            "cooperative_converged": [bool(((out.get(k) or {}).get("controller") or {}).get("converged"))
+                                      for k in ("cooperative_leg", "cooperative_kv_in_hbm_leg") if isinstance(out.get(k), dict) and "controller" in out[k]] or None,
+            "dominant_kernel_frac": dk.get("frac"), "dominant_kernel_avg_launch_us": dk.get("avg_launch_us"),
+            "prefill_mfma_frac": (out.get("prefill_detail") or {}).get("mfma_frac"),
+            "parity_max_err_in_quanta": (out.get("parity") or {}).get("max_err_in_quanta"),
+            "parity_frac_bit_identical": (out.get("parity") or {}).get("frac_bit_identical"),
+            "ids_first_divergent_step": {k: v.get("first_divergent_step") for k, v in (out.get("ids_check") or {}).items()} or None,
+            "ids_top2_gap_at_divergence": {k: v.get("top2_logit_gap_at_divergence") for k, v in (out.get("ids_check") or {}).items()
+                                           if v.get("first_divergent_step") is not None} or None}
+    r["scalars"] = {k: v for k, v in scal.items() if v is not None}
+    hl = out.get("host_link") or {}
+    c["stream_format"] = hl.get("stream_format")
+    c["bits_per_value"] = hl.get("bits_per_value_by_layer") or hl.get("bits_per_value")
+    return out
+
+
 def throttle_delta(before):
     """CFS quota stalls of the container since `before` (hostinfo.cgroup_cpu_throttle()): the host-computed legs run sixteen threads
     against a sixteen-CPU quota, so a box whose neighbours or helper threads push it over shows up here, not in the kernels"""
@@ -272,7 +310,34 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index):
+WATCHDOG_EXIT_CODE = 3
+MIN_HOST_THREADS = 4      # a rank whose policy-2 host attention gets fewer threads than this is flagged (per_rank[].host_threads_starved):
+                          # the step is then bound by the shared CPU quota, not by a GPU or a link
+
+
+def watchdog_line(out, progress, timeout_s):
+    """the headline line as the watchdog re-prints it: what finished, which leg was running when the time ran out"""
+    line = dict(out)
+    line.update(progress.get("res", {}))
+    line["dp_extra_legs"] = {"timed_out": True, "leg_running": progress.get("current"), "timeout_s": timeout_s,
+                             "legs_finished": sorted(k[:-4] for k in progress.get("res", {}) if k.endswith("_leg")),
+                             "exit_code": WATCHDOG_EXIT_CODE}
+    return line
+
+
+def watchdog_fire(out, progress, rank, timeout_s, _exit=os._exit):
+    # a thread, not SIGALRM: the main thread of a hung rank sits inside a C call (an RCCL wait, a stream synchronize) and would never
+    # reach a Python signal handler.  No restart, no exec: the process has touched the GPU -- it reports and ends.
+    sys.stderr.write(f"bench.py: rank {rank}: the extra data-parallel leg {progress.get('current')!r} exceeded {timeout_s} s; "
+                     f"keeping the headline line, exit code {WATCHDOG_EXIT_CODE}\n")
+    sys.stderr.flush()
+    if rank == 0:
+        print(json.dumps(promote_scalars(watchdog_line(out, progress, timeout_s))), flush=True)
+    _exit(WATCHDOG_EXIT_CODE)
+
+
+def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index, progress=None,
+                  rows_total=None):
     """N > 1 (every rank calls this): value_kv_in_hbm -- the same broadcast stream with policy 3/3 (KV cache in HBM, no host
     attention: what removes the per-rank host-thread bottleneck) --, value_allgather -- every rank pins 1/N of each streamed
     layer and reads it over ITS OWN host link, one all-gather per layer over xGMI -- and value_allgather_kv_in_hbm, both
@@ -282,10 +347,13 @@ def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs,
     from lia_amd.model import LiaOPTModel
     from lia_amd.scheduler import OffloadScheduler
     dev = "cuda" if backend == "nccl" else "cpu"
-    res = {}
+    progress = {} if progress is None else progress
+    rows_total = B * world if rows_total is None else rows_total
+    res = progress.setdefault("res", {})            # (the watchdog reads what has finished, and which leg was running, from here)
 
     def leg(name, mdl, kwargs):
         t0 = time.time()
+        progress["current"] = name
         try:
             generate(mdl, ids, max_steps=2, **kwargs)                          # placement / allocations of this leg, untimed
             sc = mdl._lia_scheduler
@@ -299,11 +367,12 @@ def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs,
             allv = [torch.zeros_like(v) for _ in range(world)]
             dist.all_gather(allv, v)
             worst = max(float(x[0]) for x in allv)
-            res["value_" + name] = B * world / worst
+            res["value_" + name] = rows_total / worst
             res[name + "_leg"] = {"decode_steps_timed": len(lat[2:]), "ms_per_step": 1e3 * worst, "prefill_ms": 1e3 * max(float(x[1]) for x in allv),
                                   "per_rank_h2d_gbs": [float(x[2]) for x in allv], "leg_s": time.time() - t0}
         except Exception as e:                                                  # (every rank takes the same branch: same shapes, same flags)
             res[name + "_leg"] = {"error": f"{type(e).__name__}: {e}"}
+        progress["current"] = None
 
     leg("kv_in_hbm", model, dict(gen_kwargs, prefill_policy=3, decoding_policy=3))
     if group.mode != "allgather" and world > 1:
@@ -366,8 +435,10 @@ def main(argv=None):
 
     from lia_amd.model import LiaOPTModel, resolve_shape
     from lia_amd.generation import generate
-    from lia_amd.scheduler import OffloadScheduler
+    from lia_amd.scheduler import OffloadScheduler, default_stream_format
     from lia_amd import dp
+    if a.stream_format is None:
+        a.stream_format = default_stream_format()
 
     is_llama = "llama" in a.model.lower()
     if is_llama:
@@ -376,11 +447,12 @@ def main(argv=None):
     else:
         shape = resolve_shape(a.model)
     if a.global_batch:
-        if a.global_batch % world:
-            raise SystemExit(f"--global-batch {a.global_batch} is not divisible by {world} GPUs")
-        B = a.global_batch // world
+        if a.global_batch < world:
+            raise SystemExit(f"--global-batch {a.global_batch} leaves some of the {world} GPUs without a row")
+        lo_, hi_ = dp.shard_rows(a.global_batch, rank, world)      # a remainder goes to the first ranks, one extra row each
+        B, rows_total = hi_ - lo_, a.global_batch
     else:
-        B = a.batch
+        B, rows_total = a.batch, a.batch * world
     T = a.prompt
     new = 1 + a.warmup + a.steps
     if T + new > shape.max_pos:
@@ -469,22 +541,22 @@ def main(argv=None):
 
     my_h2d_gbs = h2d_bytes / (elapsed * 1e9)
     rccl_ranks, per_rank = 1, [{"rank": 0, "host_attention_threads": host_threads, "host_attention_ms_per_step": host_attn_ms_step,
-                                "h2d_gbs": my_h2d_gbs}]
+                                "h2d_gbs": my_h2d_gbs, "rows": B, "host_threads_starved": host_threads < MIN_HOST_THREADS}]
     if dist is not None:
         dev = "cuda" if backend == "nccl" else "cpu"
         tmax = torch.tensor([elapsed, prefill_ms, dec_mean_s], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, prefill_ms, dec_mean_s = float(tmax[0]), float(tmax[1]), float(tmax[2])
-        mine = torch.tensor([float(rank), float(host_threads), host_attn_ms_step, my_h2d_gbs], dtype=torch.float64, device=dev)
+        mine = torch.tensor([float(rank), float(host_threads), host_attn_ms_step, my_h2d_gbs, float(B)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)                      # a real collective over the communicator the run used
         rccl_ranks = dist.get_world_size()
         per_rank = [{"rank": int(v[0]), "host_attention_threads": int(v[1]), "host_attention_ms_per_step": float(v[2]),
-                     "h2d_gbs": float(v[3])} for v in allr]
+                     "h2d_gbs": float(v[3]), "rows": int(v[4]), "host_threads_starved": int(v[1]) < MIN_HOST_THREADS} for v in allr]
 
     out = None
     if rank == 0:
-        tokens = B * world * a.steps
+        tokens = rows_total * a.steps
         sk_n = max(1, prof["skinny_launches"])
         sk_raw_ms = prof["skinny_ms"]
         # the HIP-event bracket reads its own cost too (an empty bracket on the same stream, measured by lia_prof_stop);
@@ -492,7 +564,7 @@ def main(argv=None):
         sk_ms = max(1e-9, sk_raw_ms - sk_n * prof.get("empty_bracket_ms", 0.0))
         achieved = prof["skinny_bytes"] / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
         traffic, traffic_src = (pmc_traffic("lia_gemm_skinny2_kernel<4") if (a.model == "opt-30b" and B == 64) else (None, None))
-        headline = (a.model == "opt-30b" and B * world == 64 and T == 256 and a.gpu_percentage == 10 and not a.cpu_layers)
+        headline = (a.model == "opt-30b" and rows_total == 64 and T == 256 and a.gpu_percentage == 10 and not a.cpu_layers)
         config5 = (a.model == "opt-30b" and a.global_batch == 256 and T == 256 and a.gpu_percentage == 10 and world > 1)
         streamed = (not is_llama) and n_gpu < shape.layers
         link_gbs = h2d_bytes / (elapsed * 1e9)
@@ -503,15 +575,15 @@ def main(argv=None):
         out = {
             "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if headline
                       else ("decode tokens/s (+ prefill ms), OPT-30B bs=256 in256/out32 gpu%=10 batch-sharded (BASELINE config 5)" if config5
-                            else f"decode tokens/s (+ prefill ms), {a.model} bs={B * world} in{T} gpu%={a.gpu_percentage}"),
+                            else f"decode tokens/s (+ prefill ms), {a.model} bs={rows_total} in{T} gpu%={a.gpu_percentage}"),
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{shape.name} shape (random-init {'U[0,1)' if a.init == 'uniform01' else 'N(0,0.02)'}), batch {B}/GPU identical rows, "
+            "config": {"workload": f"{shape.name} shape (random-init {'U[0,1)' if a.init == 'uniform01' else 'N(0,0.02)'}), batch {B if rows_total == B * world else 'ceil(' + str(rows_total) + '/' + str(world) + ')'}/GPU identical rows, "
                                    f"prompt {T}, {new} new tokens, gpu%={a.gpu_percentage} ({n_gpu} resident + {shape.layers - n_gpu} streamed layers), "
                                    f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
                                    f"num-minibatch {a.num_minibatch}{(', ' + (str(a.cpu_layers) if a.cpu_layers > 0 else 'an online-chosen number of') + ' decode layers on the host cores') if a.cpu_layers else ''}",
-                       "global_batch": B * world, "prompt_len": T, "new_tokens": new, "new_tokens_requested": 32 if not is_llama else 128,
+                       "global_batch": rows_total, "rows_per_rank": [dp.shard_rows(rows_total, r, world)[1] - dp.shard_rows(rows_total, r, world)[0] for r in range(world)], "prompt_len": T, "new_tokens": new, "new_tokens_requested": 32 if not is_llama else 128,
                        "new_tokens_note": f"the configuration asks for {32 if not is_llama else 128} new tokens; this run generated 1 + warmup + steps = {new} "
                                           f"(cache sized for {T + new} positions), so the timed decode steps run at S = {T + 1 + a.warmup}..{T + new - 1}",
                        "baseline_config": ("configs[1]" if headline else "configs[4]" if config5 else None),
@@ -530,7 +602,7 @@ def main(argv=None):
                                                 "delivery run right behind the prefill (what the reference's first-token latency contains); here it runs under "
                                                 "decode step 1, which it does not slow down (kv_delivery.first_decode_step_ms vs decode_latency_ms.mean)",
             "protocol": {"entry_point": "lia_amd.generation.generate(token_latency=True)", "max_new_tokens": new,
-                         "prefill_ms": prefill_ms, "decode_tokens_per_s": B * world / dec_mean_s,
+                         "prefill_ms": prefill_ms, "decode_tokens_per_s": rows_total / dec_mean_s,
                          "definition": "prefill = latency_list[0]; decode = batch / mean(latency_list[1:]) (run_generation.py:345-354); "
                                        "`value` brackets the last --steps decode steps with barrier + synchronize"},
             "decode_latency_ms": {"mean": 1e3 * sum(timed) / len(timed), "p90": 1e3 * timed[int(0.9 * (len(timed) - 1))], "max": 1e3 * timed[-1]},
@@ -547,6 +619,7 @@ def main(argv=None):
                          "share_of_step": (sk_ms * a.bracket_stride / a.steps) / (1e3 * elapsed / a.steps)},
             "host_link": {"bound": "pcie", "stream_format": a.stream_format if not is_llama else "raw",
                           "bits_per_value": (16.0 * wire_bytes / raw_bytes) if raw_bytes else None,
+                          "bits_per_value_by_layer": wire_stats(model, n_gpu) if not is_llama else None,
                           "weight_bytes_per_step": raw_bytes if not is_llama else None,
                           "achieved": h2d_bytes / (elapsed * 1e9), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                           "frac": h2d_bytes / (elapsed * 1e9) / PCIE_PEAK_GBS,
@@ -581,6 +654,25 @@ def main(argv=None):
         ids_check[f"{a.stream_format}_vs_raw_wire"] = first_divergence(out_ids, ids_raw, T, logits_raw)
         del logits_raw
         sched.pack12 = fmt
+
+    # ---- the prefill with the reference's K/V semantics: store_cache beside the prefill (modeling_opt.py:334-345), not deferred -----
+    if rank == 0 and world == 1 and not is_llama and not a.no_defer_kv_leg and n_gpu < shape.layers and a.prefill_policy == 0 \
+            and getattr(sched, "defer_kv", False):
+        try:
+            sched.defer_kv = False
+            pre = []
+            for _ in range(2):                                                  # (the first one re-sizes nothing, but warms the path)
+                _, lat_nd = generate(model, ids, max_steps=1, **gen_kwargs)
+                sync()
+                pre.append(1e3 * lat_nd[0])
+            out["prefill_defer_kv_0_leg"] = {"prefill_ms": min(pre), "prefill_ms_runs": pre,
+                                             "what": "first-token latency with LIA_DEFER_KV=0: the streamed layers' K/V rows go to the host caches "
+                                                     "beside the prefill's weight stream (the reference's store_cache), so this number contains the D2H "
+                                                     "of the cache like the reference's does"}
+        except Exception as e:
+            out["prefill_defer_kv_0_leg"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            sched.defer_kv = True
 
     # ---- build-defined cooperative split, beside (never instead of) the headline: the planner's host-computed layer count ------
     if rank == 0 and world == 1 and not is_llama and not a.no_cooperative_leg and not a.cpu_layers and a.decoding_policy == 2 \
@@ -661,23 +753,18 @@ def main(argv=None):
     if dist is not None and (world > 1 or force_dp) and not is_llama and not a.no_dp_extra_legs and n_gpu < shape.layers:
         # The headline of this run is already measured.  It is printed NOW, and again -- extended -- as the last line when the legs
         # are done: should a leg hang in a collective (one rank failing where the others do not), a watchdog ends every rank with
-        # exit code 0 and the line above stays the last JSON line of the output instead of the whole run being lost.
+        # exit code 3 (a process killed inside a collective has NOT succeeded) after rank 0 has re-printed the headline line with
+        # the name of the leg that hung, so the measured headline is still the last JSON line of the output.
         import threading
         if rank == 0:
             out["dp_extra_legs"] = "pending (this line is re-printed with value_kv_in_hbm / value_allgather when they finish)"
-            print(json.dumps(out), flush=True)
-
-        def _watchdog():
-            # a thread, not SIGALRM: the main thread of a hung rank sits inside a C call (an RCCL wait, a stream synchronize) and would
-            # never reach a Python signal handler
-            sys.stderr.write(f"bench.py: rank {rank}: the extra data-parallel legs exceeded {a.dp_extra_timeout} s; keeping the headline line\n")
-            sys.stderr.flush()
-            os._exit(0)
-
-        timer = threading.Timer(a.dp_extra_timeout, _watchdog)
+            print(json.dumps(promote_scalars(out)), flush=True)
+        progress = {}
+        timer = threading.Timer(a.dp_extra_timeout, watchdog_fire, args=(out, progress, rank, a.dp_extra_timeout))
         timer.daemon = True
         timer.start()
-        extra = dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index)
+        extra = dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index,
+                              progress=progress, rows_total=rows_total)
         timer.cancel()
         if rank == 0:
             out.pop("dp_extra_legs", None)
@@ -696,7 +783,7 @@ def main(argv=None):
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(json.dumps(promote_scalars(out)), flush=True)
     return 0
 
 

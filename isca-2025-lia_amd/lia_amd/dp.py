@@ -73,21 +73,33 @@ class DataParallelGroup:
         """Give each rank its own slice of the physical cores it may use (the current affinity mask -- bench.py has already
         narrowed it to the NUMA node of this rank's GPU) for the policy-2 host attention, so G ranks do not oversubscribe one
         another (OpenMP threads inherit the process affinity mask).  Slices are indexed by local rank over `world` equal
-        parts, so ranks that share a node never overlap."""
+        parts, so ranks that share a node never overlap (host_core_slice)."""
         ncpu = ncpu or (os.cpu_count() or 1)
         try:
             avail = sorted(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             return 0
-        phys = [c for c in avail if c < max(1, ncpu // 2)] or avail
-        per = max(1, len(phys) // self.world)
-        lo = (self.local_rank % self.world) * per
-        cores = set(phys[lo:lo + per]) or set(phys)
+        cores = host_core_slice(avail, ncpu, self.local_rank, self.world)
         try:
             os.sched_setaffinity(0, cores)
         except (AttributeError, OSError):
             pass
         return len(cores)
+
+
+def host_core_slice(avail, ncpu, local_rank, world):
+    """The cores of `avail` (sorted ids this process may run on) that local rank `local_rank` of `world` keeps: the physical cores
+    (ids below ncpu / 2 -- the SMT siblings follow them in Linux's numbering) cut into `world` equal runs; the remainder goes
+    unused rather than making slices uneven (a rank with one more thread finishes its host attention no earlier: the step waits
+    for the slowest).  Fewer physical cores than ranks: the ranks share them round-robin, one core each."""
+    phys = [c for c in avail if c < max(1, ncpu // 2)] or list(avail)
+    if not phys:
+        return set()
+    if len(phys) < world:
+        return {phys[local_rank % len(phys)]}
+    per = len(phys) // world
+    lo = (local_rank % world) * per
+    return set(phys[lo:lo + per])
 
 
 class RawDeviceBuffer:

@@ -16,6 +16,7 @@ import torch
 
 from .generation import generate
 from .model import LiaOPTModel, resolve_shape
+from .scheduler import default_stream_format
 
 
 def build_parser():
@@ -31,6 +32,8 @@ def build_parser():
     p.add_argument("--num-warmup", default=10, type=int)
     p.add_argument("--batch-size", default=1, type=int)
     p.add_argument("--token-latency", action="store_true")
+    p.add_argument("--prompt", default=None, type=str,
+                   help="input prompt for self-defined if needed (run_generation.py:87); needs the tokenizer files in the -m directory")
     p.add_argument("--profile", action="store_true",
                    help="one profiled generate() before the timed loop (run_generation.py:103,290-307 runs torch.profiler over five "
                         "there); here the library's own HIP-event brackets: GEMM time / rates per phase, host attention, link traffic")
@@ -44,8 +47,9 @@ def build_parser():
     p.add_argument("--enable-cxl", action="store_true")
     # build-specific
     p.add_argument("--stream-format", default=None, choices=["raw", "pack12", "pack11", "pack10"],
-                   help="wire format of the pinned streamed layers: raw bf16 (what the reference ships; default, or $LIA_STREAM_FORMAT) "
-                        "or a lossless packed format; a model directory in the build's packed format defaults to the format on disk")
+                   help="wire format of the pinned streamed layers: a lossless packed format (default pack10, or $LIA_STREAM_FORMAT; same "
+                        "results bit for bit, fewer bytes over the host link; layers that do not pack are pinned raw) or raw bf16 (what the "
+                        "reference ships); a model directory in the build's packed format defaults to the format on disk")
     p.add_argument("--auto-plan", action="store_true",
                    help="measure this box (lia_amd.planner.calibrate, a few seconds) and let the planner choose --gpu-percentage, "
                         "the policies and --cpu-layers instead of the hand-picked values of llm/scripts/lia_*.sh")
@@ -64,6 +68,35 @@ def synthetic_prompt(vocab, n_tokens, batch, seed=0):
     row = torch.randint(4, vocab, (n_tokens,), generator=g, dtype=torch.int64)
     row[0] = 2
     return row[None, :].repeat(batch, 1)          # prompt = [prompt] * batch_size  (run_generation.py:285)
+
+
+TOKENIZER_FILES = ("tokenizer.json", "tokenizer.model", "vocab.json", "tokenizer_config.json")
+
+
+def load_tokenizer(model_id):
+    """The tokenizer a local checkpoint directory ships (run_generation.py:167, `from_pretrained(args.model_id)`), or None: a shape
+    name (no files offline) or a directory without tokenizer files."""
+    if not os.path.isdir(model_id) or not any(os.path.exists(os.path.join(model_id, f)) for f in TOKENIZER_FILES):
+        return None
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(model_id, local_files_only=True)
+
+
+def prompt_input_ids(args, vocab, tokenizer, out=print):
+    """run_generation.py:262-285: `--prompt` goes through the checkpoint's tokenizer, every row of the batch is that prompt
+    (`prompt = [prompt] * args.batch_size`), and its size is printed.  The reference otherwise draws the text from its prompt.json
+    pool by --input-tokens; that file's texts are not reproduced here, so without --prompt the ids are the synthetic row of
+    --input-tokens tokens as before."""
+    if args.prompt is None:
+        return synthetic_prompt(vocab, int(args.input_tokens), args.batch_size)
+    if tokenizer is None:
+        raise SystemExit("[ERROR] --prompt needs a tokenizer: point -m at a checkpoint directory that ships its tokenizer files "
+                         f"({', '.join(TOKENIZER_FILES[:3])}); {args.model_id!r} has none")
+    row = tokenizer(args.prompt, return_tensors="pt").input_ids.to(torch.int64)
+    if row.numel() == 0 or int(row.max()) >= vocab or int(row.min()) < 0:
+        raise SystemExit(f"[ERROR] the tokenizer produced ids outside the model's vocabulary of {vocab} entries")
+    out("---- Prompt size:", int(row.shape[1]))
+    return row.repeat(args.batch_size, 1)
 
 
 def model_shape(args):
@@ -88,7 +121,7 @@ def auto_plan(args, out=print):
     if os.environ.get("LIA_PLAN_HBM_GB"):          # what-if: pretend the GPU is smaller
         box.hbm_gb = float(os.environ["LIA_PLAN_HBM_GB"])
     max_pct = int(os.environ.get("LIA_PLAN_MAX_GPU_PCT", "100"))     # what-if / tests: cap the resident share
-    fmt = args.stream_format or os.environ.get("LIA_STREAM_FORMAT", "pack10")
+    fmt = args.stream_format or default_stream_format()
     box.wire_ratio = {"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[fmt]
     shape = model_shape(args)
     pl = planner.plan(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, box, max_gpu_percentage=max_pct)
@@ -133,7 +166,7 @@ def load_model(args):
         return load_hf_opt(args.model_id)
     shape = resolve_shape(args.model_id)
     n_gpu = int(shape.layers * args.gpu_percentage / 100)
-    fmt = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[args.stream_format or os.environ.get("LIA_STREAM_FORMAT", "raw")]
+    fmt = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[args.stream_format or default_stream_format()]
     if args.prefill_policy == 1 or args.decoding_policy == 1:
         fmt = 0                      # the host path reads the raw copy in place
     from .scheduler import OffloadScheduler
@@ -212,7 +245,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     print(args)
     if not args.benchmark:
-        print("note: only --benchmark mode exists here (no tokenizer offline); running the benchmark protocol")
+        print("note: only the --benchmark protocol exists here; running it")
     # the reference's launch line is `OMP_NUM_THREADS=40 numactl -m 0 -C 0-39 python run.py ...` (README.md:78): host compute
     # on the node that holds the pinned weights / KV caches.  Here: the NUMA node of GPU 0 (LIA_PIN_NODE overrides, -1 = off).
     import os
@@ -226,7 +259,7 @@ def main(argv=None):
         auto_plan(args)
     model = load_model(args)
     if args.stream_format is None:
-        args.stream_format = os.environ.get("LIA_STREAM_FORMAT", "raw")
+        args.stream_format = default_stream_format()
     from .scheduler import OffloadScheduler
     model._lia_scheduler = OffloadScheduler(model, pack12=args.stream_format)     # generate() drives this scheduler
     generate_kwargs = dict(do_sample=False, num_beams=1, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
@@ -237,7 +270,8 @@ def main(argv=None):
         generate_kwargs["cpu_layers"] = args.cpu_layers
         if args.cpu_layers < 0 and args.cpu_layers_start is not None:
             generate_kwargs["cpu_layers_start"] = args.cpu_layers_start
-    input_ids = synthetic_prompt(model.shape.vocab, int(args.input_tokens), args.batch_size)
+    tokenizer = load_tokenizer(args.model_id)
+    input_ids = prompt_input_ids(args, model.shape.vocab, tokenizer)
     if args.profile:
         profile_once(model, input_ids, generate_kwargs)
     total_time, total_list = 0.0, []
@@ -247,6 +281,8 @@ def main(argv=None):
         gen_ids = output[0] if args.token_latency else output
         toc = time.time()
         total_new_tokens = [int(o.shape[0] - i_.shape[0]) for i_, o in zip(input_ids, gen_ids)]
+        if tokenizer is not None and args.prompt is not None:                 # run_generation.py:321-323
+            print(tokenizer.batch_decode(gen_ids, skip_special_tokens=True)[:1], total_new_tokens[:4], flush=True)
         print(gen_ids[0, input_ids.shape[1]:].tolist(), total_new_tokens[:4], flush=True)
         print("Iteration: %d, Time: %.6f sec" % (i, toc - tic), flush=True)
         if i >= args.num_warmup:

@@ -52,7 +52,8 @@ class WeightPipeline:
             self.copy_stream = torch.cuda.ExternalStream(self.lib.lia_stream_copy_stream(h))
             self.staging_tensors = None
             # the root tells every rank which layers travel pack12-encoded and how many bytes each one ships
-            meta = torch.zeros((len(model.layers), 2), dtype=torch.int64, device="cuda")
+            # (gloo validation runs without a GPU -- tests/test_dp_gloo.py -- keep the table on the host)
+            meta = torch.zeros((len(model.layers), 2), dtype=torch.int64, device="cuda" if torch.cuda.is_available() else "cpu")
             if dp_group.is_root:
                 for i, st in enumerate(model.layers):
                     if st.tier not in ("device", None):
@@ -251,6 +252,20 @@ class PinnedPool:
             n *= d
         buf = (ctypes.c_char * (2 * n)).from_address(ptr)
         return torch.frombuffer(buf, dtype=torch.int16).view(torch.bfloat16).view(*shape)
+
+
+DEFAULT_STREAM_FORMAT = "pack10"      # one default for OffloadScheduler, run_generation.py and bench.py
+
+
+def default_stream_format():
+    """Wire format of the pinned streamed layers when the caller names none: $LIA_STREAM_FORMAT, else pack10 -- a LOSSLESS encoding
+    (the device decodes it back to the same bf16 bits, tests/test_gpu_ops.py), so the results are those of the reference's raw
+    transfer; a layer whose values do not pack (encoding >= raw size, or too many out-of-window values) is pinned raw by itself
+    (LayerStore._encode_packed).  `raw` = what the reference ships (Tensor.pin_memory of the bf16 tensors, modeling_opt.py:207-227)."""
+    fmt = os.environ.get("LIA_STREAM_FORMAT", DEFAULT_STREAM_FORMAT).lower()
+    if fmt not in ("raw", "pack10", "pack11", "pack12"):
+        raise ValueError(f"LIA_STREAM_FORMAT={fmt!r}: expected raw, pack10, pack11 or pack12")
+    return fmt
 
 
 _KV_SERIAL = itertools.count(1)      # KVState / LlamaKVState objects, numbered: id() values come back after a free
@@ -532,7 +547,7 @@ class OffloadScheduler:
         self.model, self.device, self.dp = model, device, dp_group
         self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "4"))
         # wire format of the streamed layers: "pack12" (lossless 12-bit encoding, lia_pack12.hip) or "raw" bf16
-        fmt = os.environ.get("LIA_STREAM_FORMAT", "raw").lower() if pack12 is None else pack12
+        fmt = default_stream_format() if pack12 is None else pack12
         self.pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, False: 0, True: 12, 0: 0, 10: 10, 11: 11, 12: 12}[fmt]
         self.ctx = None
         self.ws_rows = 0

@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,3 +32,71 @@ def test_bench_flag_surface():
     assert 1 + a.warmup + a.steps == 32                      # the config's "out 32" by default
     a = bench.build_parser().parse_args(["--gpus", "8", "--global-batch", "256", "--steps", "20", "--warmup", "5"])
     assert a.global_batch // a.gpus == 32                    # BASELINE config 5
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lia_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_watchdog_names_the_leg_and_exits_non_zero(capsys):
+    """a data-parallel extra leg that hangs in a collective: rank 0 re-prints the headline line with the leg's name and what had
+    finished, every rank ends with exit code 3 -- never 0, the process was killed inside GPU work"""
+    import json
+    bench = _load_bench()
+    out = {"metric": "m", "value": 1.0, "roofline": {"bound": "pcie", "dominant_kernel": {"frac": 0.6, "avg_launch_us": 70.0}}, "config": {"workload": "w"},
+           "dp_extra_legs": "pending"}
+    progress = {"current": "allgather", "res": {"value_kv_in_hbm": 123.0, "kv_in_hbm_leg": {"ms_per_step": 5.0}}}
+    codes = []
+    bench.watchdog_fire(out, progress, 0, 420, _exit=codes.append)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert codes == [3] and bench.WATCHDOG_EXIT_CODE == 3
+    assert line["dp_extra_legs"] == {"timed_out": True, "leg_running": "allgather", "timeout_s": 420, "legs_finished": ["kv_in_hbm"], "exit_code": 3}
+    assert line["value_kv_in_hbm"] == 123.0 and line["value"] == 1.0
+    codes.clear()
+    bench.watchdog_fire(out, progress, 2, 420, _exit=codes.append)            # another rank: no line, same exit code
+    assert codes == [3] and capsys.readouterr().out == ""
+
+
+def test_bench_line_carries_its_scalars_inside_roofline_and_config():
+    """the driver keeps only the standard keys: value_raw_format, value_cooperative, prefill_ms, parity, first-divergence steps,
+    the dominant kernel's fraction and the prefill's MFMA fraction are repeated inside `roofline`, the wire format inside `config`"""
+    from types import SimpleNamespace as NS
+    bench = _load_bench()
+    out = {"roofline": {"bound": "pcie", "frac": 0.89, "dominant_kernel": {"frac": 0.6, "avg_launch_us": 70.0}},
+           "config": {"workload": "w"}, "prefill_ms": 690.0, "value_raw_format": 66.9, "value_cooperative": 176.4,
+           "cooperative_leg": {"controller": {"converged": True}}, "cooperative_kv_in_hbm_leg": {"controller": {"converged": False}},
+           "prefill_detail": {"mfma_frac": 0.58}, "parity": {"max_err_in_quanta": 2.0, "frac_bit_identical": 0.4},
+           "prefill_defer_kv_0_leg": {"prefill_ms": 727.0},
+           "ids_check": {"pack10_vs_raw_wire": {"first_divergent_step": None}, "cooperative_vs_headline": {"first_divergent_step": 3, "top2_logit_gap_at_divergence": 0.0625}},
+           "host_link": {"stream_format": "pack10", "bits_per_value": 10.8, "bits_per_value_by_layer": {"layers": 44, "min": 10.7, "mean": 10.8, "max": 16.0, "layers_shipped_raw": 1}}}
+    sc = bench.promote_scalars(out)["roofline"]["scalars"]
+    assert sc["value_raw_format"] == 66.9 and sc["value_cooperative"] == 176.4 and sc["prefill_ms"] == 690.0 and sc["prefill_ms_defer_kv_0"] == 727.0
+    assert sc["dominant_kernel_frac"] == 0.6 and sc["prefill_mfma_frac"] == 0.58 and sc["parity_max_err_in_quanta"] == 2.0
+    assert sc["ids_first_divergent_step"] == {"pack10_vs_raw_wire": None, "cooperative_vs_headline": 3} and sc["cooperative_converged"] == [True, False]
+    assert sc["ids_top2_gap_at_divergence"] == {"cooperative_vs_headline": 0.0625}
+    assert out["config"]["stream_format"] == "pack10" and out["config"]["bits_per_value"]["layers_shipped_raw"] == 1
+    # all-resident line: the decode GEMM is the roofline itself
+    res = bench.promote_scalars({"roofline": {"bound": "hbm", "kernel": "k", "frac": 0.7, "avg_launch_us": 50.0}, "config": {}})
+    assert res["roofline"]["scalars"] == {"dominant_kernel_frac": 0.7, "dominant_kernel_avg_launch_us": 50.0}
+    st = lambda n, sb, packed, tier="pinned": NS(nbytes=n, stream_bytes=sb, packed=packed, tier=tier, shard=None)      # noqa: E731
+    model = NS(layers=[st(1000, 1000, 0, "device"), st(1000, 675, 10), st(1000, 1000, 0), st(1000, 700, 10)])
+    ws = bench.wire_stats(model, 1)
+    assert ws["layers"] == 3 and ws["layers_shipped_raw"] == 1 and ws["max"] == 16.0 and abs(ws["min"] - 10.8) < 1e-9
+
+
+def test_bench_and_harness_share_one_default_wire_format(monkeypatch):
+    """bench.py, run.py and OffloadScheduler resolve an unnamed wire format through the same function"""
+    from lia_amd import run_generation, scheduler
+    bench = _load_bench()
+    monkeypatch.delenv("LIA_STREAM_FORMAT", raising=False)
+    assert scheduler.default_stream_format() == scheduler.DEFAULT_STREAM_FORMAT == "pack10"
+    assert bench.build_parser().parse_args([]).stream_format is None and run_generation.build_parser().parse_args([]).stream_format is None
+    monkeypatch.setenv("LIA_STREAM_FORMAT", "raw")
+    assert scheduler.default_stream_format() == "raw"
+    monkeypatch.setenv("LIA_STREAM_FORMAT", "zip")
+    with pytest.raises(ValueError):
+        scheduler.default_stream_format()

@@ -30,3 +30,31 @@ def test_summary_matches_reference_protocol(capsys):
     assert abs(res["prefill_ms"] - 1100.0) < 1e-6 and abs(res["decode_tokens_per_s"] - 64 / 0.15) < 1e-6
     ids = synthetic_prompt(50272, 256, 64)
     assert ids.shape == (64, 256) and (ids == ids[0]).all() and ids[0, 0] == 2 and ids.min() >= 2
+
+
+def test_prompt_goes_through_the_checkpoint_directorys_tokenizer(tmp_path, capsys):
+    """--prompt (run_generation.py:87,264-285): tokenized with the tokenizer the -m directory ships, one identical row per batch
+    entry, "---- Prompt size" printed; without tokenizer files --prompt is an error, and without --prompt the ids stay synthetic"""
+    import torch
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from lia_amd import run_generation as rg
+    words = ["<pad>", "</s>", "<unk>", "the", "weights", "stay", "on", "host", "and", "stream", "layer", "by"]
+    tok = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", pad_token="<pad>", eos_token="</s>").save_pretrained(str(d))
+    t = rg.load_tokenizer(str(d))
+    assert t is not None and rg.load_tokenizer("facebook/opt-30b") is None and rg.load_tokenizer(str(tmp_path)) is None
+    args = rg.build_parser().parse_args(["-m", str(d), "--batch-size", "3", "--prompt", "the weights stay on host and stream layer by layer"])
+    ids = rg.prompt_input_ids(args, 64, t)
+    assert ids.dtype == torch.int64 and ids.shape == (3, 10) and ids[0].tolist() == [3, 4, 5, 6, 7, 8, 9, 10, 11, 10]
+    assert (ids == ids[0]).all() and "---- Prompt size: 10" in capsys.readouterr().out
+    assert t.batch_decode(ids, skip_special_tokens=True)[0] == "the weights stay on host and stream layer by layer"
+    with pytest.raises(SystemExit, match="tokenizer"):
+        rg.prompt_input_ids(args, 64, None)
+    with pytest.raises(SystemExit, match="vocabulary"):
+        rg.prompt_input_ids(args, 8, t)                            # the model's embedding table is smaller than the tokenizer's ids
+    plain = rg.build_parser().parse_args(["-m", str(d), "--batch-size", "2", "--input-tokens", "16"])
+    assert plain.prompt is None and torch.equal(rg.prompt_input_ids(plain, 64, t), rg.synthetic_prompt(64, 16, 2))

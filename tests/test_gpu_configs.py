@@ -341,6 +341,32 @@ def test_run_generation_main_on_a_checkpoint_directory(tmp_path, capsys, blocked
     assert seen["ids"].shape == (B, T)
 
 
+def test_run_generation_prompt_through_the_checkpoints_tokenizer(tmp_path, capsys):
+    """`run.py -m <dir> --prompt "..."` (run_generation.py:87,264-285,321): the directory's tokenizer turns the text into the ids,
+    every row is that prompt, the continuation is the HF golden one and the decoded text is printed"""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from lia_amd import run_generation
+    z = np.load(os.path.join(GOLD, "generate_h256.npz"))
+    vocab, max_pos, H, heads, F, L, B, T, new, seed = [int(v) for v in z["cfg"]]
+    c = dict(vocab=vocab, max_pos=max_pos, H=H, heads=heads, F=F, L=L)
+    m = synth.make_model(seed, vocab, max_pos, H, F, L, float(z["w_std"][0]))
+    ckpt = str(tmp_path / "opt-test")
+    _write_hf_checkpoint(ckpt, m, c, blocked=False)
+    tok = Tokenizer(models.WordLevel({f"w{i}": i for i in range(vocab)}, unk_token="w3"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="w3", pad_token="w1", eos_token="w2").save_pretrained(ckpt)
+    prompt = synth.make_prompt_ids(seed + 1, B, T, vocab)[0]
+    text_in = " ".join(f"w{int(i)}" for i in prompt)
+    res = run_generation.main(["--benchmark", "-m", ckpt, "--dtype", "bfloat16", "--prompt", text_in, "--max-new-tokens", str(new),
+                               "--batch-size", str(B), "--token-latency", "--num-iter", "2", "--num-warmup", "1", "--greedy",
+                               "--prefill-policy", "0", "--decoding-policy", "2", "--gpu-percentage", "50", "--pin-weight"])
+    text = capsys.readouterr().out
+    assert f"---- Prompt size: {T}" in text and res["decode_tokens_per_s"] > 0
+    assert text.count(str(z["ids_bf16"][0, T:].tolist())) == 2, text[-2000:]
+    assert " ".join(f"w{int(i)}" for i in z["ids_bf16"][0, T:]) in text          # batch_decode of prompt + continuation
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # f-2: the on-disk streaming format + the dummy-weight generator twin; f-3: --auto-plan
 # ---------------------------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode, backend="gloo"):
+def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode, backend="gloo", rows=None):
     for p in (ROOT, os.path.join(ROOT, "isca-2025-lia_amd"), GOLD):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIA_DP_CHUNK_BYTES=str(96 * 1024), LIA_DP_STREAM=mode)
@@ -45,6 +45,9 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode, backend=
         vocab, max_pos, H, heads, F, L, B, T, new, seed = [int(v) for v in z["cfg"]]
         m = synth.make_model(seed, vocab, max_pos, H, F, L, float(z["w_std"][0]))
         ids = synth.make_prompt_ids(seed + 1, B, T, vocab)
+        want = z["ids_bf16"]
+        if rows is not None:                      # a global batch of len(rows) rows drawn from the golden ones (rows are independent)
+            ids, want, B = ids[list(rows)], want[list(rows)], len(rows)
         shape = OPTShape("test", H, heads, F, L, vocab=vocab, max_pos=max_pos)
         model = LiaOPTModel.from_numpy(shape, m)
         n_gpu = int(L * gpu_percentage / 100)
@@ -60,9 +63,9 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode, backend=
         lo, hi = dp.shard_rows(B, rank, world)
         out = generate(model, mine, max_new_tokens=new, min_new_tokens=new, prefill_policy=0, decoding_policy=2,
                        gpu_percentage=gpu_percentage, pin_weight=True)
-        assert (out.numpy() == z["ids_bf16"][lo:hi]).all(), (rank, out[:, T:].tolist())
+        assert out.shape[0] == hi - lo and (out.numpy() == want[lo:hi]).all(), (rank, out[:, T:].tolist())
         full = g.gather_ids(out, B)
-        assert (full.numpy() == z["ids_bf16"]).all()
+        assert full.shape[0] == B and (full.numpy() == want).all()
         if g.is_root or mode == "allgather":       # the host copies really are in the wire format that was asked for
             assert all(st.packed == {"raw": 0, "pack10": 10}[fmt] for st in model.layers[n_gpu:]), [st.packed for st in model.layers]
         if backend == "nccl":
@@ -101,3 +104,14 @@ def test_rccl_backend_world1_streamer_matches_golden(tmp_path, fmt, mode):
     port = _free_port()
     mp.spawn(_worker, args=(1, port, str(tmp_path), fmt, "generate_h256", 25, mode, "nccl"), nprocs=1, join=True)
     assert (tmp_path / "ok0").exists()
+
+
+@pytest.mark.parametrize("mode,fmt", [("broadcast", "pack10"), ("allgather", "raw")])
+def test_four_ranks_one_gpu_ragged_global_batch(tmp_path, mode, fmt):
+    """FOUR ranks on the one GPU, a global batch of 6 rows (not divisible by 4: ranks hold 2, 2, 1, 1): dp.shard_rows' remainder
+    ranks run a smaller batch through the same broadcast / all-gather schedule, and the gathered ids are the golden rows in order.
+    (What `bench.py --gpus 4 --global-batch 6` shards.)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(4, port, str(tmp_path), fmt, "generate_h256", 50, mode, "gloo", (0, 1, 2, 3, 1, 0)), nprocs=4, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(4))
