@@ -67,6 +67,9 @@ def build_parser():
     ap.add_argument("--coop-steps", type=int, default=28, help="decode steps of the cooperative leg (the controller's search takes 12-20; value_cooperative = the last 8)")
     ap.add_argument("--no-dp-extra-legs", action="store_true", help="N > 1: skip the KV-in-HBM and all-gather legs")
     ap.add_argument("--dp-extra-steps", type=int, default=6)
+    ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL; gloo for dry runs with --dp-same-gpu)")
+    ap.add_argument("--dp-same-gpu", action="store_true", help="dry run: the ranks share GPU 0 (one-GPU box, --dp-backend gloo)")
+    ap.add_argument("--force-dp", action="store_true", help="dry run: take the data-parallel (broadcast) path at world size 1")
     ap.add_argument("--dp-extra-timeout", type=int, default=420, help="seconds the extra legs may take before the run ends with the headline line only")
     ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the policy-1 CPU baseline leg")
     ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
@@ -412,18 +415,18 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    # LIA_DP_SAME_GPU=1 (validation only, with LIA_DP_BACKEND=gloo): several ranks share one GPU, so the whole
+    # --dp-same-gpu (validation only, with --dp-backend gloo): several ranks share one GPU, so the whole
     # batch-shard path (remote tiers, chunked broadcast into staging, decode on non-root ranks) runs on a 1-GPU box
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if os.environ.get("LIA_DP_SAME_GPU") == "1" else local_rank
-    backend = os.environ.get("LIA_DP_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if a.dp_same_gpu else local_rank
+    backend = a.dp_backend
     torch.cuda.set_device(dev_index)
     # the reference pins its CPU work with `numactl -m 0 -C 0-39` (README.md:78); here: the cores of the GPU's NUMA node, where
     # the pinned weights and KV caches live (LIA_PIN_NODE=<n> overrides, -1 = no pinning).  Must precede the first OpenMP team.
     from lia_amd import hostinfo
-    pin_node = int(os.environ["LIA_PIN_NODE"]) if os.environ.get("LIA_PIN_NODE") is not None else hostinfo.gpu_numa_node(dev_index)
+    pin_node = hostinfo.pin_node(dev_index)
     pinned_cpus = hostinfo.pin_to_node(pin_node) if pin_node >= 0 else 0
     dist = None
-    force_dp = os.environ.get("LIA_FORCE_DP") == "1"      # exercise the broadcast path on a single GPU (world 1)
+    force_dp = a.force_dp                                 # exercise the broadcast path on a single GPU (world 1)
     if world > 1 or force_dp:
         import torch.distributed as dist
         if "RANK" not in os.environ:

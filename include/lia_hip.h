@@ -223,18 +223,26 @@ int lia_llama_decode_layers(lia_ctx* ctx, const lia_llama_desc* d, int n_layers,
                             void* stream);
 /* A/B and test switches.  lia_set_fused_decode(1): the two entry points above take the persistent-chain route (also env
  * LIA_FUSED_DECODE=1; default 0).  lia_gemm_set_split_policy(1): the per-op decode GEMMs cut K exactly as the chain does for the same
- * shape, so that the two routes add the same products in the same order and agree bit for bit (also env
- * LIA_GEMM_SPLIT_POLICY=1; 0 = the per-launch heuristics).  lia_chain_launch_count: chain launches since the library was loaded. */
+ * shape, so that the two routes add the same products in the same order and agree bit for bit (0 = the per-launch
+ * heuristics).  lia_chain_launch_count: chain launches since the library was loaded. */
 void lia_set_fused_decode(int on);
 void lia_gemm_set_split_policy(int policy);
 long lia_chain_launch_count(void);
-/* Which kernel runs the decode GEMMs of the per-op route (M <= 128): 0 (default) = lia_gemm_skinny2_kernel; 1 (also env
- * LIA_GEMM_ENGINE=chain) = the chain kernel as a one-step program, its slabs combined by the per-op combine kernels (measured 3-6 %
+/* Which kernel runs the decode GEMMs of the per-op route (M <= 128): 0 (default) = lia_gemm_skinny2_kernel; 1 = the chain kernel as a one-step program, its slabs combined by the per-op combine kernels (measured 3-6 %
  * slower per decode step than skinny2 at the OPT-30B / Llama-3-8B shapes, results/r04_ab_*: kept as the A/B leg and for the
  * bit-identity tests).  Same bits under lia_gemm_set_split_policy(1).  lia_gemm_chain_engine_count: GEMMs the chain engine has
  * run since the library was loaded. */
 void lia_gemm_set_engine(int engine);
 long lia_gemm_chain_engine_count(void);
+/* Further A/B switches over implementations of the SAME arithmetic (bit-identical, tests/test_gpu_fused_combine.py):
+ * fuse_combine(0): every post op of a split-K GEMM (norm, SiLU*up, RoPE) is a kernel of its own instead of riding the combine;
+ * inlaunch_combine(1): the last-arriving K slice combines a tile's slabs inside the GEMM launch (measured slower at the decode
+ * shapes); tiled_variant: 262 (default) phased prefill GEMM, 259-261 its other phase / LDS-DMA forms, 256-258 the r01 kernels.
+ * lia_gemm_fused_combine_count(kind): fused combines launched per LIA_POST_* kind since the library was loaded. */
+void lia_gemm_set_fuse_combine(int on);
+void lia_gemm_set_inlaunch_combine(int on);
+void lia_gemm_set_tiled_variant(int variant);
+long lia_gemm_fused_combine_count(int kind);
 
 /* ---- host side of the cooperative policies -------------------------------------------------------
  * Indirect-access-KV masked MHA, csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp:513-842: fp32

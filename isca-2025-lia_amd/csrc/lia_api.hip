@@ -73,7 +73,6 @@ struct lia_ctx {
   char* host_stage;          // pinned: q|k|v and attention output of the policy-2 round trip
   size_t host_stage_bytes;
   int host_threads;
-  hipEvent_t sync_ev[2] = {nullptr, nullptr};   // LIA_BLOCKING_SYNC=1: the host sleeps in lia_ctx_synchronize instead of spinning
   long last_rows, last_slab_rows;  // workspace layout of the previous layer call
   // live kernel timing for bench.py's roofline object (lia_prof_*)
   bool prof_on;
@@ -184,8 +183,6 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
   if (c->chain_tmp) (void)hipFree(c->chain_tmp);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->deliver_t0) { (void)hipEventDestroy(c->deliver_t0); (void)hipEventDestroy(c->deliver_t1); }
-  for (int i = 0; i < 2; ++i)
-    if (c->sync_ev[i]) (void)hipEventDestroy(c->sync_ev[i]);
   if (c->deliver_events) {
     for (hipEvent_t e : *c->deliver_events) (void)hipEventDestroy(e);
     delete c->deliver_events;
@@ -204,14 +201,10 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
 extern "C" void* lia_ctx_compute_stream(lia_ctx* c) { return c ? (void*)c->compute : nullptr; }
 extern "C" int lia_ctx_serialized(lia_ctx* c) { return c && c->serialized ? 1 : 0; }
 
-// A/B knob (LABNOTES.md r03): hipStreamSynchronize spins on this image, one CPU of the container's CFS quota for as long as the
-// GPU works; with LIA_BLOCKING_SYNC=1 the wait is a blocking event instead (the thread sleeps, +20-50 us to wake).
-static int ctx_wait(lia_ctx* c, int which, hipStream_t st) {
-  static const bool blocking = [] { const char* e = getenv("LIA_BLOCKING_SYNC"); return e && atoi(e) == 1; }();
-  if (!blocking) { HIP_TRY(hipStreamSynchronize(st)); return LIA_OK; }
-  if (!c->sync_ev[which]) HIP_TRY(hipEventCreateWithFlags(&c->sync_ev[which], hipEventBlockingSync | hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(c->sync_ev[which], st));
-  HIP_TRY(hipEventSynchronize(c->sync_ev[which]));
+// hipStreamSynchronize spins on this image (one CPU of the container's CFS quota for as long as the GPU works); a blocking event
+// instead (the thread sleeps, +20-50 us to wake) was measured in r03: less throttling, no gain per step (LABNOTES.md) -- spinning stays.
+static int ctx_wait(hipStream_t st) {
+  HIP_TRY(hipStreamSynchronize(st));
   return LIA_OK;
 }
 
@@ -228,14 +221,14 @@ static int chain_check(lia_ctx* c) {
 
 extern "C" int lia_ctx_synchronize(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
-  if (int rc = ctx_wait(c, 0, c->compute)) return rc;
-  if (int rc = ctx_wait(c, 1, c->d2h)) return rc;
+  if (int rc = ctx_wait(c->compute)) return rc;
+  if (int rc = ctx_wait(c->d2h)) return rc;
   return chain_check(c);
 }
 
 extern "C" int lia_ctx_synchronize_compute(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
-  if (int rc = ctx_wait(c, 0, c->compute)) return rc;
+  if (int rc = ctx_wait(c->compute)) return rc;
   return chain_check(c);
 }
 
@@ -1452,10 +1445,9 @@ static int ensure_staging(lia_streamer* s) {
   HIP_TRY(hipMalloc((void**)&s->staging, s->staging_bytes * s->n_slots));
   // The wire-format decode has a whole layer's link time (~14 ms for OPT-30B) to rebuild a layer and needs ~1/30 of the chip for
   // that, but launched on a plain stream its thousands of workgroups take every CU and whatever the compute stream launches
-  // next queues behind them (a prefill LayerNorm: 88 -> 600 us, 44 times per prefill).  LIA_DECODE_CUS=n (default
-  // LIA_DECODE_CUS_DEFAULT) confines the decode stream to n compute units with a CU mask; 0 = the whole chip (r02).
+  // next queues behind them (a prefill LayerNorm: 88 -> 600 us, 44 times per prefill): the decode stream is confined to
+  // LIA_DECODE_CUS_DEFAULT compute units with a CU mask (r02: the whole chip).
   int decode_cus = LIA_DECODE_CUS_DEFAULT;
-  if (const char* e = getenv("LIA_DECODE_CUS")) decode_cus = atoi(e);
   if (s->ctx->serialized) {
     s->decode = s->ctx->compute;
   } else if (decode_cus > 0) {

@@ -628,9 +628,6 @@ __global__ __launch_bounds__(256) void lia_attn_decode_kernel(const bf16_t* __re
   }
 }
 
-// 1: first-generation kernel, 2: lia_attn_prefill128_kernel (d = 128).  LIA_ATTN_PREFILL_VARIANT overrides.
-static int g_prefill_variant = [] { const char* e = getenv("LIA_ATTN_PREFILL_VARIANT"); return e ? atoi(e) : 2; }();
-extern "C" void lia_attn_set_prefill_variant(int v) { g_prefill_variant = v; }
 
 extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* kc, const bf16_t* vc, bf16_t* out, long ldo,
                                        int B, int T, int heads, int kv_heads, int d, int Bc, int b0, int post_scale,
@@ -640,14 +637,12 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
   dim3 grid((T + 127) / 128, heads, B);
   const float scaling = 1.0f / sqrtf((float)d);
   switch (d) {
-    case 128:
-      if (g_prefill_variant == 2) {
-        const long hd = (long)kv_heads * 128;
-        // (a token-major [B][T][h][d] K/V -- strides (hd, T hd) -- was measured: same time, so the cache layout stays)
-        hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, post_scale);
-      }
-      else hipLaunchKernelGGL(lia_attn_prefill_kernel<128>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale);
+    case 128: {
+      const long hd = (long)kv_heads * 128;
+      // (a token-major [B][T][h][d] K/V -- strides (hd, T hd) -- was measured: same time, so the cache layout stays)
+      hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, post_scale);
       break;
+    }
     case 64: hipLaunchKernelGGL(lia_attn_prefill_kernel<64>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
     case 32: hipLaunchKernelGGL(lia_attn_prefill_kernel<32>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
     default: return -1;

@@ -549,7 +549,7 @@ template <int N> __device__ __forceinline__ void ch_wait_imm() {
 }
 
 template <int MT, int RT, int MH, int DW, int DX>
-__global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P, unsigned* sync, unsigned* err_host, int pos0, int spin_limit, unsigned long long* stamps, int dbg,
+__global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P, unsigned* sync, unsigned* err_host, int pos0, int spin_limit, unsigned long long* stamps,
                                                        unsigned long long* gran, unsigned epoch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = 8 / MH;                      // waves along the weight rows
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P,
     return d < 0 ? 0 : (d > WJ ? WJ : d);
   };
   auto issue_w = [&]() {
-    if (loads_w && !(dbg & 2)) load_w(w_rounds());
+    if (loads_w) load_w(w_rounds());
     else if (loads_w) ch_fifo_push(fifo, issued);
     wslot_i = wslot_i + 1 == DW ? 0 : wslot_i + 1;
     ++nw;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P,
         ch_fifo_push(fifo, issued);
       };
       auto issue_x = [&]() {
-        if (!loads_w && !(dbg & 4)) load_x();
+        if (!loads_w) load_x();
         else if (!loads_w) ch_fifo_push(fifo, issued);
         xslot_i = xslot_i + 1 == DX ? 0 : xslot_i + 1;
         ++nx;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P,
         auto compute = [&]() {
           const char* wt = wring + wslot_c * WSTAGE;
           const char* xt = xring + xslot_c * XSTAGE;
-          if (nt > 0 && !(dbg & 1)) {
+          if (nt > 0) {
             bf16x8 af[2][RT], bq[2][MTW];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -765,8 +765,8 @@ __global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P,
         while (c < c1) {
           const int L = min(min(w_cend - w_c, x_cend - x_c) - 1, c1 - c);   // requests that stay inside the cursors' items, rounds that stay inside this one
           const int d = loads_w ? w_rounds() : XJ;
-          const bool steady = L > 0 && !(dbg & 8) && w_valid && x_valid && nw == DW - 1 && nx == DX - 1 &&
-                              (ch_fifo_behind(fifo, issued) == (loads_w ? DW - 2 : DX - 2) * d || (dbg & (loads_w ? 2 : 4)));
+          const bool steady = L > 0 && w_valid && x_valid && nw == DW - 1 && nx == DX - 1 &&
+                              ch_fifo_behind(fifo, issued) == (loads_w ? DW - 2 : DX - 2) * d;
           if (steady && (!loads_w || d >= WJ - 1)) {
 #define CH_LEAN_ROUNDS(WAIT_N, LOADS)                                                                              \
             for (int i = 0; i < L; ++i) {                                                                          \
@@ -779,9 +779,9 @@ __global__ __launch_bounds__(512) void lia_chain_kernel(const LiaChainProgram P,
               ++x_c;                                                                                               \
               compute();                                                                                           \
             }
-            if (!loads_w) { CH_LEAN_ROUNDS((DX - 2) * XJ, if (dbg & 4) ch_fifo_push(fifo, issued); else load_x()) }
-            else if (d == WJ) { CH_LEAN_ROUNDS((DW - 2) * WJ, if (dbg & 2) ch_fifo_push(fifo, issued); else load_w(WJ)) }
-            else { CH_LEAN_ROUNDS((DW - 2) * (WJ - 1), if (dbg & 2) ch_fifo_push(fifo, issued); else load_w(WJ - 1)) }
+            if (!loads_w) { CH_LEAN_ROUNDS((DX - 2) * XJ, load_x()) }
+            else if (d == WJ) { CH_LEAN_ROUNDS((DW - 2) * WJ, load_w(WJ)) }
+            else { CH_LEAN_ROUNDS((DW - 2) * (WJ - 1), load_w(WJ - 1)) }
 #undef CH_LEAN_ROUNDS
             c += L;
             continue;
@@ -969,7 +969,6 @@ extern "C" int lia_chain_plan_gemm(int M, int N, int K, int glu, int n_cu, LiaCh
 }
 
 // diagnostic: a device buffer of `slots` x (n_cu x LIA_CHAIN_MAX_OPS x 4) words; launch i stamps into slot i % slots.  nullptr = off.
-static int g_chain_dbg = [] { const char* e = getenv("LIA_CHAIN_DBG"); return e ? atoi(e) : 0; }();   // timing-only ablations (wrong results): 1 no MFMA / fragment reads, 2 no W loads, 4 no x loads
 static unsigned long long* g_chain_stamps = nullptr;
 static int g_chain_stamp_slots = 0;
 static long g_chain_stamp_launch = 0;
@@ -984,7 +983,7 @@ static int ch_launch(const LiaChainProgram& prog, unsigned* sync, unsigned* err_
     attr = true;
   }
   hipLaunchKernelGGL((lia_chain_kernel<MT, RT, MH, DW, DX>), dim3(n_cu), dim3(512), lds, st, prog, sync, err_host, pos0, spin_limit,
-                     g_chain_stamps ? g_chain_stamps + (size_t)(g_chain_stamp_launch++ % g_chain_stamp_slots) * n_cu * LIA_CHAIN_MAX_OPS * 4 : nullptr, g_chain_dbg, gran, epoch);
+                     g_chain_stamps ? g_chain_stamps + (size_t)(g_chain_stamp_launch++ % g_chain_stamp_slots) * n_cu * LIA_CHAIN_MAX_OPS * 4 : nullptr, gran, epoch);
   return 0;
 }
 
@@ -993,7 +992,7 @@ extern "C" int lia_chain_launch(const LiaChainProgram* prog, int M, unsigned* sy
   ChGeom g;
   if (!prog || prog->n_ops <= 0 || prog->n_ops > LIA_CHAIN_MAX_OPS || !sync_block || n_cu <= 0 || !ch_geom(M, &g)) return -1;
   // a poll is ~1-2 us (an L2 round trip + s_sleep): 400k polls bound a lost barrier to well under a second
-  static const int spin_limit = [] { const char* e = getenv("LIA_CHAIN_SPIN_LIMIT"); return e ? atoi(e) : 400000; }();
+  const int spin_limit = 400000;
   const size_t lds = ch_lds_bytes(g);
   if (g.mt == 8) return ch_launch<8, 2, 2, 7, 3>(*prog, sync_block, err_host, pos0, n_cu, lds, spin_limit, gran, epoch, st);
   if (g.mt == 4) return ch_launch<4, 2, 1, 4, 3>(*prog, sync_block, err_host, pos0, n_cu, lds, spin_limit, gran, epoch, st);

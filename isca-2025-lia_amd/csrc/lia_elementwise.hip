@@ -133,8 +133,8 @@ __global__ __launch_bounds__(LIA_ROW_THREADS) void lia_layernorm_row_kernel(cons
   row_layernorm_block<NV>(v, gv, bv, nv, H, eps, y + row * ldy, red);
 }
 
-// up to this many rows the workgroup-per-row kernel is used (LIA_ROW_NORM_MAX_ROWS overrides: tools/norm_bench.py)
-static long g_row_norm_max_rows = [] { const char* e = getenv("LIA_ROW_NORM_MAX_ROWS"); return e ? atol(e) : 1024L; }();
+// up to this many rows the workgroup-per-row kernel is used (the cut-over measured with tools/norm_bench.py, r03)
+static const long g_row_norm_max_rows = 1024L;
 
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st) {

@@ -1134,8 +1134,9 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
 // ---------------------------------------------------------------------------------------------
 // 262 (default): phased kernel, two phases per K-tile, buffer-load LDS-DMA; 259 / 260 / 261: its four-phase and global_load_lds
 // forms; 256: the one-barrier-per-K-tile kernel of r01 (also the fallback for K / 64 odd or < 4); 257 / 258: r01's staggered
-// k-half kernel.  All produce bit-identical outputs.  LIA_GEMM_TILED_VARIANT overrides (A/B runs, tests).
-static int g_tiled_variant = [] { const char* e = getenv("LIA_GEMM_TILED_VARIANT"); return e ? atoi(e) : 262; }();
+// k-half kernel.  All produce bit-identical outputs (tests/test_gpu_fused_combine.py); lia_gemm_set_tiled_variant selects one
+// for A/B runs (tools/gemm_bench.hip).
+static int g_tiled_variant = 262;
 extern "C" void lia_gemm_set_tiled_variant(int v) { g_tiled_variant = v; }
 
 extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
@@ -1160,8 +1161,8 @@ static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw,
                      split > 1 ? partial : nullptr, tickets, ep, om);
 }
 
-// A/B switch (tests, tools): LIA_FUSE_COMBINE=0 or lia_gemm_set_fuse_combine(0) keeps every post op a kernel of its own
-static int g_fuse_combine = [] { const char* e = getenv("LIA_FUSE_COMBINE"); return (e && !strcmp(e, "0")) ? 0 : 1; }();
+// A/B switch (tests, tools): lia_gemm_set_fuse_combine(0) keeps every post op a kernel of its own
+static int g_fuse_combine = 1;
 extern "C" void lia_gemm_set_fuse_combine(int on) { g_fuse_combine = on; }
 static long g_fused_combines[5];     // launches per LIA_POST_* kind since the library was loaded (tests assert the route was taken)
 extern "C" long lia_gemm_fused_combine_count(int kind) { return (kind >= 0 && kind < 5) ? g_fused_combines[kind] : -1; }
@@ -1202,23 +1203,25 @@ static bool launch_fused_combine(const float* ws, int split, int M, int N, const
 
 // experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row,
 // 3 = force the two-block x cut at 64 < M <= 128, 4 = forbid it
+static int g_inlaunch_combine = 0;
+extern "C" void lia_gemm_set_inlaunch_combine(int on) { g_inlaunch_combine = on ? 1 : 0; }
 static int g_skinny_variant = 0;
 extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
 
 // Test / A-B knob: 1 = cut K into the slices the persistent decode chain uses for the same shape (lia_chain_plan_gemm).  The two
 // routes then add the same products in the same order and must agree bit for bit (tests/test_gpu_chain.py); 0 (default) = the
 // per-launch heuristics below.
-static int g_split_policy = [] { const char* e = getenv("LIA_GEMM_SPLIT_POLICY"); return e ? atoi(e) : 0; }();
+static int g_split_policy = 0;
 extern "C" void lia_gemm_set_split_policy(int v) { g_split_policy = v; }
 
-// Which kernel runs a decode GEMM with M <= 128: 0 (default) = lia_gemm_skinny2_kernel; 1 (LIA_GEMM_ENGINE=chain) = the persistent
+// Which kernel runs a decode GEMM with M <= 128: 0 (default) = lia_gemm_skinny2_kernel; 1 (lia_gemm_set_engine(1)) = the persistent
 // chain kernel as a one-step program (lia_chain.hip), its split-K slabs combined by the same kernels as before.  Measured (r04,
 // LABNOTES.md): the chain's steady-state loop is the faster one (7.0 TB/s on OPT-30B's fc1 at M = 64 against 6.0, 52 against 60 us
 // on Llama-3-8B's gate|up at M = 128), but as a launch of its own it pays a cold 160 KB ring and ~1 us rounds at every item
 // boundary: q|k|v / o 19-23 us against 16.7, lm_head 306 against 246 -- whole steps 3-6 % slower.  Kept for A/B runs and as a
 // second implementation to compare bits with: same products in the same order per K slice, so with
 // lia_gemm_set_split_policy(1) the two engines agree bit for bit.
-static int g_gemm_engine = [] { const char* e = getenv("LIA_GEMM_ENGINE"); return (e && !strcmp(e, "chain")) ? 1 : 0; }();
+static int g_gemm_engine = 0;
 extern "C" void lia_gemm_set_engine(int v) { g_gemm_engine = v ? 1 : 0; }
 static long g_chain_gemms = 0;
 extern "C" long lia_gemm_chain_engine_count(void) { return g_chain_gemms; }
@@ -1373,14 +1376,13 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     int cps = (nchunks + split - 1) / split;
     split = (nchunks + cps - 1) / cps;
     if (regime) *regime = 1;
-    // How the split-K slabs are combined.  Default: the small second kernel.  LIA_GEMM_SPLITK=inlaunch: by the last-arriving
-    // slice inside the launch (bit-identical, tools/splitk_ab.py) -- measured on MI355X it is SLOWER at these sizes: a tile's
+    // How the split-K slabs are combined.  Default: the small second kernel.  lia_gemm_set_inlaunch_combine(1): by the last-arriving
+    // slice inside the launch (bit-identical, tests/test_gpu_fused_combine.py) -- measured on MI355X it is SLOWER at these sizes: a tile's
     // slabs are 3-8 x 64 KB, the last arriver reads them alone while its CU's neighbours still stream, and every slice pays an
     // agent-scope release (L2 write-back): OPT-30B M = 64 qkv 58 -> 78 us, fc2 77 -> 104 us, Llama-3-8B M = 128 qkv 23 -> 38 us
     // (the two-kernel figures include the 5 us combine kernel).  cdna_hip_programming.md says as much: in-launch pays only
     // when split x slab bytes per tile is a few tens of KB.
-    static const bool in_launch = [] { const char* e = getenv("LIA_GEMM_SPLITK"); return e && !strcmp(e, "inlaunch"); }();
-    unsigned* tk = (split > 1 && tickets && in_launch && (long)((N + 127) / 128) * 16 <= LIA_GEMM_MAX_TICKETS) ? tickets : nullptr;
+    unsigned* tk = (split > 1 && tickets && g_inlaunch_combine && (long)((N + 127) / 128) * 16 <= LIA_GEMM_MAX_TICKETS) ? tickets : nullptr;
     if (ev0) (void)hipEventRecord(ev0, st);
     if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
     else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);

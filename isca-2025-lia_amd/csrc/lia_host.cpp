@@ -116,14 +116,10 @@ static void host_attention_team(const lia_bf16* q, const lia_bf16* k, const lia_
   while (heads % G) G >>= 1;
   const int ngroups = heads / G;
   const int run_bytes = G * d * (int)sizeof(lia_bf16);
-  static const int PF = [] { const char* e = getenv("LIA_HOST_ATTN_PF"); return e ? atoi(e) : 8; }();   // rows of look-ahead (0 / 2 / 4 / 6 / 8 / 12 measured: 6.0 / 5.6 / 3.1 / 2.5 / 2.2 / 4.4 ms at 16 threads)
-  static const int HINT = [] { const char* e = getenv("LIA_HOST_ATTN_HINT"); return e ? atoi(e) : 2; }();   // prefetch into L1 (0), L2 (1), non-temporal (2): 2.22-2.26 / 1.90-2.25 / 1.99-2.11 ms at 16 threads (tools/dbg_hostattn.py, three interleaved rounds)
-#define LIA_ATTN_PREFETCH(p)                                         \
-  do {                                                                \
-    if (HINT == 1) _mm_prefetch((p), _MM_HINT_T1);                    \
-    else if (HINT == 2) _mm_prefetch((p), _MM_HINT_NTA);              \
-    else _mm_prefetch((p), _MM_HINT_T0);                              \
-  } while (0)
+  // rows of look-ahead (0 / 2 / 4 / 6 / 8 / 12 measured: 6.0 / 5.6 / 3.1 / 2.5 / 2.2 / 4.4 ms at 16 threads), requested non-temporally
+  // (into L1 / L2 / non-temporal: 2.22-2.26 / 1.90-2.25 / 1.99-2.11 ms -- LABNOTES r03; the A/B switches are gone)
+  constexpr int PF = 8;
+#define LIA_ATTN_PREFETCH(p) _mm_prefetch((p), _MM_HINT_NTA)
   {
     float* sc = thread_scratch((size_t)G * S);
 #pragma omp for collapse(2) schedule(dynamic, 1) nowait
@@ -448,11 +444,12 @@ static void host_linear_skinny_team_t(const lia_bf16* x, const lia_bf16* w, cons
       if (best < 0 || span < best) { best = span; NT = per * RN; }
     }
   }
-  // A/B knobs of tools/host_linear_bench.py, read once: K-chunk length, and how the NEXT weight rows' chunk is prefetched while
-  // this one is multiplied (0 off, 1 into L2, 2 into L1).  The rows of a tile are K * 2 bytes apart, so every block of rows
-  // starts on cold lines the hardware prefetcher has not seen; its 16-24 KB are spread over the block's m-loop.
-  static const int KC = [] { const char* e = getenv("LIA_HOST_LINEAR_KC"); int v = e ? atoi(e) : 2048; return v >= 32 ? (v / 32) * 32 : 2048; }();
-  static const int PF = [] { const char* e = getenv("LIA_HOST_LINEAR_PF"); return e ? atoi(e) : 1; }();
+  // K-chunk length, and the NEXT weight rows' chunk prefetched into L2 while this one is multiplied (measured against no
+  // prefetch / into L1 and chunks of 1024 / 4096 with tools/host_linear_bench.py, LABNOTES r03).  The rows of a tile are K * 2
+  // bytes apart, so every block of rows starts on cold lines the hardware prefetcher has not seen; its 16-24 KB are spread over
+  // the block's m-loop.
+  constexpr int KC = 2048;
+  constexpr int PF = 1;
   const int ntiles = (N + NT - 1) / NT;
   const int mblocks = (M + RB - 1) / RB;
   const size_t crow = (size_t)NT + 8;                                      // C rows padded: an edge block's xmm stores stay inside
@@ -483,8 +480,7 @@ static void host_linear_skinny_team_t(const lia_bf16* x, const lia_bf16* w, cons
               const int l0 = (m0 / RB) * lp, l1 = l0 + lp < lines ? l0 + lp : lines;
               for (int j = 0; j < wn_rows; ++j)
                 for (int l = l0; l < l1; ++l) {
-                  if (PF == 2) _mm_prefetch((const char*)(wn + (long)j * K) + 64 * l, _MM_HINT_T0);
-                  else _mm_prefetch((const char*)(wn + (long)j * K) + 64 * l, _MM_HINT_T1);
+                  _mm_prefetch((const char*)(wn + (long)j * K) + 64 * l, _MM_HINT_T1);
                 }
             }
             __m512 acc[RB][RN];
@@ -547,9 +543,7 @@ static void host_linear_skinny_team_t(const lia_bf16* x, const lia_bf16* w, cons
 // fp32 tile C[M][64] (L1).  With the whole K in one pass x overflows L2 and every 4 weight rows re-read it from L3.
 static void host_linear_skinny_team(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                                     int M, int N, int K, int relu) {
-  static const int RN = [] { const char* e = getenv("LIA_HOST_LINEAR_RN"); return e ? atoi(e) : 6; }();   // 14.8 -> 14.2 ms per OPT-30B decode layer
-  if (RN == 6) host_linear_skinny_team_t<6>(x, w, bias, residual, y, M, N, K, relu);
-  else host_linear_skinny_team_t<4>(x, w, bias, residual, y, M, N, K, relu);
+  host_linear_skinny_team_t<6>(x, w, bias, residual, y, M, N, K, relu);      // 4 x 6 register blocks: 14.8 -> 14.2 ms per OPT-30B decode layer against 4 x 4
 }
 static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                                int M, int N, int K, int relu) {
@@ -560,8 +554,7 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
 // y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.
 static void host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                         long M, int N, int K, int relu) {
-  static const bool use_v1 = getenv("LIA_HOST_LINEAR_V1") != nullptr;   // A/B knob of tools/host_linear_bench.py, read once
-  if (M <= 256 && !use_v1) { host_linear_skinny(x, w, bias, residual, y, (int)M, N, K, relu); return; }
+  if (M <= 256) { host_linear_skinny(x, w, bias, residual, y, (int)M, N, K, relu); return; }
   constexpr int RB = 4;
   const long mblocks = (M + RB - 1) / RB;
   const int nblocks = (N + RB - 1) / RB;
@@ -700,8 +693,7 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   if (!scratch.p) { lia_set_error("lia_host_layer_forward: out of host memory (%zu bytes of scratch)", need * sizeof(lia_bf16)); return LIA_ERR_MEMORY; }
   // (a prefill-sized call -- policy 1 over B * T rows -- gives its block back on return: see the end of the function)
   lia_bf16 *ln = scratch.p, *q = ln + mh, *k = q + mh, *v = k + mh, *ao = v + mh, *h1 = ao + mh, *f1 = h1 + mh;
-  static const bool one_region = [] { const char* e = getenv("LIA_HOST_LAYER_REGIONS"); return !(e && atoi(e) != 1); }();   // A/B: 9 = a region per op (r02)
-  if (M <= 256 && one_region) {
+  if (M <= 256) {
     // decode: the whole layer in ONE parallel region, the ops separated by a spinning barrier (see LiaTeamBarrier)
     LiaTeamBarrier bar;
     lia_bf16* const sc = scratch.p;          // (thread_local: the workers must see the CALLER's block, not their own)

@@ -92,6 +92,10 @@ SIGNATURES = {
     "lia_gemm_set_split_policy": (None, [c_int]),
     "lia_chain_launch_count": (c_long, []),
     "lia_gemm_set_engine": (None, [c_int]),
+    "lia_gemm_set_fuse_combine": (None, [c_int]),
+    "lia_gemm_set_inlaunch_combine": (None, [c_int]),
+    "lia_gemm_set_tiled_variant": (None, [c_int]),
+    "lia_gemm_fused_combine_count": (ctypes.c_long, [c_int]),
     "lia_gemm_chain_engine_count": (c_long, []),
     "lia_host_layer_forward": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_void_p * 16), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

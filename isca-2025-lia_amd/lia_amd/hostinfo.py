@@ -46,31 +46,15 @@ def default_host_threads(world=1):
     return max(1, n // max(1, world))
 
 
-class HostTeamGovernor:
+class HostTeam:
     """Threads of the team that computes WHOLE LAYERS back to back (the cooperative split's host layers, policy 1): the attention
-    team's count, or LIA_HOST_LAYER_THREADS.  Sixteen threads busy for hundreds of milliseconds plus the main thread's helpers
-    (HIP's event thread, the spinning stream synchronize) overshoot a sixteen-CPU CFS quota now and then, and the kernel stalls
-    the container for the rest of the period (bench.py reports it per leg: `cpu_throttle`).  With LIA_HOST_TEAM_GOVERNOR=1 the
-    count follows cpu.stat -- two consecutive steps with more than 2 % of their time throttled cost one thread, at most two in
-    all.  OFF by default: three boxes, OPT-30B cooperative legs interleaved -- 15 threads ahead by 6 % on one (174 / 181 vs
-    160 / 173 tokens/s, 320-780 ms throttled per 16-thread leg), 16 threads ahead by 3-5 % on the other two, one of them with
-    750-1100 ms throttled per leg; run-to-run spread is as large as the effect (LABNOTES.md)."""
+    team's count, fixed.  (r03 tried a governor that gave threads back while cpu.stat showed CFS throttling -- sixteen busy threads
+    plus the main thread's helpers overshoot a sixteen-CPU quota now and then: three boxes, 15 threads ahead by 6 % on one, 16
+    ahead by 3-5 % on the other two, run-to-run spread as large as the effect, LABNOTES.md.  The switch is gone; bench.py still
+    reports the throttled time per leg as `cpu_throttle`.)"""
 
     def __init__(self, team):
-        env = os.environ.get("LIA_HOST_LAYER_THREADS")
-        self.pinned = bool(env) or os.environ.get("LIA_HOST_TEAM_GOVERNOR", "0") != "1"
-        self.threads = max(1, int(env)) if env else max(1, int(team))
-        self.floor = max(1, self.threads - 2) if self.threads >= 4 else self.threads
-        self.last, self.strikes, self.drops = cgroup_cpu_throttle(), 0, 0
-
-    def after_step(self, step_ms):
-        """one decode step with host-computed layers has ended -> the count for the next one"""
-        now = cgroup_cpu_throttle()
-        throttled_ms, self.last = (now[1] - self.last[1]) / 1e3, now
-        self.strikes = self.strikes + 1 if throttled_ms > 0.02 * step_ms else 0
-        if self.strikes >= 2 and not self.pinned and self.threads > self.floor:
-            self.threads, self.strikes, self.drops = self.threads - 1, 0, self.drops + 1
-        return self.threads
+        self.threads = max(1, int(team))
 
 
 def cap_torch_threads(n=None):
@@ -128,6 +112,14 @@ def gpu_numa_node(dev_index=0):
         return int(open(path).read().strip())
     except Exception:
         return -1
+
+
+def pin_node(dev_index=0):
+    """The NUMA node the host threads are confined to: $LIA_PIN_NODE when set (-1 = no pinning), else the GPU's own node."""
+    env = os.environ.get("LIA_PIN_NODE")
+    if env is not None and env.strip() != "":
+        return int(env)
+    return gpu_numa_node(dev_index)
 
 
 def pin_to_node(node):

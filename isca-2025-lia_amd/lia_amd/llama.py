@@ -184,13 +184,13 @@ class LlamaScheduler:
     """forward(ids, kv, gpu_percentage=..., num_minibatch=...) -> (logits, next ids) on the device."""
 
     def __init__(self, model, device=0, n_slots=4, pack=None):
-        import os
+        from .scheduler import default_stream_format
         self.model, self.device, self.n_slots = model, device, n_slots
-        fmt = os.environ.get("LIA_STREAM_FORMAT", "raw").lower() if pack is None else pack
+        fmt = default_stream_format() if pack is None else pack
         self.pack = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, 0: 0, 10: 10, 11: 11, 12: 12, False: 0, True: 12}[fmt]
         self.ctx = self.pipe = None
         self.hidden, self.resident, self.tables = {}, {}, None
-        self.prefill_tail = os.environ.get("LIA_PREFILL_TAIL", "1") != "0"      # last layer of a prefill: last position only behind q|k|v
+        self.prefill_tail = True      # last layer of a prefill: last position only behind q|k|v (False: every position)
 
     def _ensure(self, rows, B, T, n_gpu, smax):
         sh, lib = self.model.shape, N.lib()

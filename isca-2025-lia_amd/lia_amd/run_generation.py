@@ -53,6 +53,9 @@ def build_parser():
     p.add_argument("--auto-plan", action="store_true",
                    help="measure this box (lia_amd.planner.calibrate, a few seconds) and let the planner choose --gpu-percentage, "
                         "the policies and --cpu-layers instead of the hand-picked values of llm/scripts/lia_*.sh")
+    p.add_argument("--plan-max-gpu-percentage", default=100, type=int,
+                   help="--auto-plan what-if: the plan keeps at most this share of the layers resident (the others must stream)")
+    p.add_argument("--plan-hbm-gb", default=0.0, type=float, help="--auto-plan what-if: plan as if the GPU had this much HBM")
     p.add_argument("--cpu-layers", default=0, type=int,
                    help="with --decoding-policy 2: this many streamed layers take their decode step on the host cores (policy 1 per layer); "
                         "-1 = chosen online from the measured decode steps (scheduler.CoopController), seeded by the planner")
@@ -118,9 +121,9 @@ def auto_plan(args, out=print):
     """--auto-plan: calibrate the box, plan, overwrite the LIA flags with the plan (f-3)."""
     from . import planner
     box = planner.calibrate(verbose=False)
-    if os.environ.get("LIA_PLAN_HBM_GB"):          # what-if: pretend the GPU is smaller
-        box.hbm_gb = float(os.environ["LIA_PLAN_HBM_GB"])
-    max_pct = int(os.environ.get("LIA_PLAN_MAX_GPU_PCT", "100"))     # what-if / tests: cap the resident share
+    if args.plan_hbm_gb:                           # what-if: pretend the GPU is smaller
+        box.hbm_gb = float(args.plan_hbm_gb)
+    max_pct = int(args.plan_max_gpu_percentage)    # what-if / tests: cap the resident share
     fmt = args.stream_format or default_stream_format()
     box.wire_ratio = {"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[fmt]
     shape = model_shape(args)
@@ -252,7 +255,7 @@ def main(argv=None):
     from . import hostinfo
     import torch
     if torch.cuda.is_available():
-        node = int(os.environ["LIA_PIN_NODE"]) if os.environ.get("LIA_PIN_NODE") is not None else hostinfo.gpu_numa_node(0)
+        node = hostinfo.pin_node(0)
         if node >= 0 and hostinfo.pin_to_node(node):
             print(f"host threads pinned to NUMA node {node}")
     if args.auto_plan:

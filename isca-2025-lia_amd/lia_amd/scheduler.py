@@ -254,6 +254,7 @@ class PinnedPool:
         return torch.frombuffer(buf, dtype=torch.int16).view(torch.bfloat16).view(*shape)
 
 
+COOP_HEADROOM = 10                    # raw host copies kept beyond the planner's count: the room the online controller may search upward
 DEFAULT_STREAM_FORMAT = "pack10"      # one default for OffloadScheduler, run_generation.py and bench.py
 
 
@@ -545,7 +546,7 @@ class OffloadScheduler:
     def __init__(self, model, device=0, n_slots=None, dp_group=None, pack12=None):
         import os
         self.model, self.device, self.dp = model, device, dp_group
-        self.n_slots = n_slots or int(os.environ.get("LIA_STREAM_SLOTS", "4"))
+        self.n_slots = n_slots or 4
         # wire format of the streamed layers: "pack12" (lossless 12-bit encoding, lia_pack12.hip) or "raw" bf16
         fmt = default_stream_format() if pack12 is None else pack12
         self.pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, False: 0, True: 12, 0: 0, 10: 10, 11: 11, 12: 12}[fmt]
@@ -560,8 +561,8 @@ class OffloadScheduler:
         # them to the host caches then (lia_kv_deliver), instead of beside the prefill's weight stream.  LIA_DEFER_KV=0: deliver at once.
         self.defer_kv = os.environ.get("LIA_DEFER_KV", "1") != "0"
         # the last layer of a prefill computes everything behind its q|k|v projection on the last position only (lia_layer_forward_last);
-        # LIA_PREFILL_TAIL=0: every position, as the reference does
-        self.prefill_tail = os.environ.get("LIA_PREFILL_TAIL", "1") != "0"
+        # prefill_tail = False: every position, as the reference does (same ids, tests/test_gpu_round3.py)
+        self.prefill_tail = True
         self._kv_hold = None        # ((B, T, first streamed layer), [(k, v, KV struct) per streamed layer])
         # every delivery ticket not yet waited for, whichever KVState it belongs to: ticket -> (weakref(KVState), layer).  The
         # holding caches are shared by all generations of this scheduler, so a new prefill may only write them once ALL of these
@@ -662,6 +663,9 @@ class OffloadScheduler:
         return self.resident_ptrs[idx]
 
     # -- one forward -----------------------------------------------------------------------------------
+    # forward = _validate (shapes and flags -> a step record) -> _place (host set, cache sides, layer tiers) -> embed ->
+    # _run_layers (resident run, streamed / host-computed layers) -> lm_head -> _deliver (K/V to the host caches, synchronize,
+    # the cooperative controller's sample).  Each phase reads and extends the step record `s`; none reaches back.
     def forward(self, input_ids, kv_state, prefill_policy=1, decoding_policy=1, no_overlap=False, pin_weight=False,
                 gpu_percentage=0, num_minibatch=1, enable_cxl=False, max_new_tokens=None, suppress_token=-1, cpu_layers=0,
                 cpu_layers_start=None):
@@ -670,7 +674,29 @@ class OffloadScheduler:
         the cooperative split of the reference taken per layer.  Prefill is unaffected (policy 0 for every layer).
         cpu_layers=-1: the count is chosen ONLINE (CoopController) from the measured decode steps, starting at cpu_layers_start
         (default: planner.plan_cpu_layers for this shape and box defaults)."""
-        m, sh = self.model, self.model.shape
+        s = self._validate(input_ids, kv_state, prefill_policy, decoding_policy, no_overlap, gpu_percentage, num_minibatch)
+        self._place(s, kv_state, pin_weight, enable_cxl, max_new_tokens, cpu_layers, cpu_layers_start)
+        m, sh, ctx = self.model, self.model.shape, self.ctx
+        ids_dev = input_ids.to("cuda", non_blocking=False).contiguous()
+        N.check(ctx.lib.lia_embed(ctypes.c_void_p(ids_dev.data_ptr()), ctypes.c_void_p(m.embed_tokens.data_ptr()),
+                                  ctypes.c_void_p(m.embed_positions.data_ptr()), ctypes.c_void_p(s.x.data_ptr()), s.B, s.T, s.pos0,
+                                  sh.hidden, ctypes.c_void_p(ctx.stream)), "lia_embed")
+        if s.policy == 1 and s.n_gpu < s.L:
+            self._await_kv(kv_state)
+            hidden = self._host_layers(s.x, kv_state, s.n_gpu, s.B, s.T, s.pos0)  # resident prefix on the GPU, the rest on the CPU
+            logits, nxt = ctx.lm_head(hidden, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
+            ctx.synchronize()
+            kv_state.len = s.pos0 + s.T
+            return logits, nxt
+        hidden = self._run_layers(s, kv_state)
+        logits, nxt = ctx.lm_head(hidden, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
+        self._deliver(s, kv_state)
+        return logits, nxt
+
+    def _validate(self, input_ids, kv_state, prefill_policy, decoding_policy, no_overlap, gpu_percentage, num_minibatch):
+        """shapes and flags of one forward -> the step record; raises on the combinations the path does not have"""
+        from types import SimpleNamespace
+        sh = self.model.shape
         B, T = input_ids.shape
         L = sh.layers
         n_gpu = int(L * gpu_percentage / 100)                      # lia/modeling_opt.py:1182
@@ -686,13 +712,20 @@ class OffloadScheduler:
         if B % num_minibatch:
             raise ValueError(f"batch {B} not divisible by num_minibatch {num_minibatch}")
         mini = B // num_minibatch if (policy in (0, 3) and is_prefill) or policy == 0 else B   # :1178 mini_bsz
-        overlap = not no_overlap
+        return SimpleNamespace(B=B, T=T, L=L, n_gpu=n_gpu, is_prefill=is_prefill, policy=policy, prefill_policy=prefill_policy,
+                               decoding_policy=decoding_policy, gpu_percentage=gpu_percentage, mini=mini, overlap=not no_overlap,
+                               pos0=kv_state.len, coop=None, cpu_set=frozenset(), host_act=frozenset(), host_now=frozenset(),
+                               t_fwd0=None, busy0=0.0, hold=None, x=None, y=None)
 
-        # move_gpu_layer / pin_memory, idempotent.  The policy-1 host path reads the host copy directly, so the pack12
-        # wire format is only used when neither phase runs on the CPU.
+    def _place(self, s, kv_state, pin_weight, enable_cxl, max_new_tokens, cpu_layers, cpu_layers_start):
+        """the host-computed layer set (fixed or the online controller's), the side every cache lives on, the layers' tiers
+        (move_gpu_layer / pin_memory, idempotent), the hidden-state buffers and the holding caches of a deferred K/V delivery"""
+        m = self.model
+        n_gpu, L, B, T, is_prefill, decoding_policy = s.n_gpu, s.L, s.B, s.T, s.is_prefill, s.decoding_policy
+        # The policy-1 host path reads the host copy directly, so the packed wire format is only used when neither phase runs on the CPU.
         coop = None
         if cpu_layers and cpu_layers < 0 and decoding_policy in (2, 3) and self.dp is None and n_gpu < L - 1:
-            coop = self._coop_controller(n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, cpu_layers_start)
+            coop = self._coop_controller(n_gpu, L, B, T, max_new_tokens, s.gpu_percentage, decoding_policy, cpu_layers_start)
             self._fit_host_candidates(coop, enable_cxl and pin_weight)
             cpu_set = coop.superset()                                # layers that keep a raw host copy (and a host KV cache)
         else:
@@ -709,7 +742,7 @@ class OffloadScheduler:
                 for i in getattr(kv_state, "dual", {}):                  # an empty cache changes sides for free
                     kv_state.move_cache(N.lib(), i, to_device=(i not in need_host))
         shard = (self.dp.rank, self.dp.world) if (self.dp is not None and self.dp.world > 1 and self.dp.mode == "allgather") else None
-        wire = self.pack12 if (prefill_policy != 1 and decoding_policy != 1) else 0
+        wire = self.pack12 if (s.prefill_policy != 1 and decoding_policy != 1) else 0
         if m.placed_for != m._place_key(n_gpu, pin_weight, enable_cxl, wire, cpu_set, shard):
             # the flags changed since the last placement: the model re-tiers its layers (policy 1 wants raw host copies,
             # another gpu%, wire format or host tier).  Copies in flight read host buffers that are about to be freed and
@@ -721,40 +754,28 @@ class OffloadScheduler:
         m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=cpu_set, shard=shard)
         if coop is not None and is_prefill:
             coop.new_sequence()                                      # the first decode step is not a sample of the steady state
-        host_act = coop.host_set() if coop is not None else cpu_set   # the layers whose DECODE step runs on the host cores
-        host_now = host_act if not is_prefill else frozenset()    # layers this forward computes on the host
-        t_fwd0 = None
+        s.coop, s.cpu_set = coop, cpu_set
+        s.host_act = coop.host_set() if coop is not None else cpu_set   # the layers whose DECODE step runs on the host cores
+        s.host_now = s.host_act if not is_prefill else frozenset()    # layers this forward computes on the host
         if coop is not None and not is_prefill:
             import time
-            t_fwd0, busy0 = time.time(), (self.pipe.poll_stats()[1] if self.pipe else 0.0)
-        rows = B * T if n_gpu > 0 else mini * T                    # resident layers take the whole batch
-        if policy == 0 and n_gpu < L:
-            rows = max(rows, mini * kv_state.smax)                 # policy-0 decode parks the cached prefix in a slab
-        x, y = self._ensure(rows, B, T, n_gpu)
-        ctx, pipe = self.ctx, self.pipe
-        pos0 = kv_state.len
-
-        ids_dev = input_ids.to("cuda", non_blocking=False).contiguous()
-        N.check(ctx.lib.lia_embed(ctypes.c_void_p(ids_dev.data_ptr()), ctypes.c_void_p(m.embed_tokens.data_ptr()),
-                                  ctypes.c_void_p(m.embed_positions.data_ptr()), ctypes.c_void_p(x.data_ptr()), B, T, pos0,
-                                  sh.hidden, ctypes.c_void_p(ctx.stream)), "lia_embed")
-
-        first_streamed = n_gpu
-        hold = None
-        if is_prefill and policy == 0 and n_gpu < L and self.defer_kv and pos0 == 0:
+            s.t_fwd0, s.busy0 = time.time(), (self.pipe.poll_stats()[1] if self.pipe else 0.0)
+        rows = B * T if n_gpu > 0 else s.mini * T                  # resident layers take the whole batch
+        if s.policy == 0 and n_gpu < L:
+            rows = max(rows, s.mini * kv_state.smax)               # policy-0 decode parks the cached prefix in a slab
+        s.x, s.y = self._ensure(rows, B, T, n_gpu)
+        if is_prefill and s.policy == 0 and n_gpu < L and self.defer_kv and s.pos0 == 0:
             self._await_all_deliveries()          # (host-blocking: afterwards nothing on the D2H stream reads the holding caches)
-            hold = self._hold_caches(B, T, n_gpu)
-        if policy == 1 and n_gpu < L:
-            import time
-            self._await_kv(kv_state)
-            t_host = time.time()
-            x = self._host_layers(x, kv_state, n_gpu, B, T, pos0)  # resident prefix on the GPU, the rest on the CPU
-            if not is_prefill:
-                self._host_team(self.dp.world if self.dp else 1).after_step(1e3 * (time.time() - t_host))
-            logits, nxt = ctx.lm_head(x, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
-            ctx.synchronize()
-            kv_state.len = pos0 + T
-            return logits, nxt
+            s.hold = self._hold_caches(B, T, n_gpu)
+
+    def _run_layers(self, s, kv_state):
+        """the decoder layers of one forward on the GPU path: the resident run, then every streamed layer behind its weight copy
+        (or on the host cores, for the cooperative split's host set); returns the hidden state that feeds lm_head"""
+        m, sh, ctx, pipe = self.model, self.model.shape, self.ctx, self.pipe
+        B, T, L, n_gpu, is_prefill, policy, mini, overlap, pos0, hold = s.B, s.T, s.L, s.n_gpu, s.is_prefill, s.policy, s.mini, s.overlap, s.pos0, s.hold
+        host_act, host_now, x, y = s.host_act, s.host_now, s.x, s.y
+        first_streamed = n_gpu
+
         def next_streamed(i, wrapped):
             """the streamed layer after i that needs a slot: decode forwards skip the host-computed layers"""
             while True:
@@ -771,9 +792,9 @@ class OffloadScheduler:
         xlast = None
         first = 0
         if not is_prefill and n_gpu > 0:
-            # decode: the resident run (whole batch, everything on the GPU incl. KV -- policy 3; :1246-1260) in ONE call: per layer an
-            # attention launch and a persistent chain launch (lia_chain.hip); LIA_FUSED_DECODE=0 and shapes the chain does not cover
-            # take the layer-by-layer route inside the library
+            # decode: the resident run (whole batch, everything on the GPU incl. KV -- policy 3; :1246-1260) in ONE library call
+            # (lia_decode_layers: the per-op route layer by layer, or with LIA_FUSED_DECODE=1 an attention launch and a
+            # persistent chain launch per layer, lia_chain.hip)
             key = (n_gpu, kv_state.serial, kv_state.version, self._resident(0)[0])
             if getattr(self, "_run_key", None) != key:
                 ptrs = []
@@ -789,9 +810,6 @@ class OffloadScheduler:
         for idx in range(first, L):
             if idx < n_gpu:
                 # resident layer: whole batch, everything on the GPU incl. KV (policy 3; :1246-1260)
-                if not is_prefill and idx + 1 < n_gpu:
-                    nw = self._resident(idx + 1)                   # decode: LN1 of the next resident layer rides in this layer's fc2 combine
-                    ctx.chain_next_norm(nw[0], nw[1])
                 if tail_last and idx == L - 1:
                     xlast = torch.empty((B, 1, sh.hidden), dtype=torch.bfloat16, device="cuda")
                     ctx.layer_forward_last(m.desc, 3, self._resident(idx), x, xlast, kv_state.kv[idx], B, T, pos0, 0)
@@ -842,8 +860,13 @@ class OffloadScheduler:
             x, y = y, x
             if not overlap:
                 ctx.synchronize()
+        return x if xlast is None else xlast
 
-        logits, nxt = ctx.lm_head(x if xlast is None else xlast, m.final_ln_w, m.final_ln_b, m.embed_tokens, sh.ln_eps, suppress_token)
+    def _deliver(self, s, kv_state):
+        """behind lm_head: the deferred K/V deliveries of a policy-0 prefill (tickets, awaited per layer by the first decode
+        step), the synchronisation the policy needs, the new cache length, and the cooperative controller's sample of the step"""
+        sh, ctx, pipe = self.model.shape, self.ctx, self.pipe
+        B, T, L, n_gpu, hold = s.B, s.T, s.L, s.n_gpu, s.hold
         if hold is not None:
             # the deferred deliveries, in the order the first decode step will need them; tickets are awaited per layer there
             import time
@@ -863,26 +886,24 @@ class OffloadScheduler:
             N.check(ctx.lib.lia_ctx_synchronize_compute(ctx.handle), "lia_ctx_synchronize_compute")
         else:
             ctx.synchronize()
-            if policy == 0 or (is_prefill and cpu_set):
+            if s.policy == 0 or (s.is_prefill and s.cpu_set):
                 ctx.kv_store_wait()                                # host cache complete before the next step reads it
-        kv_state.len = pos0 + T
-        if t_fwd0 is not None:
+        kv_state.len = s.pos0 + T
+        coop = s.coop
+        if s.t_fwd0 is not None:
             import time
-            step_ms = 1e3 * (time.time() - t_fwd0)
-            busy = (self.pipe.poll_stats()[1] - busy0) / max(step_ms, 1e-6) if self.pipe else 0.0
+            step_ms = 1e3 * (time.time() - s.t_fwd0)
+            busy = (self.pipe.poll_stats()[1] - s.busy0) / max(step_ms, 1e-6) if self.pipe else 0.0
             before = coop.host_set()
-            if before:
-                self._host_team(1).after_step(step_ms)                # a throttled container gives a host thread back
             coop.observe(step_ms, min(busy, 1.0))
             after = coop.host_set()
             for li in after - before:                             # newly host-computed: a queued copy of it will never be used
                 pipe.forget(li)
-            if decoding_policy == 3 and after != before:
+            if s.decoding_policy == 3 and after != before:
                 # KV in HBM: the cache of a layer that changes sides follows it (0.5 GB per layer at the headline shape, ~10 ms)
                 for li in sorted(after ^ before):
                     self._await_kv(kv_state, li)
                     self.kv_moved_bytes += kv_state.move_cache(ctx.lib, li, to_device=(li not in after))
-        return logits, nxt
 
     def _coop_controller(self, n_gpu, L, B, T, max_new_tokens, gpu_percentage, decoding_policy, start):
         key = (n_gpu, L, B, decoding_policy)
@@ -902,7 +923,7 @@ class OffloadScheduler:
             kept = CoopStore.load(store_key) if seeded_ok else None
             if kept is not None:
                 start = max(0, min(kept[0], len(order)))
-            self._coop = CoopController(order, start, min(len(order), int(start) + int(os.environ.get("LIA_COOP_HEADROOM", "10"))))
+            self._coop = CoopController(order, start, min(len(order), int(start) + COOP_HEADROOM))
             self._coop.store_key = store_key
             if kept is not None:                 # a count this box converged on before: look one to each side, nothing further
                 self._coop.seeded, self._coop.bracketed, self._coop.stride_i = True, True, len(CoopController.STRIDES) - 1
@@ -942,7 +963,7 @@ class OffloadScheduler:
 
     def host_team_report(self):
         g = getattr(self, "_host_gov", None)
-        return None if g is None else {"threads": g.threads, "dropped": g.drops, "pinned_by_env": g.pinned}
+        return None if g is None else {"threads": g.threads}
 
     def coop_report(self):
         return self._coop.report() if self._coop is not None else None
@@ -970,10 +991,10 @@ class OffloadScheduler:
         return frozenset(n_gpu + 1 + int((j + 0.5) * (n_str - 1) / count) for j in range(count))
 
     def _host_team(self, world=1):
-        """the governor of the whole-layer host team (hostinfo.HostTeamGovernor), created with the attention team's count"""
+        """the whole-layer host team (hostinfo.HostTeam): the attention team's count"""
         if getattr(self, "_host_gov", None) is None:
             from . import hostinfo
-            self._host_gov = hostinfo.HostTeamGovernor(getattr(self, "host_threads", None) or hostinfo.default_host_threads(world))
+            self._host_gov = hostinfo.HostTeam(getattr(self, "host_threads", None) or hostinfo.default_host_threads(world))
         return self._host_gov
 
     def _hidden_pair(self, nbytes):

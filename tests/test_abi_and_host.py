@@ -164,37 +164,25 @@ def test_hostinfo():
     assert isinstance(hostinfo.cpu_model(), str) and "avx512f" in hostinfo.isa_flags()
 
 
-def test_host_team_governor_gives_threads_back_under_throttling(monkeypatch):
-    """LIA_HOST_TEAM_GOVERNOR=1: the whole-layer host team keeps its count while the container is not throttled, loses one thread
-    after two consecutive steps with > 2 % of their time throttled, two at most; LIA_HOST_LAYER_THREADS pins the count; without
-    the switch the count never moves"""
+def test_pin_node_follows_the_switch(monkeypatch):
+    """LIA_PIN_NODE: the NUMA node the host threads are confined to (-1 = off); unset = the GPU's node from sysfs"""
     from lia_amd import hostinfo
-    monkeypatch.delenv("LIA_HOST_LAYER_THREADS", raising=False)
-    monkeypatch.setenv("LIA_HOST_TEAM_GOVERNOR", "1")
-    clock = {"us": 0}
-    monkeypatch.setattr(hostinfo, "cgroup_cpu_throttle", lambda: (0, clock["us"]))
-    g = hostinfo.HostTeamGovernor(16)
-    for _ in range(5):
-        assert g.after_step(350.0) == 16                       # quiet box
-    clock["us"] += 20000
-    assert g.after_step(350.0) == 16                           # one throttled step (20 ms of 350) is not a pattern
-    assert g.after_step(350.0) == 16                           # ... and a clean one resets the count
-    for want in (16, 15, 15, 14, 14, 14, 14):                  # two in a row cost a thread; the floor is team - 2
-        clock["us"] += 20000
-        assert g.after_step(350.0) == want
-    assert g.drops == 2
-    assert hostinfo.HostTeamGovernor(2).floor == 2             # tiny teams (a rank of an 8-GPU run) are left alone
-    monkeypatch.setenv("LIA_HOST_LAYER_THREADS", "12")
-    p = hostinfo.HostTeamGovernor(16)
-    for _ in range(4):
-        clock["us"] += 50000
-        assert p.after_step(350.0) == 12
-    monkeypatch.delenv("LIA_HOST_LAYER_THREADS")
-    monkeypatch.delenv("LIA_HOST_TEAM_GOVERNOR")
-    off = hostinfo.HostTeamGovernor(16)
-    for _ in range(4):
-        clock["us"] += 50000
-        assert off.after_step(350.0) == 16                     # the default: the count stays
+    monkeypatch.setattr(hostinfo, "gpu_numa_node", lambda dev=0: 5)
+    monkeypatch.delenv("LIA_PIN_NODE", raising=False)
+    assert hostinfo.pin_node(0) == 5
+    monkeypatch.setenv("LIA_PIN_NODE", "-1")
+    assert hostinfo.pin_node(0) == -1
+    monkeypatch.setenv("LIA_PIN_NODE", "1")
+    assert hostinfo.pin_node(3) == 1
+    monkeypatch.setenv("LIA_PIN_NODE", "")
+    assert hostinfo.pin_node(0) == 5
+    assert hostinfo.pin_to_node(10 ** 6) == 0                  # no such node: nothing pinned
+
+
+def test_host_team_is_the_attention_teams_count():
+    """the whole-layer host team: a fixed count (r03's throttle governor and its two switches are gone)"""
+    from lia_amd import hostinfo
+    assert hostinfo.HostTeam(16).threads == 16 and hostinfo.HostTeam(0).threads == 1 and not hasattr(hostinfo, "HostTeamGovernor")
 
 
 def test_shapes_and_flag_defaults():
@@ -379,12 +367,11 @@ def _host_linear_reference(x, w, b, r, relu):
     return synth.f32_to_bf16_bits(t)
 
 
-@pytest.mark.parametrize("rn", ["4", "6"])
-def test_host_linear_edge_shapes_and_epilogue(native, rn, tmp_path):
-    """lia_host_linear, both register-block widths of the decode kernel (LIA_HOST_LINEAR_RN, read once per process -> a child
-    process per setting): N not a multiple of the block or of 16, M not a multiple of 4, K-chunk tails, M > 256 (the generic
-    kernel), bias / ReLU / residual in every combination that the layer uses.  Against exact arithmetic: <= 1 % of the outputs
-    may differ by one bf16 ulp (fp32 summation order), none by more."""
+def test_host_linear_edge_shapes_and_epilogue(native, tmp_path):
+    """lia_host_linear (4 x 6 register blocks in the decode kernel): N not a multiple of the block or of 16, M not a multiple of
+    4, K-chunk tails, M > 256 (the generic kernel), bias / ReLU / residual in every combination that the layer uses.  Against
+    exact arithmetic: <= 1 % of the outputs may differ by one bf16 ulp (fp32 summation order), none by more.  (A child process:
+    the reference values are computed in float64 numpy next to an OpenMP team.)"""
     import subprocess
     import sys
     if not native.lib().lia_host_has_avx512_bf16():
@@ -411,8 +398,7 @@ for (M, n, k, relu, use_b, use_r) in T._HOST_LINEAR_CASES:
     assert neq.mean() <= 0.01 and ulp.max() <= 1, (M, n, k, float(neq.mean()), int(ulp.max()))
 print("ok")
 """
-    env = dict(os.environ, LIA_HOST_LINEAR_RN=rn)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
 
 

@@ -200,3 +200,34 @@ def test_chain_repeatable_under_many_launches():
     assert N.lib().lia_chain_launch_count() - n0 >= 300 * 3
     sched.close()
     model.close()
+
+
+def test_fused_decode_environment_switch(tmp_path):
+    """LIA_FUSED_DECODE=1 (read once when the library loads, hence a child process): the resident layers of a decode step take the
+    persistent-chain route -- chain launches are counted -- and the ids are those of the default per-op route"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, sys
+sys.path[:0] = [%r, %r]
+import torch
+from lia_amd import _native as N
+from lia_amd.generation import generate
+from lia_amd.llama import LiaLlamaModel, LlamaShape
+shape = LlamaShape("env", 512, 4, 2, 1024, 2, 1024, max_pos=64)
+model = LiaLlamaModel.random_init(shape, seed=4)
+ids = torch.randint(4, 1024, (16, 8), generator=torch.Generator().manual_seed(2))
+out = generate(model, ids, max_new_tokens=4, min_new_tokens=4, gpu_percentage=100, pin_weight=True)
+print(json.dumps({"ids": out.tolist(), "chain_launches": N.lib().lia_chain_launch_count()}))
+''' % (os.path.join(root, "isca-2025-lia_amd"), root)
+    res = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, LIA_FUSED_DECODE=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["1"]["chain_launches"] > 0 and res["0"]["chain_launches"] == 0
+    assert res["1"]["ids"] == res["0"]["ids"]

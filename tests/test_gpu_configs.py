@@ -353,18 +353,20 @@ def test_run_generation_prompt_through_the_checkpoints_tokenizer(tmp_path, capsy
     m = synth.make_model(seed, vocab, max_pos, H, F, L, float(z["w_std"][0]))
     ckpt = str(tmp_path / "opt-test")
     _write_hf_checkpoint(ckpt, m, c, blocked=False)
-    tok = Tokenizer(models.WordLevel({f"w{i}": i for i in range(vocab)}, unk_token="w3"))
-    tok.pre_tokenizer = pre_tokenizers.Whitespace()
-    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="w3", pad_token="w1", eos_token="w2").save_pretrained(ckpt)
+    word = lambda i: {1: "<pad>", 2: "</s>", 3: "<unk>"}.get(int(i), f"w{int(i)}")      # noqa: E731  (special tokens are matched as substrings: keep them unlike the words)
+    tok = Tokenizer(models.WordLevel({word(i): i for i in range(vocab)}, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", pad_token="<pad>", eos_token="</s>").save_pretrained(ckpt)
     prompt = synth.make_prompt_ids(seed + 1, B, T, vocab)[0]
-    text_in = " ".join(f"w{int(i)}" for i in prompt)
+    text_in = " ".join(word(i) for i in prompt)
     res = run_generation.main(["--benchmark", "-m", ckpt, "--dtype", "bfloat16", "--prompt", text_in, "--max-new-tokens", str(new),
                                "--batch-size", str(B), "--token-latency", "--num-iter", "2", "--num-warmup", "1", "--greedy",
                                "--prefill-policy", "0", "--decoding-policy", "2", "--gpu-percentage", "50", "--pin-weight"])
     text = capsys.readouterr().out
     assert f"---- Prompt size: {T}" in text and res["decode_tokens_per_s"] > 0
     assert text.count(str(z["ids_bf16"][0, T:].tolist())) == 2, text[-2000:]
-    assert " ".join(f"w{int(i)}" for i in z["ids_bf16"][0, T:]) in text          # batch_decode of prompt + continuation
+    cont = [int(i) for i in z["ids_bf16"][0, T:]]
+    assert all(i > 3 for i in cont) and " ".join(word(i) for i in cont) in text      # batch_decode of prompt + continuation
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -411,7 +413,7 @@ def test_dummy_checkpoint_directory_streams_like_the_generator(tmp_path, wire):
 
 def test_save_packed_round_trip_and_auto_plan_through_the_harness(tmp_path, capsys, monkeypatch):
     """save_packed(model) -> `run.py -m <dir> --auto-plan ...`: the planner calibrates the box through the C ABI (a few
-    seconds), chooses gpu% / policies (LIA_PLAN_MAX_GPU_PCT caps the resident share, so layers MUST stream), the harness loads the
+    seconds), chooses gpu% / policies (--plan-max-gpu-percentage caps the resident share, so layers MUST stream), the harness loads the
     packed directory, and the ids are the HF golden ids."""
     from lia_amd import packed_checkpoint as pc, planner, run_generation
     from lia_amd.model import LiaOPTModel, OPTShape
@@ -426,12 +428,12 @@ def test_save_packed_round_trip_and_auto_plan_through_the_harness(tmp_path, caps
     box = planner.calibrate()
     c = box.calibrated
     assert c["seconds"] < 10 and 15 < c["link_gbs"] < 70 and 1500 < c["hbm_gbs"] < 8000 and 400 < c["mfma_tflops"] < 2500 and c["host_attention_gbs"] > 1
-    monkeypatch.setenv("LIA_PLAN_MAX_GPU_PCT", "50")      # at most half of the layers may be resident: the others MUST stream
     prompt = synth.make_prompt_ids(seed + 1, B, T, vocab)[0]
     monkeypatch.setattr(run_generation, "synthetic_prompt",
                         lambda vocab_, n, batch, seed=0: __import__("torch").from_numpy(np.tile(prompt[None, :], (batch, 1))))
     res = run_generation.main(["--benchmark", "-m", d, "--dtype", "bfloat16", "--input-tokens", str(T), "--max-new-tokens", str(new),
-                               "--batch-size", str(B), "--token-latency", "--num-iter", "2", "--num-warmup", "1", "--greedy", "--auto-plan"])
+                               "--batch-size", str(B), "--token-latency", "--num-iter", "2", "--num-warmup", "1", "--greedy", "--auto-plan",
+                               "--plan-max-gpu-percentage", "50"])         # at most half of the layers may be resident: the others MUST stream
     text = capsys.readouterr().out
     assert "auto-plan: gpu%=" in text and "auto-plan: gpu%=100" not in text and res["decode_tokens_per_s"] > 0
     assert text.count(str(z["ids_bf16"][0, T:].tolist())) == 2, text[-3000:]

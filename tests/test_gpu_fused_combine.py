@@ -178,3 +178,65 @@ def test_llama_layers_fused_equals_unfused(B, H, heads, kvh, F, T):
         assert (fk == pk).all() and (fv == pv).all()
     ctx.close()
     model.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 7168, 7168), (128, 4096, 14336), (20, 1024, 4096)])
+def test_inlaunch_splitk_combine_equals_the_combine_kernel(M, N, K):
+    """lia_gemm_set_inlaunch_combine(1): the last-arriving K slice of a tile combines the slabs inside the GEMM launch (ticket per
+    tile) -- slower than the second kernel at these sizes (lia_gemm.hip), kept as the A/B leg: same slabs added in the same
+    order, so the same bits"""
+    import torch
+    from lia_amd import _native as N_, ops
+    lib = N_.lib()
+    lib.lia_gemm_set_inlaunch_combine.argtypes = [ctypes.c_int]
+    lib.lia_gemm_set_inlaunch_combine.restype = None
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = (0.02 * torch.randn((N, K), generator=g, device="cuda")).to(torch.bfloat16)
+    bias = (0.1 * torch.randn((N,), generator=g, device="cuda")).to(torch.bfloat16)
+    res = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
+    torch.cuda.synchronize()
+    ctx = ops.Context(0, 8 * M * N * 4 + (1 << 20))
+    try:
+        outs = []
+        for on in (1, 0):
+            lib.lia_gemm_set_inlaunch_combine(on)
+            y = ctx.linear(x, w, bias=bias, residual=res)
+            ctx.synchronize()
+            outs.append(to_bits(y).copy())
+        assert (outs[0] == outs[1]).all(), f"{(outs[0] != outs[1]).sum()} of {outs[0].size} values differ"
+    finally:
+        lib.lia_gemm_set_inlaunch_combine(0)
+        ctx.close()
+
+
+def test_tiled_prefill_gemm_variants_are_bit_identical():
+    """lia_gemm_set_tiled_variant: the phased kernel (262, default), its four-phase / global_load_lds forms (259-261), r01's
+    one-barrier kernel (256) and staggered k-half kernels (257 / 258) all add the same products in the same order"""
+    import torch
+    from lia_amd import _native as N_, ops
+    lib = N_.lib()
+    lib.lia_gemm_set_tiled_variant.argtypes = [ctypes.c_int]
+    lib.lia_gemm_set_tiled_variant.restype = None
+    M, N, K = 1024, 1536, 1024
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = (0.03 * torch.randn((N, K), generator=g, device="cuda")).to(torch.bfloat16)
+    bias = (0.1 * torch.randn((N,), generator=g, device="cuda")).to(torch.bfloat16)
+    torch.cuda.synchronize()
+    ctx = ops.Context(0, 1 << 24)
+    try:
+        ref = None
+        for v in (262, 261, 260, 259, 258, 257, 256):
+            lib.lia_gemm_set_tiled_variant(v)
+            y = ctx.linear(x, w, bias=bias, relu=True)
+            ctx.synchronize()
+            bits = to_bits(y).copy()
+            if ref is None:
+                ref = bits
+                want = torch.relu((x.float() @ w.float().T + bias.float()).to(torch.bfloat16).float())
+                assert float((y.float() - want).abs().max()) <= 0.02 * float(want.abs().max())
+            assert (bits == ref).all(), f"variant {v}: {(bits != ref).sum()} of {ref.size} values differ from variant 262"
+    finally:
+        lib.lia_gemm_set_tiled_variant(262)
+        ctx.close()

@@ -274,18 +274,20 @@ def test_layer_forward_last_equals_last_position_of_full_prefill(policy, H, head
     ctx.close()
 
 
-def test_generate_with_and_without_the_prefill_tail(monkeypatch):
-    """LIA_PREFILL_TAIL=0 (every position of the last layer, as the reference computes it) and the default give the golden ids"""
+def test_generate_with_and_without_the_prefill_tail():
+    """scheduler.prefill_tail = False (every position of the last layer, as the reference computes it) and the default give the
+    golden ids"""
     import torch
     from lia_amd.generation import generate
+    from lia_amd.scheduler import OffloadScheduler
     z, m, ids, c = _load("generate_h256")
-    outs = []
-    for tail in ("1", "0"):
-        monkeypatch.setenv("LIA_PREFILL_TAIL", tail)
+    for tail in (True, False):
         for flags in (HEADLINE, dict(gpu_percentage=100, prefill_policy=0, decoding_policy=2, pin_weight=True)):
             model = _model(m, c)
+            model._lia_scheduler = OffloadScheduler(model)
+            assert model._lia_scheduler.prefill_tail is True             # the default
+            model._lia_scheduler.prefill_tail = tail
             out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], **flags)
-            assert model._lia_scheduler.prefill_tail == (tail == "1")
             assert (out.numpy() == z["ids_bf16"]).all(), (tail, flags, out[0, c["T"]:].tolist())
             model._lia_scheduler.close()
             model.close()
@@ -309,7 +311,8 @@ def test_tier_moves_leave_the_layer_usable_when_the_host_allocation_is_refused(m
         raise MemoryError(f"{what}: refused by the test")
 
     monkeypatch.setattr(hostinfo, "guard_host_allocation", refuse)
-    for move in (lambda: st.to_pinned(10), lambda: st.to_cxl(0), lambda: st.to_pinned(0, shard=(0, 2))):
+    assert st.packed == 10                        # (the default wire format: to_pinned(10) would be a no-op, so ask for another one)
+    for move in (lambda: st.to_pinned(12), lambda: st.to_cxl(0), lambda: st.to_pinned(0, shard=(0, 2))):
         with pytest.raises(MemoryError):
             move()
         assert st.tier == "device" and st._dev is not None and st._ptr is None        # nothing lost, nothing leaked
