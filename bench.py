@@ -686,7 +686,9 @@ def main(argv=None):
             c0, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
                                             planner.Box(host_threads=host_threads,
                                                         wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]))
-            coop_kwargs = dict(gen_kwargs, cpu_layers=-1, cpu_layers_start=c0)      # -1: the scheduler's online controller, seeded by the plan
+            # -1: the scheduler's online controller.  No explicit start: it begins on the count this box converged on last time
+            # (scheduler.CoopStore, +-1 probes only) when there is one, else on the same plan as c0
+            coop_kwargs = dict(gen_kwargs, cpu_layers=-1)
             ids_coop, lat_coop, logits_coop = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **coop_kwargs)
             tail = lat_coop[-max(1, min(8, a.coop_steps // 2)):]                     # after the controller's search
             out["value_cooperative"] = B / (sum(tail) / len(tail))
@@ -708,7 +710,7 @@ def main(argv=None):
                                                 planner.Box(host_threads=host_threads,
                                                             wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
                                                 kv_in_hbm=True)
-                kv_kwargs = dict(gen_kwargs, prefill_policy=3, decoding_policy=3, cpu_layers=-1, cpu_layers_start=c3)
+                kv_kwargs = dict(gen_kwargs, prefill_policy=3, decoding_policy=3, cpu_layers=-1)
                 ids_kv, lat_kv, logits_kv = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **kv_kwargs)
                 tail = lat_kv[-max(1, min(8, a.coop_steps // 2)):]
                 out["value_cooperative_kv_in_hbm"] = B / (sum(tail) / len(tail))
