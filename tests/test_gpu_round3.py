@@ -372,3 +372,43 @@ def test_bench_line_contract_on_a_small_model():
     assert d["value_cooperative"] > 0 and "error" not in d["cooperative_leg"]
     assert d["value_cooperative_kv_in_hbm"] > 0 and "error" not in d["cooperative_kv_in_hbm_leg"], d.get("cooperative_kv_in_hbm_leg")
     assert d["ids_check"]["cooperative_vs_headline"]["steps_compared"] >= 4 and d["ids_check"]["cooperative_kv_in_hbm_vs_headline"]["steps_compared"] >= 4
+
+
+def test_a_layer_that_does_not_pack_ships_raw_by_itself():
+    """pack10 on the wire, one streamed layer whose values do not fit the format (magnitudes spread over 24 binades: most fall
+    outside the symbol window): that layer alone is pinned raw (LayerStore._encode_packed), the others travel packed, and the ids /
+    logits are those of the all-raw run bit for bit (the format is lossless, the fallback is the reference's own transfer).
+    bench.py's wire_stats reports it as layers_shipped_raw."""
+    import importlib.util
+    import torch
+    from lia_amd.generation import generate
+    from lia_amd.scheduler import OffloadScheduler
+    z, m, ids, c = _load("generate_h256")
+    rs = np.random.RandomState(5)
+    m = dict(m, layers=[dict(lw) for lw in m["layers"]])
+    li = len(m["layers"]) - 1
+    for name in ("fc1_w", "fc2_w", "q_w", "k_w", "v_w", "out_w"):
+        shp = m["layers"][li][name].shape
+        wide = 0.02 * np.exp2(-24.0 * rs.random_sample(shp)) * np.where(rs.random_sample(shp) < 0.5, -1.0, 1.0)
+        m["layers"][li][name] = synth.f32_to_bf16_bits(wide.astype(np.float32))
+    runs = {}
+    for fmt in ("raw", "pack10"):
+        model = _model(m, c)
+        model._lia_scheduler = OffloadScheduler(model, pack12=fmt)
+        out, _, logits = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], return_logits=True,
+                                  prefill_policy=0, decoding_policy=2, gpu_percentage=0, pin_weight=True)
+        runs[fmt] = (out.numpy().copy(), [lg.cpu().view(torch.int16).numpy().copy() for lg in logits])
+        if fmt == "pack10":
+            packed = [st.packed for st in model.layers]
+            assert packed[li] == 0 and all(p == 10 for p in packed[:li]), packed
+            assert model.layers[li].stream_bytes == model.layers[li].nbytes and model.layers[0].stream_bytes < 0.75 * model.layers[0].nbytes
+            spec = importlib.util.spec_from_file_location("lia_bench_ws", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+            bench = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bench)
+            ws = bench.wire_stats(model, 0)
+            assert ws["layers_shipped_raw"] == 1 and ws["max"] == 16.0 and ws["min"] < 12.0
+        model._lia_scheduler.close()
+        model.close()
+    assert (runs["raw"][0] == runs["pack10"][0]).all()
+    for a, b in zip(runs["raw"][1], runs["pack10"][1]):
+        assert (a == b).all()
