@@ -462,20 +462,12 @@ def main(argv=None):
         raise SystemExit("prompt + steps exceeds max positions")
     n_gpu = shape.layers if (is_llama and a.gpu_percentage >= 100) else int(shape.layers * a.gpu_percentage / 100)
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
-    coop_start = None
-    if a.cpu_layers < 0 and not is_llama:
-        # -1: the scheduler's online controller picks the count from the measured decode steps; the planner only seeds it
-        from lia_amd import planner
-        coop_start, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
-                                                planner.Box(host_threads=host_threads,
-                                                            wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
-                                                kv_in_hbm=(a.prefill_policy == 3 and a.decoding_policy == 3))
+    # --cpu-layers -1: the scheduler's online controller picks the count from the measured decode steps, starting on the count this
+    # box converged on last time (scheduler.CoopStore) or else on planner.plan_cpu_layers' estimate -- no explicit start from here
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
                  gpu_percentage=a.gpu_percentage, num_minibatch=a.num_minibatch, enable_cxl=a.enable_cxl, no_overlap=False)
     if a.cpu_layers:
         flags["cpu_layers"] = a.cpu_layers
-        if coop_start is not None:
-            flags["cpu_layers_start"] = coop_start
     if a.cxl_nodes:
         from lia_amd.cxl.numa_alloc import set_cxl_nodes
         set_cxl_nodes([int(v) for v in a.cxl_nodes.split(",")])

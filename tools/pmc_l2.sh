@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 out=gpurun_out/prof_${tag}_l2
 mkdir -p "$out"
-timeout 900 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d "$out" -o pmc -- python3 bench.py --steps 2 --no-cpu-baseline --no-raw-leg --no-cooperative-leg "$@" > "$out/run.log" 2>&1
+timeout 900 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d "$out" -o pmc -- python3 bench.py --steps 2 --no-cpu-baseline --no-raw-leg --no-cooperative-leg --no-defer-kv-leg "$@" > "$out/run.log" 2>&1
 tail -2 "$out/run.log" | cut -c1-200
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, os, re, sys
