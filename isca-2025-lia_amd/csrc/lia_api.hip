@@ -1003,10 +1003,11 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode step over a run of HBM-resident layers: per layer ONE attention launch and ONE persistent chain launch (lia_chain.hip)
+// decode step over a run of HBM-resident layers in one call: the per-op route layer by layer (default), or per layer ONE attention
+// launch and ONE persistent chain launch (lia_chain.hip)
 // ------------------------------------------------------------------------------------------------
 // Route switch: LIA_FUSED_DECODE=1 or lia_set_fused_decode(1) takes the persistent-chain route; the default (0) runs the same layers
-// through the per-layer entry points -- measured 3-6 % faster per step (r04, LABNOTES.md: a seam inside the launch costs what a
+// through the per-layer entry points -- measured 4-9 % faster per step (r04, LABNOTES.md: a seam inside the launch costs what a
 // kernel boundary costs, and the per-op kernels need no 160 KB ring started cold)
 static int g_fused_decode = [] { const char* e = getenv("LIA_FUSED_DECODE"); return (e && !strcmp(e, "1")) ? 1 : 0; }();
 extern "C" void lia_set_fused_decode(int on) { g_fused_decode = on ? 1 : 0; }

@@ -17,6 +17,11 @@
 //     meets, then plain loads / LDS-DMA.  Results never depend on placement; blockIdx % 8 only decides who waits for whom;
 //   * every spin is bounded (spin_limit polls): a barrier that times out sets the error word and the launch runs to its end.
 //
+// Status (r04): measured 4-9 % SLOWER per decode step than the per-op route it was meant to replace (16.85 vs 16.10 ms OPT-30B
+// resident, 8.42 vs 7.72 ms Llama-3-8B, results/r04_ab_*): a seam -- ring drain + grid barrier + reduce step + cold ring -- costs
+// what a kernel boundary + combine kernel costs, and the per-op kernels' tails overlap the next launch's head.  Opt-in
+// (LIA_FUSED_DECODE=1 / lia_set_fused_decode(1)); kept as a second implementation of the same arithmetic.  LABNOTES.md r04.
+//
 // Arithmetic: the K loop is lia_gemm_skinny2_kernel's (same chunks in the same order into the same accumulators), the combines
 // add the slabs slice 0, 1, ... and finish a value with lia_epilogue.h / lia_common.h's device functions -- so a chain launch
 // and the per-op path with the same K slices (lia_gemm_launch's force_split) give the same bits (tests/test_gpu_chain.py).

@@ -253,8 +253,8 @@ class LlamaScheduler:
         xlast = None
         first = 0
         if T == 1 and n_gpu > 0 and mini == B:
-            # decode: the resident run in ONE call -- per layer an attention launch and a persistent chain launch (lia_chain.hip);
-            # LIA_FUSED_DECODE=0 / shapes the chain does not cover take the layer-by-layer route inside the library
+            # decode: the resident run in ONE library call (lia_llama_decode_layers: the per-op route layer by layer with the chained
+            # norms, or with LIA_FUSED_DECODE=1 an attention launch and a persistent chain launch per layer, lia_chain.hip)
             key = (n_gpu, kv_state.serial, kv_state.version, resident(0)[0])
             if getattr(self, "_run_key", None) != key:
                 ptrs = []

@@ -1,12 +1,14 @@
 """-m gpu: the persistent decode chain (csrc/lia_chain.hip) against the per-op route, bit for bit.
 
-lia_decode_layers / lia_llama_decode_layers run the resident layers of a decode step as, per layer, one attention launch and ONE
-persistent launch (out-proj, norm, MLP, the next layer's norm and q|k|v projection, with the split-K combines inside).  The
+With lia_set_fused_decode(1), lia_decode_layers / lia_llama_decode_layers run the resident layers of a decode step as, per layer,
+one attention launch and ONE persistent launch (out-proj, norm, MLP, the next layer's norm and q|k|v projection, with the split-K
+combines inside).  The
 arithmetic is the per-op route's: same K chunks into the same accumulators, slabs added slice 0, 1, ..., values finished by the
 same device functions.  With lia_gemm_set_split_policy(1) the per-op GEMMs cut K into the chain's slices, so the two routes
 must agree on EVERY bit of the logits, the ids and the K/V rows they append -- any race in the in-launch hand-offs (grid
-barriers, write-through stores, LDS-DMA rings) shows up as a difference.  The per-op route itself is pinned to the oracle and
-to the reference goldens by the other -m gpu tests, which now run their decode steps through the chain as well.
+barriers, write-through stores, LDS-DMA rings) shows up as a difference.  The per-op route itself -- the default: the chain
+measured 4-9 % slower per step and is opt-in (LIA_FUSED_DECODE=1, lia_set_fused_decode(1)) -- is pinned to the oracle and to the
+reference goldens by the other -m gpu tests.
 """
 import numpy as np
 import pytest
