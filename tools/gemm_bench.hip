@@ -69,6 +69,27 @@ int main(int argc, char** argv) {
         ++nwg; first = std::min(first, q[0]); last = std::max(last, q[4]); last_start = std::max(last_start, q[0]); first_end = std::min(first_end, q[4]);
         d01 += (double)(q[1] - q[0]); d12 += (double)(q[2] - q[1]); d23 += (double)(q[3] - q[2]); d34 += (double)(q[4] - q[3]);
       }
+      if (getenv("S2DUMP")) {
+        // K-loop time and end time per workgroup, grouped by blockIdx.x % 8 (the XCD the dispatcher deals it to) and by octiles
+        double sum[8] = {0}, mx[8] = {0}; int cnt[8] = {0};
+        std::vector<double> loops, ends;
+        for (int g = 0; g < 8192; ++g) {
+          const unsigned long long* q = h.data() + 8 * g;
+          if (!q[0]) continue;
+          const double l = (double)(q[2] - q[1]) * 0.01, e = (double)(q[4] - first) * 0.01;
+          sum[g % 8] += l; mx[g % 8] = std::max(mx[g % 8], e); ++cnt[g % 8];
+          loops.push_back(l); ends.push_back(e);
+        }
+        printf("   per g %% 8: K loop avg / last end:");
+        for (int i = 0; i < 8; ++i) printf("  %d: %.1f / %.1f", i, cnt[i] ? sum[i] / cnt[i] : 0.0, mx[i]);
+        std::sort(loops.begin(), loops.end()); std::sort(ends.begin(), ends.end());
+        printf("\n   K loop us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f;  end us: p10 %.1f p50 %.1f p90 %.1f max %.1f\n", loops.front(), loops[loops.size() / 10],
+               loops[loops.size() / 2], loops[loops.size() * 9 / 10], loops.back(), ends[ends.size() / 10], ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends.back());
+        // first 32 workgroups in launch order: start offset, first chunk, loop
+        printf("   g: start / first chunk / loop / end:");
+        for (int g = 0; g < 8192 && g < 24; ++g) { const unsigned long long* q = h.data() + 8 * g; if (q[0]) printf("  %d: %.1f/%.1f/%.1f/%.1f", g, (q[0] - first) * 0.01, (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[4] - first) * 0.01); }
+        printf("\n");
+      }
       printf("%-8s M=%d N=%d K=%d: event bracket %.1f us; %d workgroups, span %.2f us (starts spread over %.2f us, first end at %.2f us); per workgroup: "
              "first chunk %.2f us, K loop %.2f us, stores issued %.2f us, drain %.2f us\n", sh.name, M, sh.N, sh.K, ms * 1e3, nwg, (last - first) * 0.01,
              (last_start - first) * 0.01, (first_end - first) * 0.01, d01 * 0.01 / nwg, d12 * 0.01 / nwg, d23 * 0.01 / nwg, d34 * 0.01 / nwg);
