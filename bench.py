@@ -79,7 +79,9 @@ def build_parser():
                     help="wire format of the streamed layers: raw bf16, or a lossless packed encoding (default: lia_amd.scheduler."
                          "default_stream_format() = $LIA_STREAM_FORMAT or pack10 -- the same default as run.py / OffloadScheduler)")
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--bracket-stride", type=int, default=8, help="HIP-event bracket around every Nth decode GEMM launch (a bracket "
+    ap.add_argument("--bracket-stride", type=int, default=0, help="0 = 8 when layers stream (the step is link-bound, a bracket's gaps are free), "
+                    "32 when every layer is resident (r04: the 16-24 brackets per step at stride 8 cost 0.2-0.3 ms of a 7.7 / 16 ms step); "
+                    "HIP-event bracket around every Nth decode GEMM launch (a bracket "
                     "costs two ~6 us idle gaps on the stream; 8 is co-prime to the 193 / 129 launches of an OPT-30B / Llama-3-8B step)")
     ap.add_argument("--cpu-layers", type=int, default=0,
                     help="build-defined: with decoding policy 2, this many streamed layers run their decode step on the host cores "
@@ -461,6 +463,8 @@ def main(argv=None):
     if T + new > shape.max_pos:
         raise SystemExit("prompt + steps exceeds max positions")
     n_gpu = shape.layers if (is_llama and a.gpu_percentage >= 100) else int(shape.layers * a.gpu_percentage / 100)
+    if a.bracket_stride <= 0:
+        a.bracket_stride = 32 if n_gpu >= shape.layers else 8       # both co-prime to the 193 / 129 launches of an OPT-30B / Llama-3-8B step
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
     # --cpu-layers -1: the scheduler's online controller picks the count from the measured decode steps, starting on the count this
     # box converged on last time (scheduler.CoopStore) or else on planner.plan_cpu_layers' estimate -- no explicit start from here
