@@ -45,6 +45,8 @@ def lib():
         L.lia_oracle_lm_head.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f]
         L.lia_oracle_set_fast.argtypes = [i]
         L.lia_oracle_set_fast.restype = None
+        L.lia_oracle_set_attn_twin.argtypes = [i]
+        L.lia_oracle_set_attn_twin.restype = None
         L.lia_oracle_fast_available.restype = i
         L.lia_oracle_num_threads.restype = i
         L.lia_oracle_set_threads.argtypes = [i]
