@@ -55,8 +55,10 @@ def build_parser():
     ap.add_argument("--global-batch", type=int, default=0, help="total rows, split evenly over the GPUs (BASELINE config 5: 256 over 8)")
     ap.add_argument("--prompt", type=int, default=256)
     ap.add_argument("--gpu-percentage", type=int, default=10)
-    ap.add_argument("--prefill-policy", type=int, default=0)
-    ap.add_argument("--decoding-policy", type=int, default=2)
+    ap.add_argument("--prefill-policy", type=int, default=None, help="default: 0 on one GPU (BASELINE configs[1]); on N > 1 GPUs 3 when every "
+                    "rank's KV cache fits its HBM (plan_policies), else 0")
+    ap.add_argument("--decoding-policy", type=int, default=None, help="default: 2 on one GPU; on N > 1 GPUs 3 (KV in HBM: G ranks share the host's "
+                    "CPU quota, host attention would run on 1/G of it each), else 2")
     ap.add_argument("--num-minibatch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raw-leg", action="store_true", help="skip the second, shorter leg with raw bf16 on the wire")
@@ -72,9 +74,14 @@ def build_parser():
     ap.add_argument("--force-dp", action="store_true", help="dry run: take the data-parallel (broadcast) path at world size 1")
     ap.add_argument("--dp-extra-timeout", type=int, default=420, help="seconds the extra legs may take before the run ends with the headline line only")
     ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the policy-1 CPU baseline leg")
+    ap.add_argument("--cpu-prefill-layers", type=int, default=2, help="layers of the policy-1 CPU prefill measured through lia_host_layer_forward "
+                    "at the configuration's B x T (cpu_baseline.prefill; 0 = keep the oracle's scaled one-layer sample only)")
     ap.add_argument("--enable-cxl", action="store_true", help="streamed weights live in the NUMA/CXL tier (numa_alloc_interleave + hipHostRegister)")
     ap.add_argument("--cxl-nodes", default=None, help="NUMA nodes of the CXL tier, e.g. 2,3 (default LIA_CXL_NODES or 2,3)")
-    ap.add_argument("--init", default="normal", choices=["normal", "uniform01"])
+    ap.add_argument("--init", default="normal", choices=["normal", "uniform01", "trained-like"],
+                    help="normal = HF _init_weights N(0, 0.02) (the headline); uniform01 = the reference's dummy-weight recipe; trained-like = "
+                         "per-tensor scales over ~3 binades, 0.1 %% outlier channels at 20 sigma, LayerNorm gains near 1 (a stress of the wire "
+                         "format: config.bits_per_value and layers_shipped_raw say what it cost)")
     ap.add_argument("--stream-format", default=None, choices=sorted(WIRE),
                     help="wire format of the streamed layers: raw bf16, or a lossless packed encoding (default: lia_amd.scheduler."
                          "default_stream_format() = $LIA_STREAM_FORMAT or pack10 -- the same default as run.py / OffloadScheduler)")
@@ -88,6 +95,7 @@ def build_parser():
                          "(policy 1 per layer, weights never cross the link); 0 = the reference's uniform policy; -1 = let "
                          "lia_amd.planner.plan_cpu_layers choose from the box's host rates")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)   # CPU test of the --gpus N self-launch
+    ap.add_argument("--selftest-dp-line", action="store_true", help=argparse.SUPPRESS)    # CPU (gloo) test of the N > 1 parts of the line
     return ap
 
 
@@ -181,6 +189,45 @@ def cpu_oracle_sample(shape, B, T, threads):
             "inner_loop": "avx512_bf16 vdpbf16ps" if fast else "fp32 fma",
             "sample": f"oracle policy 1, ONE {shape.name}-shaped layer: decode step B={B} S={T + 1} x{reps} and prefill B={Bp} T={T}; "
                       f"scaled x{L} layers (x{B // Bp} batch for prefill); embeddings / lm_head excluded"}
+
+
+def cpu_product_prefill_sample(model, shape, B, T, threads, n_layers=2):
+    """The CPU baseline's PREFILL through the product's own host path (r05, r04 verdict item 5): lia_host_layer_forward on the
+    configuration's full B x T rows (M = B * T > 256 -> the generic host GEMM, not the decode kernel) for n_layers consecutive
+    "layers" (one drawn layer's weights, each call fed the previous call's output and its own KV cache), scaled to the model's
+    layer count.  ~20 TFLOP per OPT-30B layer: a few seconds per layer on 16 cores."""
+    import ctypes
+    import numpy as np
+    import torch
+    from lia_amd import _native as N, ops
+    from lia_amd.model import draw_layer
+    L = N.lib()
+    H, F, heads = shape.hidden, shape.ffn, shape.heads
+    d = H // heads
+    flat = draw_layer(shape, model.offsets, model.layer_bytes, li=5, seed=321).cpu()
+    torch.cuda.synchronize()
+    host = flat.view(torch.int16).numpy().view(np.uint16)
+    arr = (ctypes.c_void_p * 16)(*[host.ctypes.data + off for off in model.offsets])
+    rs = np.random.RandomState(3)
+    blk = (rs.standard_normal(1 << 20)).astype(np.float32)
+    x = np.resize(((blk.view(np.uint32) + 0x8000) >> 16).astype(np.uint16), B * T * H).reshape(B, T, H).copy()
+    y = np.empty_like(x)
+    per = []
+    for _ in range(n_layers):
+        kc = np.zeros((T + 2, B, heads, d), np.uint16)
+        vc = np.zeros_like(kc)
+        t0 = time.time()
+        rc = L.lia_host_layer_forward(ctypes.byref(model.desc), ctypes.byref(arr), x.ctypes.data, y.ctypes.data, kc.ctypes.data, vc.ctypes.data,
+                                      T + 2, B, B, T, 0, 0, threads)
+        per.append(time.time() - t0)
+        if rc != 0:
+            raise RuntimeError(f"lia_host_layer_forward: {L.lia_last_error()}")
+        x, y = y, x
+    flops = 2.0 * B * T * (4.0 * H * H + 2.0 * H * F)
+    return {"prefill_ms": 1e3 * min(per) * shape.layers, "kind": f"product host path, {n_layers} layers measured",
+            "layer_s": per, "layer_tflops": flops / min(per) / 1e12, "threads": threads,
+            "sample": f"lia_host_layer_forward(policy 1) on B={B} x T={T} rows (M={B * T}: the M > 256 host kernel), {n_layers} layers of the "
+                      f"{shape.name} shape back to back, best layer x {shape.layers}; embeddings / lm_head excluded"}
 
 
 def parity_sample(sched, model, shape, B, T, threads):
@@ -330,7 +377,10 @@ def watchdog_line(out, progress, timeout_s):
     return line
 
 
-def watchdog_fire(out, progress, rank, timeout_s, _exit=os._exit):
+WATCHDOG_GRACE_S = 2.0
+
+
+def watchdog_fire(out, progress, rank, timeout_s, _exit=os._exit, _sleep=time.sleep):
     # a thread, not SIGALRM: the main thread of a hung rank sits inside a C call (an RCCL wait, a stream synchronize) and would never
     # reach a Python signal handler.  No restart, no exec: the process has touched the GPU -- it reports and ends.
     sys.stderr.write(f"bench.py: rank {rank}: the extra data-parallel leg {progress.get('current')!r} exceeded {timeout_s} s; "
@@ -338,15 +388,19 @@ def watchdog_fire(out, progress, rank, timeout_s, _exit=os._exit):
     sys.stderr.flush()
     if rank == 0:
         print(json.dumps(promote_scalars(watchdog_line(out, progress, timeout_s))), flush=True)
+    else:
+        # the launcher (torch.distributed.run) SIGTERMs every worker ~0.1 s after the first one fails: the other ranks hold on long
+        # enough for rank 0 to serialise and flush its line
+        _sleep(WATCHDOG_GRACE_S)
     _exit(WATCHDOG_EXIT_CODE)
 
 
 def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs, B, world, rank, n_gpu, fmt, host_threads, dev_index, progress=None,
                   rows_total=None):
-    """N > 1 (every rank calls this): value_kv_in_hbm -- the same broadcast stream with policy 3/3 (KV cache in HBM, no host
-    attention: what removes the per-rank host-thread bottleneck) --, value_allgather -- every rank pins 1/N of each streamed
-    layer and reads it over ITS OWN host link, one all-gather per layer over xGMI -- and value_allgather_kv_in_hbm, both
-    together.  Short legs (--dp-extra-steps)."""
+    """N > 1 (every rank calls this): value_policy_0_2 (or value_kv_in_hbm when the headline leg ran 0 / 2) -- the same broadcast
+    stream with the other cache placement: host attention on each rank's share of the CPU quota vs the KV cache in HBM --,
+    value_allgather -- every rank pins 1/N of each streamed layer and reads it over ITS OWN host link, one all-gather per layer over
+    xGMI -- and value_allgather_<other placement>, both together.  Short legs (--dp-extra-steps)."""
     import torch
     from lia_amd.generation import generate
     from lia_amd.model import LiaOPTModel
@@ -379,7 +433,12 @@ def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs,
             res[name + "_leg"] = {"error": f"{type(e).__name__}: {e}"}
         progress["current"] = None
 
-    leg("kv_in_hbm", model, dict(gen_kwargs, prefill_policy=3, decoding_policy=3))
+    # the OTHER cache placement than the headline leg's: with the default N > 1 policies (3 / 3, plan_policies) that is the
+    # reference's 0 / 2 with host attention on this rank's share of the CPU quota -- `value_policy_0_2` --, with 0 / 2 named on the
+    # command line it is `value_kv_in_hbm`
+    headline_kv_in_hbm = (gen_kwargs.get("prefill_policy"), gen_kwargs.get("decoding_policy")) == (3, 3)
+    alt_name, alt = ("policy_0_2", dict(prefill_policy=0, decoding_policy=2)) if headline_kv_in_hbm else ("kv_in_hbm", dict(prefill_policy=3, decoding_policy=3))
+    leg(alt_name, model, dict(gen_kwargs, **alt))
     if group.mode != "allgather" and world > 1:
         # every rank needs its own slice of every streamed layer: the root gives its copies up, all ranks draw the (seeded) layers
         # again and pin slice r of G.  The resident layers and the head stay as they are.
@@ -395,12 +454,101 @@ def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs,
             leg("allgather", m2, gen_kwargs)
             # ... and both together: every rank's own link AND no host attention -- the configuration in which neither the root's
             # PCIe link nor the shared CPU quota bounds the step
-            leg("allgather_kv_in_hbm", m2, dict(gen_kwargs, prefill_policy=3, decoding_policy=3))
+            leg("allgather_" + alt_name, m2, dict(gen_kwargs, **alt))
             m2._lia_scheduler.close()
             m2.close()
         except Exception as e:
             res["allgather_leg"] = {"error": f"{type(e).__name__}: {e}"}
     return res
+
+
+def plan_rows(a, rank, world):
+    """(rows of this rank, rows of the whole job): --batch is per GPU (weak scaling), --global-batch is split over the ranks with
+    the remainder on the first ones (BASELINE config 5: 256 over 8)"""
+    from lia_amd import dp
+    if a.global_batch:
+        if a.global_batch < world:
+            raise SystemExit(f"--global-batch {a.global_batch} leaves some of the {world} GPUs without a row")
+        lo_, hi_ = dp.shard_rows(a.global_batch, rank, world)
+        return hi_ - lo_, a.global_batch
+    return a.batch, a.batch * world
+
+
+def kv_cache_bytes(shape, rows, positions, layers=None):
+    """K and V rows of `layers` layers (default: all) for `rows` sequences of `positions` tokens, bf16"""
+    return 2 * 2 * positions * rows * shape.hidden * (shape.layers if layers is None else layers)
+
+
+def plan_policies(a, world, shape, rows, T, new, layer_bytes, hbm_bytes, n_gpu):
+    """(prefill policy, decode policy, why) when the command line names none.  One GPU: the reference's 0 / 2 (BASELINE configs[1]).
+    N > 1: the ranks of a node share ONE host -- 16 CPUs of quota on the GPU box, i.e. 2 host-attention threads per rank at N = 8,
+    ~480 ms of host attention in a 650 ms step -- so the default leg keeps every layer's KV cache in HBM
+    (policies 3 / 3, SURVEY 8 f-1) whenever it fits beside the resident layers, the streamer slots + staging and the workspace;
+    the 0 / 2 run is then the extra leg `value_policy_0_2`."""
+    if a.prefill_policy is not None or a.decoding_policy is not None:
+        return (0 if a.prefill_policy is None else a.prefill_policy), (2 if a.decoding_policy is None else a.decoding_policy), "named on the command line"
+    if world <= 1:
+        return 0, 2, "one GPU: the reference's prefill 0 / decode 2"
+    need = kv_cache_bytes(shape, rows, T + new) + (n_gpu + 4 + 4) * layer_bytes + 2 * kv_cache_bytes(shape, rows, T, 1) + (6 << 30)
+    if need <= 0.85 * hbm_bytes:
+        return 3, 3, f"N = {world}: KV of every layer in HBM ({need / 2**30:.1f} GiB of {hbm_bytes / 2**30:.0f} GiB per rank), no host attention on the shared CPU quota"
+    return 0, 2, f"N = {world}: the KV cache does not fit HBM beside the layers ({need / 2**30:.1f} GiB of {hbm_bytes / 2**30:.0f} GiB): host attention"
+
+
+def reduce_over_ranks(dist, backend, rank, world, elapsed, prefill_ms, dec_mean_s, host_threads, host_attn_ms_step, my_h2d_gbs, B):
+    """MAX over ranks of the three times + every rank's host-thread / link figures, through REAL collectives of the communicator
+    the run used: (elapsed, prefill_ms, dec_mean_s, rccl_ranks, per_rank)"""
+    import torch
+    per_rank = [{"rank": 0, "host_attention_threads": host_threads, "host_attention_ms_per_step": host_attn_ms_step,
+                 "h2d_gbs": my_h2d_gbs, "rows": B, "host_threads_starved": host_threads < MIN_HOST_THREADS}]
+    if dist is None:
+        return elapsed, prefill_ms, dec_mean_s, 1, per_rank
+    dev = "cuda" if backend == "nccl" else "cpu"
+    tmax = torch.tensor([elapsed, prefill_ms, dec_mean_s], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    mine = torch.tensor([float(rank), float(host_threads), host_attn_ms_step, my_h2d_gbs, float(B)], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    per_rank = [{"rank": int(v[0]), "host_attention_threads": int(v[1]), "host_attention_ms_per_step": float(v[2]),
+                 "h2d_gbs": float(v[3]), "rows": int(v[4]), "host_threads_starved": int(v[1]) < MIN_HOST_THREADS} for v in allr]
+    return float(tmax[0]), float(tmax[1]), float(tmax[2]), dist.get_world_size(), per_rank
+
+
+def dp_config_fields(a, shape, rows_total, world, group_mode, host_threads, policies):
+    from lia_amd import dp
+    return {"global_batch": rows_total, "rows_per_rank": [dp.shard_rows(rows_total, r, world)[1] - dp.shard_rows(rows_total, r, world)[0] for r in range(world)],
+            "parallelism": (f"dp{world} batch-shard, {group_mode} weight stream" if world > 1 else "single GPU"),
+            "host_attention_threads": host_threads, "policies": {"prefill": policies[0], "decode": policies[1], "why": policies[2]}}
+
+
+def dp_line_selftest(a):
+    """CPU-only (gloo) body behind --selftest-dp-line: everything the N > 1 line says ABOUT the job split -- row plan, default
+    policies, host threads per rank, the MAX / all-gather reductions, config.rows_per_rank -- through the same functions main()
+    uses, with synthetic per-rank timings (rank r: 10 + r ms per step).  No GPU, no model: tests/test_bench_launcher.py."""
+    import torch.distributed as dist
+    from lia_amd import hostinfo
+    from lia_amd.model import resolve_shape
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    shape = resolve_shape(a.model)
+    B, rows_total = plan_rows(a, rank, world)
+    T, new = a.prompt, 1 + a.warmup + a.steps
+    n_gpu = int(shape.layers * a.gpu_percentage / 100)
+    pol = plan_policies(a, world, shape, B, T, new, 2 * (4 * shape.hidden ** 2 + 2 * shape.hidden * shape.ffn), 288 * 2 ** 30, n_gpu)
+    host_threads = a.host_threads or hostinfo.default_host_threads(world)
+    step_s = (10.0 + rank) * 1e-3
+    elapsed, prefill_ms, dec_mean_s, ranks, per_rank = reduce_over_ranks(dist, "gloo", rank, world, step_s * a.steps, 100.0 + rank, step_s, host_threads,
+                                                                          1.5 * rank, 50.0 if rank == 0 else 0.0, B)
+    dist.barrier()
+    if rank == 0:
+        cfg = {"workload": f"{shape.name} shape, dp line selftest"}
+        cfg.update(dp_config_fields(a, shape, rows_total, world, "broadcast", host_threads, pol))
+        print(json.dumps({"metric": "dp line selftest", "value": rows_total * a.steps / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "scaling": "strong" if a.global_batch else "weak",
+                          "prefill_ms": prefill_ms, "rccl_ranks": ranks, "collective_backend": "gloo", "per_rank": per_rank, "config": cfg,
+                          "dp_line_selftest": True}), flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def main(argv=None):
@@ -410,6 +558,8 @@ def main(argv=None):
         return self_launch(a.gpus, argv)
     if a.selftest_launcher:
         return launcher_selftest()
+    if a.selftest_dp_line:
+        return dp_line_selftest(a)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -451,13 +601,7 @@ def main(argv=None):
         shape = resolve_llama_shape(a.model)
     else:
         shape = resolve_shape(a.model)
-    if a.global_batch:
-        if a.global_batch < world:
-            raise SystemExit(f"--global-batch {a.global_batch} leaves some of the {world} GPUs without a row")
-        lo_, hi_ = dp.shard_rows(a.global_batch, rank, world)      # a remainder goes to the first ranks, one extra row each
-        B, rows_total = hi_ - lo_, a.global_batch
-    else:
-        B, rows_total = a.batch, a.batch * world
+    B, rows_total = plan_rows(a, rank, world)
     T = a.prompt
     new = 1 + a.warmup + a.steps
     if T + new > shape.max_pos:
@@ -466,6 +610,9 @@ def main(argv=None):
     if a.bracket_stride <= 0:
         a.bracket_stride = 32 if n_gpu >= shape.layers else 8       # both co-prime to the 193 / 129 launches of an OPT-30B / Llama-3-8B step
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
+    layer_bytes_est = 2 * (4 * shape.hidden ** 2 + 2 * shape.hidden * shape.ffn) if not is_llama else 0
+    policies = plan_policies(a, world, shape, B, T, new, layer_bytes_est, torch.cuda.get_device_properties(dev_index).total_memory, n_gpu) if not is_llama else (0, 0, "llama: all resident")
+    a.prefill_policy, a.decoding_policy = policies[0], policies[1]
     # --cpu-layers -1: the scheduler's online controller picks the count from the measured decode steps, starting on the count this
     # box converged on last time (scheduler.CoopStore) or else on planner.plan_cpu_layers' estimate -- no explicit start from here
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
@@ -520,6 +667,8 @@ def main(argv=None):
             st["pre_h2d"] = sched.stream_stats()
         if step == 1 + a.warmup:                         # exactly --steps decode steps follow
             sched.stream_stats(reset=True)
+            if not is_llama:
+                sched.decode_stats(reset=True)
             sched.ctx.prof_start(16384, stride=a.bracket_stride)
             sync()
             st["thr0"] = hostinfo.cgroup_cpu_throttle()
@@ -531,6 +680,7 @@ def main(argv=None):
     thr1 = hostinfo.cgroup_cpu_throttle()
     prof = sched.ctx.prof_stop()
     h2d_bytes, h2d_ms = sched.stream_stats()
+    wire_dec = sched.decode_stats() if not is_llama else {"launches": 0, "ms": 0.0, "bytes_in": 0.0, "bytes_out": 0.0}
     prof_prefill, (pre_h2d_bytes, pre_h2d_ms) = st["prof_prefill"], st["pre_h2d"]
     assert len(lat) == new and out_ids.shape == (B, T + new)
     prefill_ms = 1e3 * lat[0]                             # run_generation.py:345: first-token latency
@@ -539,19 +689,8 @@ def main(argv=None):
     host_attn_ms_step = prof.get("host_attention_ms", 0.0) / max(1, a.steps)
 
     my_h2d_gbs = h2d_bytes / (elapsed * 1e9)
-    rccl_ranks, per_rank = 1, [{"rank": 0, "host_attention_threads": host_threads, "host_attention_ms_per_step": host_attn_ms_step,
-                                "h2d_gbs": my_h2d_gbs, "rows": B, "host_threads_starved": host_threads < MIN_HOST_THREADS}]
-    if dist is not None:
-        dev = "cuda" if backend == "nccl" else "cpu"
-        tmax = torch.tensor([elapsed, prefill_ms, dec_mean_s], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, prefill_ms, dec_mean_s = float(tmax[0]), float(tmax[1]), float(tmax[2])
-        mine = torch.tensor([float(rank), float(host_threads), host_attn_ms_step, my_h2d_gbs, float(B)], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)                      # a real collective over the communicator the run used
-        rccl_ranks = dist.get_world_size()
-        per_rank = [{"rank": int(v[0]), "host_attention_threads": int(v[1]), "host_attention_ms_per_step": float(v[2]),
-                     "h2d_gbs": float(v[3]), "rows": int(v[4]), "host_threads_starved": int(v[1]) < MIN_HOST_THREADS} for v in allr]
+    elapsed, prefill_ms, dec_mean_s, rccl_ranks, per_rank = reduce_over_ranks(dist, backend, rank, world, elapsed, prefill_ms, dec_mean_s, host_threads,
+                                                                              host_attn_ms_step, my_h2d_gbs, B)
 
     out = None
     if rank == 0:
@@ -578,16 +717,15 @@ def main(argv=None):
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{shape.name} shape (random-init {'U[0,1)' if a.init == 'uniform01' else 'N(0,0.02)'}), batch {B if rows_total == B * world else 'ceil(' + str(rows_total) + '/' + str(world) + ')'}/GPU identical rows, "
+            "config": {"workload": f"{shape.name} shape (random-init {'U[0,1)' if a.init == 'uniform01' else 'trained-like (per-tensor scales, outlier channels)' if a.init == 'trained-like' else 'N(0,0.02)'}), batch {B if rows_total == B * world else 'ceil(' + str(rows_total) + '/' + str(world) + ')'}/GPU identical rows, "
                                    f"prompt {T}, {new} new tokens, gpu%={a.gpu_percentage} ({n_gpu} resident + {shape.layers - n_gpu} streamed layers), "
                                    f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
                                    f"num-minibatch {a.num_minibatch}{(', ' + (str(a.cpu_layers) if a.cpu_layers > 0 else 'an online-chosen number of') + ' decode layers on the host cores') if a.cpu_layers else ''}",
-                       "global_batch": rows_total, "rows_per_rank": [dp.shard_rows(rows_total, r, world)[1] - dp.shard_rows(rows_total, r, world)[0] for r in range(world)], "prompt_len": T, "new_tokens": new, "new_tokens_requested": 32 if not is_llama else 128,
+                       **dp_config_fields(a, shape, rows_total, world, (group.mode if group is not None else None), host_threads, policies), "prompt_len": T, "new_tokens": new, "new_tokens_requested": 32 if not is_llama else 128,
                        "new_tokens_note": f"the configuration asks for {32 if not is_llama else 128} new tokens; this run generated 1 + warmup + steps = {new} "
                                           f"(cache sized for {T + new} positions), so the timed decode steps run at S = {T + 1 + a.warmup}..{T + new - 1}",
                        "baseline_config": ("configs[1]" if headline else "configs[4]" if config5 else None),
-                       "parallelism": (f"dp{world} batch-shard, {group.mode} weight stream" if world > 1 else "single GPU"),
-                       "host_attention_threads": host_threads, "host_numa_node": pin_node if pinned_cpus else None},
+                       "host_numa_node": pin_node if pinned_cpus else None},
             "prefill_ms": prefill_ms,
             "prefill_ms_note": ("first-token latency = latency_list[0] (run_generation.py:345).  With the policy-0 prefill the K/V rows of the streamed "
                                 "layers are parked in HBM and delivered to the host caches AFTER the first token (kv_delivery below; LIA_DEFER_KV=0 "
@@ -635,8 +773,34 @@ def main(argv=None):
         if a.cpu_layers < 0 and not is_llama:
             out["cooperative_controller"] = sched.coop_report()
         dk = out.pop("dominant_kernel_roofline")
+        dk["ms_per_step"] = sk_ms * a.bracket_stride / a.steps
         if streamed:
-            out["roofline"]["dominant_kernel"] = dk
+            # the kernel with the LARGEST per-step time inside the timed region leads (r04 verdict: the wire-format decode, 44 launches of
+            # ~0.5 ms on its own stream, outweighs the decode GEMMs' ~11 ms); the other one is reported beside it
+            wk = None
+            if wire_dec["launches"]:
+                wn = wire_dec["launches"]
+                w_ms = max(1e-9, wire_dec["ms"] - wn * prof.get("empty_bracket_ms", 0.0))
+                w_bytes = wire_dec["bytes_in"] + wire_dec["bytes_out"]
+                w_traffic, w_src = pmc_traffic(f"lia_{a.stream_format}_decode_kernel") if (a.model == "opt-30b" and B == 64) else (None, None)
+                wk = {"bound": "hbm", "kernel": f"lia_{a.stream_format}_decode_kernel (wire format -> bf16 layer in the streamer slot, own stream)",
+                      "achieved": w_bytes / (w_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "traffic": w_traffic, "traffic_source": w_src, "launches": wn, "avg_launch_us": 1e3 * w_ms / wn,
+                      "avg_bracket_us_raw": 1e3 * wire_dec["ms"] / wn, "algorithmic_bytes_per_launch": w_bytes / wn,
+                      "algorithmic_bytes_what": "encoded layer read once + bf16 layer written once",
+                      "ms_per_step": w_ms / a.steps, "share_of_step": (w_ms / a.steps) / (1e3 * elapsed / a.steps),
+                      "on_critical_path": False}
+            if wk is not None and wk["ms_per_step"] >= dk["ms_per_step"]:
+                out["roofline"]["dominant_kernel"] = wk
+                out["roofline"]["decode_gemm_kernel"] = dk
+            else:
+                out["roofline"]["dominant_kernel"] = dk
+                out["roofline"]["wire_decode_kernel"] = wk
+            # what the link DELIVERS in model bytes (every streamed layer's bf16 weights once per step) next to what crosses it
+            out["roofline"]["algorithmic_h2d_bytes"] = raw_bytes
+            out["roofline"]["algorithmic_h2d_gbs"] = raw_bytes / (elapsed / a.steps) / 1e9
+            out["roofline"]["algorithmic_h2d_note"] = ("bf16 weight bytes of the streamed layers per decode step (SURVEY 8d: 54.27 GB for the headline) / step time; "
+                                                       "`traffic` / `achieved` are the lossless wire encoding's bytes, which is what the link physically carries")
         else:                       # all-resident: the decode GEMM IS the binding roofline
             out["roofline"] = dict(dk, dominant_kernel=None)
 
@@ -664,6 +828,7 @@ def main(argv=None):
                 _, lat_nd = generate(model, ids, max_steps=1, **gen_kwargs)
                 sync()
                 pre.append(1e3 * lat_nd[0])
+            out["prefill_ms_defer_kv_0"] = min(pre)
             out["prefill_defer_kv_0_leg"] = {"prefill_ms": min(pre), "prefill_ms_runs": pre,
                                              "what": "first-token latency with LIA_DEFER_KV=0: the streamed layers' K/V rows go to the host caches "
                                                      "beside the prefill's weight stream (the reference's store_cache), so this number contains the D2H "
@@ -737,16 +902,30 @@ def main(argv=None):
         except Exception as e:          # the oracle sample below still gives a baseline
             product = {"error": f"{type(e).__name__}: {e}"}
         orc = cpu_oracle_sample(shape, B, T, host_threads)
+        try:
+            cpu_pre = cpu_product_prefill_sample(model, shape, B, T, host_threads, a.cpu_prefill_layers) if a.cpu_prefill_layers > 0 else None
+        except Exception as e:
+            cpu_pre = {"error": f"{type(e).__name__}: {e}"}
         best = max(orc["decode_tokens_per_s"], product.get("decode_tokens_per_s", 0.0))
         out["cpu_baseline"] = {"value": best, "unit": "tokens/s", "cores": ((sched.host_team_report() or {}).get("threads", host_threads) if best == product.get("decode_tokens_per_s") else host_threads), "kind": "port",
                                "implementation": ("product host path through generate()" if best == product.get("decode_tokens_per_s") else "oracle restatement, one-layer sample"),
                                "sample": product.get("sample", orc["sample"]),
-                               "product_host_path": product, "oracle_port": orc, "prefill_ms": orc["prefill_ms"],
+                               "product_host_path": product, "oracle_port": orc,
+                               "prefill_ms": (cpu_pre or {}).get("prefill_ms", orc["prefill_ms"]),
+                               "prefill": (cpu_pre if cpu_pre and "prefill_ms" in cpu_pre else dict(cpu_pre or {}, prefill_ms=orc["prefill_ms"], kind="oracle restatement, one-layer B/8 sample scaled")),
                                "cpu": hostinfo.cpu_model(), "isa": hostinfo.isa_flags(), "cpus_usable": hostinfo.usable_cpus()}
         try:
             out["parity"] = parity_sample(sched, model, shape, B, T, host_threads)
         except Exception as e:
             out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        # whether a cooperative leg started on a count an EARLIER process left in $LIA_STATE_DIR (scheduler.CoopStore keeps and reads
+        # it only when that variable is set): a seeded and an unseeded run of the same box are different measurements
+        seeded = {k: bool(((out.get(k) or {}).get("controller") or {}).get("seeded_from_store")) for k in ("cooperative_leg", "cooperative_kv_in_hbm_leg")
+                  if isinstance(out.get(k), dict) and "controller" in out[k]}
+        if seeded:
+            out["cooperative_seeded_from_store"] = seeded
+            out["cooperative_state_dir"] = os.environ.get("LIA_STATE_DIR")
     if rank == 0 and ids_check:
         out["ids_check"] = ids_check
 
@@ -758,7 +937,7 @@ def main(argv=None):
         # the name of the leg that hung, so the measured headline is still the last JSON line of the output.
         import threading
         if rank == 0:
-            out["dp_extra_legs"] = "pending (this line is re-printed with value_kv_in_hbm / value_allgather when they finish)"
+            out["dp_extra_legs"] = "pending (this line is re-printed with value_policy_0_2 (or value_kv_in_hbm) / value_allgather when they finish)"
             print(json.dumps(promote_scalars(out)), flush=True)
         progress = {}
         timer = threading.Timer(a.dp_extra_timeout, watchdog_fire, args=(out, progress, rank, a.dp_extra_timeout))

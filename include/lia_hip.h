@@ -322,6 +322,10 @@ int lia_stream_stats(lia_streamer* s, double* bytes, double* busy_ms, int reset)
 /* the same totals without ever blocking: copies still in flight are left for a later call (used inside the token loop by the
  * online cooperative-split controller, which must not wait for the prefetched layers) */
 int lia_stream_poll_stats(lia_streamer* s, double* bytes, double* busy_ms);
+/* Live timing of the wire-format decode kernel (bench.py's roofline.dominant_kernel; the role rocprofv3's per-kernel average plays
+ * in profiles/): launches, summed HIP-event milliseconds around the MAIN decode kernel on the decode stream, encoded bytes read and
+ * bf16 bytes written by them since the last reset.  Waits for the decodes still in flight. */
+int lia_stream_decode_stats(lia_streamer* s, long* launches, double* ms, double* bytes_in, double* bytes_out, int reset);
 void* lia_stream_copy_stream(lia_streamer* s);
 
 /* ---- host memory tiers ------------------------------------------------------------------------------

@@ -1321,7 +1321,7 @@ extern "C" int lia_decode_layers(lia_ctx* ctx, const lia_layer_desc* d, int n_la
 extern "C" size_t lia_pack12_bound(size_t n_values);
 extern "C" size_t lia_pack11_bound(size_t n_values);
 extern "C" size_t lia_pack10_bound(size_t n_values);
-extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st);
+extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 
 #ifndef LIA_DECODE_CUS_DEFAULT
 #define LIA_DECODE_CUS_DEFAULT 0
@@ -1336,6 +1336,12 @@ struct lia_streamer {
   hipStream_t decode;     // pack12 decode kernels run here, ordered after the slot's copy by an event
   std::vector<hipEvent_t> landed;
   std::vector<char> decoded_on_side;
+  // live timing of the wire-format decode kernel (lia_stream_decode_stats): one event pair per slot around the MAIN decode kernel
+  std::vector<hipEvent_t> d0, d1;
+  std::vector<char> decode_pending;
+  std::vector<double> decode_in, decode_out;      // bytes of the pending launch: encoded layer read, bf16 layer written
+  double dec_ms, dec_in, dec_out;
+  long dec_launches;
   hipStream_t copy;
   std::vector<hipEvent_t> copied, released, t0, t1;
   std::vector<char> has_release, timing_pending, was_marked;
@@ -1343,6 +1349,18 @@ struct lia_streamer {
   char* bounce;
   double bytes, busy_ms;
 };
+
+static void streamer_collect_decode(lia_streamer* s, int slot, bool wait) {
+  if (s->decode_pending.empty() || !s->decode_pending[slot]) return;
+  if (!wait && hipEventQuery(s->d1[slot]) != hipSuccess) return;
+  if (hipEventSynchronize(s->d1[slot]) == hipSuccess) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->d0[slot], s->d1[slot]) == hipSuccess) {
+      s->dec_ms += ms; s->dec_in += s->decode_in[slot]; s->dec_out += s->decode_out[slot]; s->dec_launches++;
+    }
+  }
+  s->decode_pending[slot] = 0;
+}
 
 static void streamer_collect(lia_streamer* s, int slot) {
   if (!s->timing_pending[slot]) return;
@@ -1362,6 +1380,7 @@ extern "C" int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, l
   lia_streamer* s = new lia_streamer();
   s->ctx = ctx; s->n_slots = n_slots; s->slot_bytes = align_up(slot_bytes, 256);
   s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr; s->staging = nullptr; s->staging_bytes = 0;
+  s->dec_ms = s->dec_in = s->dec_out = 0; s->dec_launches = 0;
   HIP_TRY(hipMalloc((void**)&s->slots, s->slot_bytes * n_slots));
   if (ctx->serialized) s->copy = ctx->compute;
   else HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
@@ -1390,6 +1409,8 @@ extern "C" void lia_stream_destroy(lia_streamer* s) {
   if (s->staging) {
     (void)hipStreamSynchronize(s->decode);
     for (hipEvent_t e : s->landed) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->d0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->d1) (void)hipEventDestroy(e);
     if (s->decode != s->ctx->compute) (void)hipStreamDestroy(s->decode);
     (void)hipFree(s->staging);
   }
@@ -1466,7 +1487,13 @@ static int ensure_staging(lia_streamer* s) {
   }
   s->landed.resize(s->n_slots);
   s->decoded_on_side.assign(s->n_slots, 0);
-  for (int i = 0; i < s->n_slots; ++i) HIP_TRY(hipEventCreateWithFlags(&s->landed[i], hipEventDisableTiming));
+  s->d0.resize(s->n_slots); s->d1.resize(s->n_slots);
+  s->decode_pending.assign(s->n_slots, 0); s->decode_in.assign(s->n_slots, 0.0); s->decode_out.assign(s->n_slots, 0.0);
+  for (int i = 0; i < s->n_slots; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&s->landed[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&s->d0[i]));
+    HIP_TRY(hipEventCreate(&s->d1[i]));
+  }
   return LIA_OK;
 }
 
@@ -1504,8 +1531,13 @@ extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_valu
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));                       // copy-engine busy time ends here
   HIP_TRY(hipEventRecord(s->landed[slot], s->copy));
   HIP_TRY(hipStreamWaitEvent(s->decode, s->landed[slot], 0));
-  lia_packed_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, format, s->decode);
+  streamer_collect_decode(s, slot, true);                              // (the slot's previous decode finished long ago: its consumer released the slot)
+  lia_packed_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, format, s->decode,
+                           s->d0[slot], s->d1[slot]);
   HIP_TRY(hipGetLastError());
+  s->decode_in[slot] = (double)s->pending_bytes[slot];
+  s->decode_out[slot] = 2.0 * (double)n_values;
+  s->decode_pending[slot] = 1;
   s->decoded_on_side[slot] = 1;
   return LIA_OK;
 }
@@ -1516,7 +1548,7 @@ extern "C" int lia_pack_decode(const char* src_device, lia_bf16* dst_device, siz
     lia_set_error("lia_pack_decode: n_values=%zu format=%d", n_values, format);
     return LIA_ERR_INVALID;
   }
-  lia_packed_decode_launch(src_device, dst_device, n_values, format, (hipStream_t)stream);
+  lia_packed_decode_launch(src_device, dst_device, n_values, format, (hipStream_t)stream, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   return LIA_OK;
 }
@@ -1579,6 +1611,20 @@ extern "C" int lia_stream_stats(lia_streamer* s, double* bytes, double* busy_ms,
   if (bytes) *bytes = s->bytes;
   if (busy_ms) *busy_ms = s->busy_ms;
   if (reset) { s->bytes = 0; s->busy_ms = 0; }
+  return LIA_OK;
+}
+
+// Live timing of the wire-format decode kernel (the largest GPU consumer of a link-bound decode step; bench.py's
+// roofline.dominant_kernel): HIP events on the decode stream around the main decode kernel of every packed layer since the last
+// reset.  bytes_in = encoded bytes the kernel read, bytes_out = bf16 bytes it wrote (its algorithmic traffic: each once).
+extern "C" int lia_stream_decode_stats(lia_streamer* s, long* launches, double* ms, double* bytes_in, double* bytes_out, int reset) {
+  if (!s) return LIA_ERR_INVALID;
+  for (int i = 0; i < s->n_slots; ++i) streamer_collect_decode(s, i, true);
+  if (launches) *launches = s->dec_launches;
+  if (ms) *ms = s->dec_ms;
+  if (bytes_in) *bytes_in = s->dec_in;
+  if (bytes_out) *bytes_out = s->dec_out;
+  if (reset) { s->dec_ms = s->dec_in = s->dec_out = 0; s->dec_launches = 0; }
   return LIA_OK;
 }
 

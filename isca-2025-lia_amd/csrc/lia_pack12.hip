@@ -686,7 +686,141 @@ __device__ __forceinline__ uint64_t lp10_get_bits(const uint32_t* stream, uint64
   return v;
 }
 
+// ---- decode (r05) ----------------------------------------------------------------------------------------------
+// r01-r04 decoded a lane's 16 values one at a time (extract c1, branch to level 2, branch to level 3, assemble x): ~30 VALU
+// operations per value with every branch taken by some lane of the wave -- 616 M values x 30 / (256 CUs x 64 lanes x 2.4 GHz)
+// = 0.47 ms of vector ALU time per OPT-30B layer against 0.26 ms of memory time (0.83 GB in + 1.23 GB out at 8 TB/s): the
+// kernel was VALU-bound at 0.56 ms.  Now four values travel per 32-bit register, one per byte, and nothing branches:
+//   * level 1: the two plane nibbles of a group index a 256-entry LDS table -> the four 2-bit codes as bytes + the escape mask;
+//     the exponents are ONE v_perm_b32 (the region's symbol word as the byte source, the code bytes as the selector);
+//   * level 2: the next four 2-bit codes of the lane's stream are spread to bytes and DEPOSITED onto the escape positions by a
+//     second v_perm_b32 whose selector comes from a 16-entry LDS table indexed by the escape nibble (selector byte = rank of the
+//     position among the set bits, 0x0c = constant zero elsewhere) -- a 4-wide PDEP; exponents again by v_perm_b32;
+//   * level 3: same deposit for the 4-bit codes, exponent e3 + nibble (0 for codes 14 / 15) out of two 8-byte v_perm tables;
+//   * sign|mantissa and exponent bytes become four bf16 by byte arithmetic + two byte interleaves.
+// ~14 operations per value.  Same format, same bits out (tests/test_gpu_ops.py::test_pack10_*, tools/pack10_decode_bench).
+constexpr unsigned LP10_DECODE_GRID = 32768;
+__device__ __forceinline__ uint32_t lp10_bytemask(uint32_t bits01) {      // bytes 0x01 -> 0xff, 0x00 -> 0x00
+  return __builtin_amdgcn_perm(0u, 0u, bits01 + 0x0c0c0c0cu);           // v_perm selector 0x0c = 0x00, 0x0d = 0xff
+}
+
+// inclusive wave prefix sum by DPP (row_shr 1/2/4/8, row_bcast 15 / 31): six VALU operations, no LDS traffic
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+// The encoded planes are loaded and the rebuilt values stored NON-TEMPORALLY (each is touched once by this kernel), in a grid of
+// 32768 workgroups: measured on MI355X (tools/pack10_decode_bench, one OPT-30B layer, results/r05_pack10_decode_ab.log) 586 us
+// (r04 kernel) -> 414 (this arithmetic, r04's 8192 workgroups, plain accesses) -> 397 (32768 workgroups) -> 385 us (non-temporal)
+// = 5.36 TB/s = 0.67 of 8 TB/s; issuing the next block's plane loads before decoding this one (a software prefetch) gained
+// nothing on top (391-402 us), one workgroup per four blocks without a loop lost (414-460 us).
 __global__ __launch_bounds__(256) void lia_pack10_decode_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
+  __shared__ uint2 lut1[256];        // [n1 << 4 | n0] -> {code bytes c1 of the four values, 0xff where c1 == 3}
+  __shared__ uint32_t lut4[16];      // [position nibble] -> v_perm selector that deposits compact bytes 0.. onto the set positions
+  {
+    const uint32_t t = threadIdx.x, n0 = t & 15, n1 = t >> 4;
+    uint32_t c = 0, m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t ci = ((n0 >> i) & 1) | (((n1 >> i) & 1) << 1);
+      c |= ci << (8 * i);
+      if (ci == 3) m |= 0xffu << (8 * i);
+    }
+    lut1[t] = uint2{c, m};
+    if (t < 16) {
+      uint32_t sel = 0, rank = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((t >> i) & 1) sel |= rank++ << (8 * i);
+        else sel |= 0x0cu << (8 * i);
+      }
+      lut4[t] = sel;
+    }
+  }
+  __syncthreads();
+  const LiaPack10Header* hd = (const LiaPack10Header*)src;
+  const size_t nblk = hd->n / 1024;
+  const Lp10Region* rtab = (const Lp10Region*)(src + hd->off_rtab);
+  const int rshift = (int)hd->region_shift;
+  const uint8_t* pa = (const uint8_t*)(src + hd->off_a);
+  const uint16_t *p0 = (const uint16_t*)(src + hd->off_b0), *p1 = (const uint16_t*)(src + hd->off_b1);
+  const uint32_t* tab2 = (const uint32_t*)(src + hd->off_tab2);
+  const uint32_t* tab3 = (const uint32_t*)(src + hd->off_tab3);
+  const uint32_t* l2w = (const uint32_t*)(src + hd->off_l2);
+  const uint32_t* l3w = (const uint32_t*)(src + hd->off_l3);
+  const int lane = threadIdx.x & 63;
+  size_t blk = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t stride = (size_t)gridDim.x * 4;
+  typedef uint32_t lp_u32x4 __attribute__((ext_vector_type(4)));
+  for (; blk < nblk; blk += stride) {
+    const Lp10Region rt = rtab[blk >> rshift];
+    const uint32_t sym1 = __builtin_amdgcn_readfirstlane(rt.sym1), sym2 = __builtin_amdgcn_readfirstlane(rt.sym2);
+    const uint32_t e3b = __builtin_amdgcn_readfirstlane(rt.e3) * 0x01010101u;
+    // level-3 exponent tables: byte i of q0|q1|q2|q3 = e3 + i, entries 14 / 15 = 0
+    const uint32_t q0 = e3b + 0x03020100u, q1 = e3b + 0x07060504u, q2 = e3b + 0x0b0a0908u, q3 = (e3b + 0x00000d0cu) & 0x0000ffffu;
+    const size_t g = blk * 64 + lane;
+    const lp_u32x4 av = __builtin_nontemporal_load((const lp_u32x4*)(pa + g * 16));
+    const uint32_t a[4] = {av[0], av[1], av[2], av[3]};
+    const uint32_t b0 = __builtin_nontemporal_load(p0 + g), b1 = __builtin_nontemporal_load(p1 + g);
+    const uint32_t esc1 = b0 & b1;
+    const int n2 = __popc(esc1);
+    const int ex2 = wave_incl_scan_dpp(n2) - n2;
+    uint32_t l2 = 0;
+    if (n2) l2 = (uint32_t)lp10_get_bits(l2w, ((uint64_t)tab2[blk] + ex2) * 2, 2 * n2);
+    if (n2 < 16) l2 &= (1u << (2 * n2)) - 1u;
+    const int n3 = __popc(l2 & (l2 >> 1) & 0x55555555u);
+    const int ex3 = wave_incl_scan_dpp(n3) - n3;
+    uint64_t l3 = 0;
+    if (n3) l3 = lp10_get_bits(l3w, ((uint64_t)tab3[blk] + ex3) * 4, 4 * n3);
+    uint32_t o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // ---- level 1
+      const uint32_t n0 = (b0 >> (4 * j)) & 15u, n1 = (b1 >> (4 * j)) & 15u;
+      const uint2 c1m = lut1[(n1 << 4) | n0];
+      uint32_t E = __builtin_amdgcn_perm(0u, sym1, c1m.x);
+      // ---- level 2: the lane's next popc(nib) codes go to the escape positions of this group
+      const uint32_t nib = n0 & n1;
+      const uint32_t c8 = l2 & 0xffu;
+      uint32_t s2 = (c8 | (c8 << 12)) & 0x000f000fu;
+      s2 = (s2 | (s2 << 6)) & 0x03030303u;
+      const uint32_t C2 = __builtin_amdgcn_perm(0u, s2, lut4[nib]);
+      l2 >>= 2 * __popc(nib);
+      E = (__builtin_amdgcn_perm(0u, sym2, C2) & c1m.y) | (E & ~c1m.y);
+      // ---- level 3: positions whose level-2 code is 3
+      const uint32_t t3 = C2 & (C2 >> 1) & 0x01010101u;
+      const uint32_t idx3 = __builtin_amdgcn_udot4(t3, 0x08040201u, 0u, false);
+      const uint32_t x16 = (uint32_t)l3 & 0xffffu;
+      uint32_t s3 = (x16 | (x16 << 8)) & 0x00ff00ffu;
+      s3 = (s3 | (s3 << 4)) & 0x0f0f0f0fu;
+      const uint32_t N = __builtin_amdgcn_perm(0u, s3, lut4[idx3]);
+      l3 >>= 4 * __popc(idx3);
+      const uint32_t sel7 = N & 0x07070707u;
+      const uint32_t hi8 = lp10_bytemask((N >> 3) & 0x01010101u);
+      const uint32_t E3 = (__builtin_amdgcn_perm(q3, q2, sel7) & hi8) | (__builtin_amdgcn_perm(q1, q0, sel7) & ~hi8);
+      const uint32_t m3 = lp10_bytemask(t3);
+      E = (E3 & m3) | (E & ~m3);
+      // ---- bf16 = sign << 15 | exponent << 7 | mantissa, four at a time: low bytes, high bytes, interleave
+      const uint32_t A = a[j];
+      const uint32_t lo = (A & 0x7f7f7f7fu) | ((E & 0x01010101u) << 7);
+      const uint32_t hi = (A & 0x80808080u) | ((E >> 1) & 0x7f7f7f7fu);
+      o[2 * j] = __builtin_amdgcn_perm(hi, lo, 0x05010400u);
+      o[2 * j + 1] = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+    }
+    __builtin_nontemporal_store(lp_u32x4{o[0], o[1], o[2], o[3]}, (lp_u32x4*)(dst + g * 16));
+    __builtin_nontemporal_store(lp_u32x4{o[4], o[5], o[6], o[7]}, (lp_u32x4*)(dst + g * 16 + 8));
+  }
+}
+
+#ifdef LIA_PACK10_AB
+// the r01-r04 decode, kept for tools/pack10_decode_bench.hip only (bit-identity + timing of the two)
+__global__ __launch_bounds__(256) void lia_pack10_decode_v1_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
   const LiaPack10Header* hd = (const LiaPack10Header*)src;
   const size_t nblk = hd->n / 1024;
   const Lp10Region* rtab = (const Lp10Region*)(src + hd->off_rtab);
@@ -744,6 +878,8 @@ __global__ __launch_bounds__(256) void lia_pack10_decode_kernel(const char* __re
   }
 }
 
+#endif
+
 __global__ __launch_bounds__(256) void lia_pack10_patch_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
   const LiaPack10Header* hd = (const LiaPack10Header*)src;
   const uint2* esc = (const uint2*)(src + hd->off_esc);
@@ -798,22 +934,30 @@ extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, 
 }
 
 // Decode either format (the header's magic says which); asynchronous on `st`.
-extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st) {
+// ev0 / ev1 (nullable): recorded on `st` immediately around the MAIN decode kernel (lia_stream_decode_stats; the patch kernel
+// behind it -- a few hundred escape records -- is outside the bracket, as a profiler's per-kernel duration would have it).
+extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (format == 10) {
     size_t nblk = n_values / 1024;
     unsigned blocks = (unsigned)((nblk + 3) / 4);
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > LP10_DECODE_GRID) blocks = LP10_DECODE_GRID;
     if (blocks == 0) return;
+    if (ev0) (void)hipEventRecord(ev0, st);
     hipLaunchKernelGGL(lia_pack10_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
+    if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(lia_pack10_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
   } else if (format == 11) {
     size_t nblk = n_values / 1024;
     unsigned blocks = (unsigned)((nblk + 3) / 4);
     if (blocks > 8192) blocks = 8192;
     if (blocks == 0) return;
+    if (ev0) (void)hipEventRecord(ev0, st);
     hipLaunchKernelGGL(lia_pack11_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
+    if (ev1) (void)hipEventRecord(ev1, st);
     hipLaunchKernelGGL(lia_pack11_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
   } else {
+    if (ev0) (void)hipEventRecord(ev0, st);
     lia_pack12_decode_launch(src, dst, n_values, st);
+    if (ev1) (void)hipEventRecord(ev1, st);
   }
 }

@@ -128,6 +128,8 @@ SIGNATURES = {
     "lia_stream_release": (c_int, [c_void_p, c_int, c_void_p]),
     "lia_stream_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double), c_int]),
     "lia_stream_poll_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
+    "lia_stream_decode_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(c_double), ctypes.POINTER(c_double),
+                                        ctypes.POINTER(c_double), c_int]),
     "lia_stream_copy_stream": (c_void_p, [c_void_p]),
     "numa_alloc_node": (c_void_p, [c_size_t, c_int]),
     "numa_alloc_interleave": (c_void_p, [c_size_t]),

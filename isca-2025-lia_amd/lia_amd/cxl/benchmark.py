@@ -1,96 +1,134 @@
-"""Host-tier H2D bandwidth microbenchmark: twin of lia/cxl/benchmark.py (:9-128) + run.sh.
+"""Host-tier H2D bandwidth microbenchmark: the measurement of lia/cxl/benchmark.py (:9-128) + run.sh, taken on the path the
+scheduler itself uses -- the C ABI's weight streamer (lia_stream_prefetch: pinned hipMemcpyAsync on the copy stream into an HBM
+slot) -- instead of the reference's `Tensor.copy_(non_blocking=True)`.
 
     python -m lia_amd.cxl.benchmark --gpu [--cpu] [--cxl] [--register] [--nodes 1]
 
---gpu : time `number` x 4 GiB host->HBM copies (2048 x 2048 x 1024 int8, benchmark.py:16-18), DDR-pinned or, with
-        --cxl, from the NUMA-interleaved tier (numa_alloc_tensor); --register additionally hipHostRegisters the
-        NUMA range (what the scheduler's --enable-cxl path does; the reference cannot).
---cpu : concurrently run 8192^3 fp32 CPU GEMMs (benchmark.py:46-63) to show the interference.
-Prints the reference's two lines: "[t s] Average Transfer Bandwidth: x GB/s" / "[t s] Average Compute Time: y seconds".
+--gpu : `number` = 3 copies of a 4 GiB host buffer (2048 x 2048 x 1024 int8, benchmark.py:16-18) per timed repeat, 3 repeats
+        after 2 warm-up rounds; the source is DDR-pinned (lia_host_alloc_pinned) or, with --cxl, the NUMA-interleaved tier
+        (numa_alloc_tensor); --register hipHostRegisters that range (what --enable-cxl does in the scheduler; the reference
+        leaves it pageable, numa_alloc.py:49, so its copies are staged -- here an unregistered source goes through the
+        streamer's pinned bounce buffer, the same staging).
+--cpu : 8192^3 fp32 GEMMs on the host cores at the same time (benchmark.py:46-63), to show the interference.
+Prints the reference's two lines: "[t s] Average Transfer Bandwidth: x GB/s" / "[t s] Average Compute Time: y seconds", and
+returns {"transfer_gbs", "copy_engine_gbs", "compute_s"} (copy_engine_gbs: bytes / the copy stream's own busy time, lia_stream_stats).
 """
 import argparse
+import ctypes
+import threading
 import time
-from queue import Queue
-from threading import Thread
 
-import numpy as np
 import torch
 
+from .. import _native as N
+from ..ops import Context
 from .numa_alloc import numa_alloc_tensor, numa_free_tensor, set_cxl_nodes
+
+NUMBER, REPEAT, WARMUP = 3, 3, 2          # benchmark.py:10-12
+CHUNK = 1 << 30                           # the 4 GiB buffer crosses the link in four 1 GiB slot-sized copies
+
+
+class _Transfer:
+    """the host buffer of one tier + a two-slot streamer; run() = REPEAT timed groups of NUMBER whole-buffer transfers"""
+
+    def __init__(self, from_cxl, register, nbytes):
+        self.lib, self.nbytes, self.numa = N.lib(), nbytes, None
+        if from_cxl:
+            self.numa = numa_alloc_tensor((nbytes,), torch.int8, register=register)
+            if self.numa is None:
+                raise MemoryError("Failed to allocate NUMA memory.")
+            self.numa.fill_(1)
+            self.ptr, self.pinned = self.numa.data_ptr(), bool(register)
+        else:
+            self.ptr, self.pinned = self.lib.lia_host_alloc_pinned(nbytes), True
+            if not self.ptr:
+                raise MemoryError(N.lib().lia_last_error().decode(errors="replace"))
+            ctypes.memset(self.ptr, 1, nbytes)
+        self.ctx = Context(0, 0)
+        self.chunk = min(CHUNK, nbytes)
+        self.h = ctypes.c_void_p()
+        N.check(self.lib.lia_stream_create(self.ctx.handle, 2, self.chunk, ctypes.byref(self.h)), "lia_stream_create")
+        self.costs, self.total, self.busy = [], 0.0, (0.0, 0.0)
+
+    def _whole_buffer(self, slot):
+        for off in range(0, self.nbytes, self.chunk):
+            n = min(self.chunk, self.nbytes - off)
+            N.check(self.lib.lia_stream_prefetch(self.h, slot, ctypes.c_void_p(self.ptr + off), n, int(self.pinned)), "lia_stream_prefetch")
+            N.check(self.lib.lia_stream_wait(self.h, slot, ctypes.c_void_p(self.ctx.stream)), "lia_stream_wait")
+            N.check(self.lib.lia_stream_release(self.h, slot, ctypes.c_void_p(self.ctx.stream)), "lia_stream_release")
+            slot ^= 1
+        return slot
+
+    def run(self):
+        b, ms = ctypes.c_double(), ctypes.c_double()
+        self.lib.lia_stream_stats(self.h, ctypes.byref(b), ctypes.byref(ms), 1)
+        self.costs, t_all, slot = [], time.time(), 0
+        for _ in range(REPEAT):
+            self.ctx.synchronize()
+            t0 = time.time()
+            for _ in range(NUMBER):
+                slot = self._whole_buffer(slot)
+            self.ctx.synchronize()
+            self.costs.append(time.time() - t0)
+        self.total = time.time() - t_all
+        self.lib.lia_stream_stats(self.h, ctypes.byref(b), ctypes.byref(ms), 1)
+        self.busy = (b.value, ms.value)
+
+    def close(self):
+        self.lib.lia_stream_destroy(self.h)
+        self.ctx.close()
+        if self.numa is not None:
+            numa_free_tensor(self.numa)
+        else:
+            self.lib.lia_host_free_pinned(ctypes.c_void_p(self.ptr))
+
+
+class _Compute:
+    def __init__(self, mm):
+        self.a, self.b = torch.ones(mm, mm), torch.ones(mm, mm)
+        self.costs, self.total = [], 0.0
+
+    def run(self):
+        self.costs, t_all = [], time.time()
+        for _ in range(REPEAT):
+            t0 = time.time()
+            for _ in range(NUMBER):
+                torch.mm(self.a, self.b)
+            self.costs.append(time.time() - t0)
+        self.total = time.time() - t_all
+
+    def close(self):
+        pass
 
 
 def benchmark(is_compute, is_transfer, from_cxl, register=False, size_scale=1.0, mm=8192, out=print):
-    number, repeat, warmup = 3, 3, 2
-    res = {}
-    if is_transfer:
-        b0, s0, h0 = int(2048 * size_scale), 2048, 1024
-        dtype = torch.int8
-        size = b0 * s0 * h0 * number / (1024 ** 3)
-        if from_cxl:
-            t_cpu = numa_alloc_tensor((b0, s0, h0), dtype, register=register)
-            if t_cpu is None:
-                out("Failed to allocate NUMA memory.")
-                return res
-            t_cpu.fill_(1)
-        else:
-            t_cpu = torch.ones((b0, s0, h0), dtype=dtype, pin_memory=True, device="cpu")
-        t_gpu = torch.ones((b0, s0, h0), dtype=dtype, device="cuda:0")
-
-        def memcpy(queue):
-            costs = []
-            total = time.time()
-            for _ in range(repeat):
-                torch.cuda.synchronize()
-                st = time.time()
-                for _ in range(number):
-                    t_gpu.copy_(t_cpu, non_blocking=True)
-                torch.cuda.synchronize()
-                costs.append(time.time() - st)
-            queue.put(costs)
-            queue.put(time.time() - total)
-
-    if is_compute:
-        mat1 = torch.ones(mm, mm, dtype=torch.float32)
-        mat2 = torch.ones(mm, mm, dtype=torch.float32)
-
-        def compute(queue):
-            costs = []
-            total = time.time()
-            for _ in range(repeat):
-                st = time.time()
-                for _ in range(number):
-                    _ = torch.mm(mat1, mat2)
-                costs.append(time.time() - st)
-            queue.put(costs)
-            queue.put(time.time() - total)
-
-    def one_round():
-        qs, ths = {}, []
+    res, workers = {}, {}
+    nbytes = int(2048 * size_scale) * 2048 * 1024
+    try:
         if is_transfer:
-            qs["t"] = Queue()
-            ths.append(Thread(target=memcpy, args=(qs["t"],)))
-        if is_compute:
-            qs["c"] = Queue()
-            ths.append(Thread(target=compute, args=(qs["c"],)))
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        return qs
-
-    for _ in range(warmup):
-        one_round()
-    qs = one_round()
-    if is_transfer:
-        times, total = qs["t"].get(), qs["t"].get()
-        res["transfer_gbs"] = size / float(np.mean(times))
-        out(f"[{total:.3f} s] Average Transfer Bandwidth: {res['transfer_gbs']:.3f} GB/s")
+            workers["transfer"] = _Transfer(from_cxl, register, nbytes)
+    except MemoryError as e:
+        out(str(e))
+        return res
     if is_compute:
-        times, total = qs["c"].get(), qs["c"].get()
-        res["compute_s"] = float(np.mean(times))
-        out(f"[{total:.3f} s] Average Compute Time: {res['compute_s']:.3f} seconds")
-    if is_transfer and from_cxl:
-        numa_free_tensor(t_cpu)
+        workers["compute"] = _Compute(mm)
+    for rnd in range(WARMUP + 1):                                     # the last round is the one reported
+        threads = [threading.Thread(target=w.run) for w in workers.values()]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if is_transfer:
+        w = workers["transfer"]
+        res["transfer_gbs"] = nbytes * NUMBER / 2 ** 30 / (sum(w.costs) / len(w.costs))
+        res["copy_engine_gbs"] = w.busy[0] / max(w.busy[1], 1e-9) / 1e6
+        out(f"[{w.total:.3f} s] Average Transfer Bandwidth: {res['transfer_gbs']:.3f} GB/s")
+    if is_compute:
+        w = workers["compute"]
+        res["compute_s"] = sum(w.costs) / len(w.costs)
+        out(f"[{w.total:.3f} s] Average Compute Time: {res['compute_s']:.3f} seconds")
+    for w in workers.values():
+        w.close()
     return res
 
 

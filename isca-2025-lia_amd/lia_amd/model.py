@@ -61,7 +61,7 @@ def resolve_shape(name):
 
 
 def _drawer(init, g):
-    def draw(*size):
+    def draw(*size):          # ("trained-like": embeddings and every tensor draw_layer does not special-case are N(0, 0.02))
         if init == "uniform01":
             return torch.rand(*size, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
         return (0.02 * torch.randn(*size, generator=g, device="cuda", dtype=torch.float32)).to(torch.bfloat16)
@@ -80,6 +80,24 @@ def draw_head(shape, seed=0, init="normal"):
     return tok, pos, torch.ones(H, dtype=torch.bfloat16, device="cuda"), torch.zeros(H, dtype=torch.bfloat16, device="cuda")
 
 
+# init="trained-like" (r05, build-defined stress of the wire format; no checkpoint is available offline): what a trained OPT
+# layer looks like to an exponent coder and a N(0, 0.02) draw does not -- every tensor has its own scale (spread over ~3 binades,
+# fc2 / out-proj smaller than q / k / v, a per-layer drift), 0.1 % of a weight matrix's input channels are outlier columns at 20
+# sigma (the "massive activation" channels of trained OPT models), LayerNorm gains sit near 1 with a few large ones, biases and
+# LayerNorm offsets are small but not zero.
+_TRAINED_SCALE = {"q_w": 1.6, "k_w": 1.6, "v_w": 0.9, "out_w": 0.7, "fc1_w": 1.0, "fc2_w": 0.45}
+
+
+def _draw_trained_like(n, r, c, g, li, layers):
+    sigma = 0.02 * _TRAINED_SCALE[n] * (2.0 ** (-1.5 * li / max(1, layers - 1))) * (0.75 + 0.5 * float(torch.rand(1, generator=g, device="cuda")))
+    w = sigma * torch.randn(r, c, generator=g, device="cuda", dtype=torch.float32)
+    n_out = max(1, int(round(0.001 * c)))
+    cols = torch.randperm(c, generator=g, device="cuda")[:n_out]
+    w[:, cols] = 20.0 * sigma * torch.randn(r, n_out, generator=g, device="cuda", dtype=torch.float32).sign() * \
+        (0.8 + 0.4 * torch.rand(r, n_out, generator=g, device="cuda"))
+    return w.to(torch.bfloat16)
+
+
 def draw_layer(shape, offsets, layer_bytes, li, seed=0, init="normal"):
     """Layer li of a seeded random model as the packed flat buffer (CUDA bf16): every layer has its own seed, so any subset of
     layers -- one at a time in the checkpoint writer, the resident prefix on a data-parallel peer -- draws the same values."""
@@ -93,10 +111,19 @@ def draw_layer(shape, offsets, layer_bytes, li, seed=0, init="normal"):
         o = offsets[i] // 2
         if n in shapes:
             r, c = shapes[n]
-            flat[o:o + r * c] = draw(r, c).reshape(-1)
+            flat[o:o + r * c] = (_draw_trained_like(n, r, c, g, li, shape.layers) if init == "trained-like" else draw(r, c)).reshape(-1)
         elif init == "uniform01":
             k = F if n == "fc1_b" else H
             flat[o:o + k] = draw(k)
+        elif init == "trained-like":
+            k = F if n == "fc1_b" else H
+            if n in ("ln1_w", "ln2_w"):
+                gam = 1.0 + 0.15 * torch.randn(k, generator=g, device="cuda")
+                big = torch.randperm(k, generator=g, device="cuda")[:max(1, k // 512)]
+                gam[big] = 4.0 + 4.0 * torch.rand(big.numel(), generator=g, device="cuda")
+                flat[o:o + k] = gam.to(torch.bfloat16)
+            else:
+                flat[o:o + k] = (0.05 * torch.randn(k, generator=g, device="cuda")).to(torch.bfloat16)
         elif n in ("ln1_w", "ln2_w"):
             flat[o:o + H] = 1.0
     return flat

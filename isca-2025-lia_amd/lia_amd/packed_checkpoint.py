@@ -146,7 +146,7 @@ def main(argv=None):
     ap.add_argument("--model", type=str, default="opt-66b")
     ap.add_argument("--save_dir", type=str, required=True)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--init", default="uniform01", choices=["uniform01", "normal"])
+    ap.add_argument("--init", default="uniform01", choices=["uniform01", "normal", "trained-like"])
     ap.add_argument("--wire", default="pack10", choices=["raw", "pack10", "pack11", "pack12"])
     a = ap.parse_args(argv)
     shape = resolve_shape(a.model)

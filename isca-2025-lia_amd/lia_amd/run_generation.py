@@ -61,7 +61,7 @@ def build_parser():
                         "-1 = chosen online from the measured decode steps (scheduler.CoopController), seeded by the planner")
     p.add_argument("--cpu-layers-start", default=None, type=int, help=argparse.SUPPRESS)
     p.add_argument("--seed", default=0, type=int)
-    p.add_argument("--init", default="normal", choices=["normal", "uniform01"],
+    p.add_argument("--init", default="normal", choices=["normal", "uniform01", "trained-like"],
                    help="uniform01 = the reference's dummy-weight recipe (utils/opt-weight-gen.py:61-62)")
     return p
 

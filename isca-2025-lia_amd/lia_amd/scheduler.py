@@ -192,6 +192,12 @@ class WeightPipeline:
                 return True
         return False
 
+    def decode_stats(self, reset=False):
+        """wire-format decode kernel since the last reset: {"launches", "ms", "bytes_in", "bytes_out"} (lia_stream_decode_stats)"""
+        n, ms, bi, bo = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        N.check(self.lib.lia_stream_decode_stats(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(bi), ctypes.byref(bo), int(reset)))
+        return {"launches": n.value, "ms": ms.value, "bytes_in": bi.value, "bytes_out": bo.value}
+
     def poll_stats(self):
         """(bytes, busy ms) of the copies that have COMPLETED so far -- never blocks (stats() waits for the queued copies)"""
         b, ms = ctypes.c_double(), ctypes.c_double()
@@ -352,21 +358,23 @@ class KVState:
 
 
 class CoopStore:
-    """The converged host-layer count of a (model, batch, placement, wire format, host team) configuration, kept in a small JSON file
-    next to the box calibration (LIA_STATE_DIR, default ~/.cache/lia_amd): the next process starts its search ON that count with
-    +-1 probes (a handful of decode steps to `converged`) instead of at the planner's estimate with stride 3.  Best effort: an
-    unreadable / unwritable file only means the search starts from the planner's seed."""
+    """The converged host-layer count of a (model, batch, prompt bucket, new tokens, placement, host tier, wire format, host team)
+    configuration, kept in a small JSON file -- ONLY where the user named a place for it (LIA_STATE_DIR; r04 wrote to
+    ~/.cache/lia_amd unasked, so a benchmark's cooperative legs depended on whatever ran on the box before, and GPU tests wrote into
+    the user's home: ADVICE r04).  The next process with the same key starts its search ON that count -- one stride-3 probe on the
+    side the link points to, then +-1 -- instead of at the planner's estimate.  Best effort: without LIA_STATE_DIR, or with an
+    unreadable / unwritable file, the search starts from the planner's seed and nothing is written."""
 
     FILE = "coop_counts.json"
 
     @staticmethod
     def path():
-        d = os.environ.get("LIA_STATE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "lia_amd")
-        return os.path.join(d, CoopStore.FILE)
+        d = os.environ.get("LIA_STATE_DIR")
+        return os.path.join(d, CoopStore.FILE) if d else None
 
     @staticmethod
     def load(key):
-        if key is None:
+        if key is None or CoopStore.path() is None:
             return None
         try:
             import json
@@ -378,22 +386,25 @@ class CoopStore:
 
     @staticmethod
     def save(key, count, ms):
-        if key is None or ms is None:
+        if key is None or ms is None or CoopStore.path() is None:
             return False
         try:
+            import fcntl
             import json
             p = CoopStore.path()
             os.makedirs(os.path.dirname(p), exist_ok=True)
-            try:
-                with open(p) as f:
-                    all_ = json.load(f)
-            except (OSError, ValueError):
-                all_ = {}
-            all_[key] = {"count": int(count), "ms": round(float(ms), 3)}
-            tmp = f"{p}.{os.getpid()}.tmp"
-            with open(tmp, "w") as f:
-                json.dump(all_, f, indent=1, sort_keys=True)
-            os.replace(tmp, p)                    # whole-file swap: a reader never sees half a file
+            with open(p + ".lock", "w") as lk:        # read-modify-write under an exclusive lock: two processes keep each other's entries
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                try:
+                    with open(p) as f:
+                        all_ = json.load(f)
+                except (OSError, ValueError):
+                    all_ = {}
+                all_[key] = {"count": int(count), "ms": round(float(ms), 3)}
+                tmp = f"{p}.{os.getpid()}.tmp"
+                with open(tmp, "w") as f:
+                    json.dump(all_, f, indent=1, sort_keys=True)
+                os.replace(tmp, p)                    # whole-file swap: a reader never sees half a file
             return True
         except OSError:
             return False
@@ -918,15 +929,22 @@ class OffloadScheduler:
             order = self.cpu_layer_order(n_gpu, L)
             sh = self.model.shape
             from . import hostinfo
-            store_key = "|".join(str(v) for v in (sh.name, sh.hidden, sh.ffn, L, n_gpu, B, decoding_policy, self.pack12,
-                                                  self.host_threads or hostinfo.default_host_threads(1)))
+            # everything that moves the optimum is in the key: the prompt length in buckets of a power of two (the host attention and
+            # the caches' size scale with it), the new tokens, which tier the streamed layers live in
+            tiers = sorted({st.tier for st in getattr(self.model, "layers", [])[n_gpu:] if getattr(st, "tier", None) not in ("device", None)}) or ["-"]
+            t_bucket = 1 << max(0, int(T) - 1).bit_length()
+            store_key = "|".join(str(v) for v in (sh.name, sh.hidden, sh.ffn, L, n_gpu, B, f"T<={t_bucket}", f"new{max_new_tokens or 0}", decoding_policy,
+                                                  self.pack12, "+".join(tiers), self.host_threads or hostinfo.default_host_threads(1)))
             kept = CoopStore.load(store_key) if seeded_ok else None
             if kept is not None:
                 start = max(0, min(kept[0], len(order)))
             self._coop = CoopController(order, start, min(len(order), int(start) + COOP_HEADROOM))
             self._coop.store_key = store_key
-            if kept is not None:                 # a count this box converged on before: look one to each side, nothing further
-                self._coop.seeded, self._coop.bracketed, self._coop.stride_i = True, True, len(CoopController.STRIDES) - 1
+            if kept is not None:
+                # a count this box converged on before for exactly this configuration: the search starts ON it, but still opens with
+                # the stride-3 probe (one candidate, on the side the link points to) before the +-1 round -- a stored count that is
+                # wrong for today's box is left in two moves, not walked away from one count at a time
+                self._coop.seeded = True
             self._coop_key = key
         return self._coop
 
@@ -1094,6 +1112,9 @@ class OffloadScheduler:
 
     def stream_stats(self, reset=False):
         return self.pipe.stats(reset) if self.pipe else (0.0, 0.0)
+
+    def decode_stats(self, reset=False):
+        return self.pipe.decode_stats(reset) if self.pipe else {"launches": 0, "ms": 0.0, "bytes_in": 0.0, "bytes_out": 0.0}
 
     def close(self):
         if self.pipe:

@@ -19,3 +19,10 @@ def oracle():
     import lia_oracle
     lia_oracle.lib()
     return lia_oracle
+
+
+@pytest.fixture(autouse=True)
+def _no_state_outside_the_test(tmp_path, monkeypatch):
+    """the cooperative controller's converged counts (scheduler.CoopStore) and the box calibration go where LIA_STATE_DIR points:
+    every test gets its own empty directory, so no test depends on an earlier run and none writes into the user's home"""
+    monkeypatch.setenv("LIA_STATE_DIR", str(tmp_path / "lia_state"))

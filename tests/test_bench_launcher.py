@@ -28,7 +28,16 @@ def test_bench_flag_surface():
     sys.path.insert(0, ROOT)
     import bench
     a = bench.build_parser().parse_args([])
-    assert (a.gpus, a.steps, a.warmup, a.batch, a.prompt, a.gpu_percentage, a.prefill_policy, a.decoding_policy) == (1, 31, 0, 64, 256, 10, 0, 2)
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.prompt, a.gpu_percentage, a.prefill_policy, a.decoding_policy) == (1, 31, 0, 64, 256, 10, None, None)
+    from lia_amd.model import resolve_shape
+    shape = resolve_shape("opt-30b")
+    lb = 2 * (4 * shape.hidden ** 2 + 2 * shape.hidden * shape.ffn)
+    # one GPU: the reference's 0 / 2 (BASELINE configs[1]); N > 1: KV in HBM when it fits, the named policies always win
+    assert bench.plan_policies(a, 1, shape, 64, 256, 32, lb, 288 << 30, 4)[:2] == (0, 2)
+    assert bench.plan_policies(a, 8, shape, 32, 256, 32, lb, 288 << 30, 4)[:2] == (3, 3)
+    assert bench.plan_policies(a, 8, shape, 32, 256, 32, lb, 16 << 30, 4)[:2] == (0, 2)           # a 16 GiB device: no room
+    named = bench.build_parser().parse_args(["--prefill-policy", "0", "--decoding-policy", "2"])
+    assert bench.plan_policies(named, 8, shape, 32, 256, 32, lb, 288 << 30, 4)[:2] == (0, 2)
     assert 1 + a.warmup + a.steps == 32                      # the config's "out 32" by default
     a = bench.build_parser().parse_args(["--gpus", "8", "--global-batch", "256", "--steps", "20", "--warmup", "5"])
     assert a.global_batch // a.gpus == 32                    # BASELINE config 5
@@ -57,8 +66,41 @@ def test_watchdog_names_the_leg_and_exits_non_zero(capsys):
     assert line["dp_extra_legs"] == {"timed_out": True, "leg_running": "allgather", "timeout_s": 420, "legs_finished": ["kv_in_hbm"], "exit_code": 3}
     assert line["value_kv_in_hbm"] == 123.0 and line["value"] == 1.0
     codes.clear()
-    bench.watchdog_fire(out, progress, 2, 420, _exit=codes.append)            # another rank: no line, same exit code
+    naps = []
+    bench.watchdog_fire(out, progress, 2, 420, _exit=codes.append, _sleep=naps.append)      # another rank: no line, same exit code ...
     assert codes == [3] and capsys.readouterr().out == ""
+    assert naps == [bench.WATCHDOG_GRACE_S] and bench.WATCHDOG_GRACE_S >= 1.0                # ... after a grace period: rank 0's line gets out first
+
+
+def test_dp_line_at_world_8_over_gloo():
+    """`python bench.py --gpus 8 --global-batch 256` as far as a box without GPUs can take it (r04 verdict item 6): the self-launch,
+    eight ranks over gloo, and everything the line says about the SPLIT of the job through the functions main() itself uses --
+    plan_rows (32 rows per rank), plan_policies (KV in HBM by default at N > 1), hostinfo.default_host_threads (this container's CPUs
+    over 8 ranks), reduce_over_ranks (MAX of the per-rank times, all-gather of the per-rank figures), dp_config_fields."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-dp-line", "--global-batch", "256", "--model", "opt-30b",
+                        "--steps", "5", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["dp_line_selftest"] is True and d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 256 and d["config"]["rows_per_rank"] == [32] * 8 and d["config"]["parallelism"].startswith("dp8 batch-shard")
+    assert d["config"]["policies"]["prefill"] == 3 and d["config"]["policies"]["decode"] == 3 and "HBM" in d["config"]["policies"]["why"]
+    assert [r["rank"] for r in d["per_rank"]] == list(range(8)) and all(r["rows"] == 32 for r in d["per_rank"])
+    from lia_amd import hostinfo
+    thr = hostinfo.default_host_threads(8)
+    assert all(r["host_attention_threads"] == thr and r["host_threads_starved"] == (thr < 4) for r in d["per_rank"])
+    assert [r["host_attention_ms_per_step"] for r in d["per_rank"]] == [1.5 * r for r in range(8)] and d["per_rank"][0]["h2d_gbs"] == 50.0
+    # MAX over ranks: the slowest rank (17 ms per step) sets the job's rate
+    assert abs(d["ms_per_step"] - 17.0) < 1e-9 and abs(d["value"] - 256 * 5 / (5 * 17e-3)) < 1e-6 and abs(d["prefill_ms"] - 107.0) < 1e-9
+    # a ragged split: 19 rows over 8 ranks
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-dp-line", "--global-batch", "19", "--model", "opt-125m",
+                        "--prefill-policy", "0", "--decoding-policy", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["config"]["rows_per_rank"] == [3, 3, 3, 2, 2, 2, 2, 2] and [r["rows"] for r in d["per_rank"]] == [3, 3, 3, 2, 2, 2, 2, 2]
+    assert d["config"]["policies"]["prefill"] == 0 and d["config"]["policies"]["decode"] == 2
 
 
 def test_bench_line_carries_its_scalars_inside_roofline_and_config():

@@ -343,6 +343,8 @@ def test_coop_store_seeds_the_next_process(tmp_path, monkeypatch):
     it with +-1 probes: converged within a handful of steps"""
     from types import SimpleNamespace
     from lia_amd.scheduler import CoopController, CoopStore, OffloadScheduler
+    monkeypatch.delenv("LIA_STATE_DIR", raising=False)
+    assert CoopStore.path() is None and CoopStore.save("k", 1, 1.0) is False and CoopStore.load("k") is None    # nothing is kept unasked
     monkeypatch.setenv("LIA_STATE_DIR", str(tmp_path))
     assert CoopStore.load("k") is None and CoopStore.save(None, 3, 1.0) is False
     assert CoopStore.save("k", 18, 401.234) and CoopStore.load("k") == (18, 401.234)
@@ -374,13 +376,39 @@ def test_coop_store_seeds_the_next_process(tmp_path, monkeypatch):
         t, link = box(ctl2.c)
         ctl2.observe(t, min(1.0, link / t))
         n2 += 1
-    assert ctl2.centre == 18 and n2 <= 6 < n1 and set(seen) <= {17, 18, 19}, (n1, n2, seen)
+    # starts ON the stored count; one stride-3 probe (a stored count that no longer fits is left quickly), then +-1
+    assert ctl2.centre == 18 and n2 <= 12 and n2 < n1 and seen[0] == 18 and set(seen) <= {15, 17, 18, 19, 21}, (n1, n2, seen)
+    # ... and a stored count that is WRONG for today's box (the optimum moved to 24) is left in strides, not one count at a time
+    me._coop = None
+    CoopStore.save(ctl2.store_key, 12, 400.0)
+
+    def box24(c):
+        link, host = (44 - c) * 14.7, 20 + c * 12.0
+        return max(link, host), link
+
+    ctl5 = OffloadScheduler._coop_controller(me, 4, 48, 64, 1, 32, 10, 3, None)
+    assert ctl5.seeded and ctl5.c == 12
+    n5 = 0
+    while not ctl5.report()["converged"] and n5 < 80:
+        t, link = box24(ctl5.c)
+        ctl5.observe(t, min(1.0, link / t))
+        n5 += 1
+    best = min(range(0, ctl5.c_max + 1), key=lambda c: box24(c)[0])
+    assert abs(ctl5.centre - best) <= 1 and n5 <= 30, (ctl5.centre, best, n5)
+    CoopStore.save(ctl2.store_key, 18, 401.0)
     me._coop = None
     ctl3 = OffloadScheduler._coop_controller(me, 4, 48, 64, 1, 32, 10, 3, 9)   # an explicit start is taken as given
     assert ctl3.c == 9 and not ctl3.seeded
     me._coop = None
     ctl4 = OffloadScheduler._coop_controller(me, 4, 48, 32, 1, 32, 10, 3, None)  # another batch size: another key
     assert not ctl4.seeded and ctl4.c == 12
+    me._coop = None
+    ctl6 = OffloadScheduler._coop_controller(me, 4, 48, 64, 1024, 32, 10, 3, None)  # another prompt bucket: another key
+    assert not ctl6.seeded
+    me._coop = None
+    ctl7 = OffloadScheduler._coop_controller(me, 4, 48, 64, 1, 128, 10, 3, None)   # more new tokens: another key
+    assert not ctl7.seeded
+    assert len({c.store_key for c in (ctl, ctl4, ctl6, ctl7)}) == 4
 
 
 def test_bench_first_divergence_reports_step_and_gap():
