@@ -41,7 +41,7 @@ sys.path.insert(0, os.path.join(ROOT, "isca-2025-lia_amd"))
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
 PCIE_PEAK_GBS = 63.0       # PCIe Gen5 x16 spec
-WIRE = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}
+WIRE = {"raw": 0, "pack10": 10}
 
 
 def build_parser():
@@ -447,9 +447,9 @@ def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs,
             st.close()
         group.mode = "allgather"
         try:
-            m2 = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, host_owner=True, pack12=fmt,
+            m2 = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, host_owner=True, wire=fmt,
                                          shard=(rank, world))
-            m2._lia_scheduler = OffloadScheduler(m2, device=dev_index, dp_group=group, pack12=fmt)
+            m2._lia_scheduler = OffloadScheduler(m2, device=dev_index, dp_group=group, wire=fmt)
             m2._lia_scheduler.host_threads = host_threads
             leg("allgather", m2, gen_kwargs)
             # ... and both together: every rank's own link AND no host attention -- the configuration in which neither the root's
@@ -633,11 +633,11 @@ def main(argv=None):
         sched = LlamaScheduler(model, device=dev_index)
     else:
         model = LiaOPTModel.random_init(shape, seed=0, init=a.init, n_gpu_layers=n_gpu, pin_weight=True, enable_cxl=a.enable_cxl,
-                                        host_owner=(group is None or group.is_root or group.mode == "allgather"), pack12=fmt,
+                                        host_owner=(group is None or group.is_root or group.mode == "allgather"), wire=fmt,
                                         shard=((rank, world) if (group is not None and world > 1 and group.mode == "allgather") else None),
                                         raw_layers=(OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, a.cpu_layers)
                                                     if (a.cpu_layers > 0 and a.decoding_policy in (2, 3) and group is None) else ()))
-        sched = OffloadScheduler(model, device=dev_index, dp_group=group, pack12=fmt)
+        sched = OffloadScheduler(model, device=dev_index, dp_group=group, wire=fmt)
         sched.host_threads = host_threads
     model._lia_scheduler = sched                         # generate() drives this scheduler
     g = torch.Generator().manual_seed(0)
@@ -807,7 +807,7 @@ def main(argv=None):
     # ---- second leg: the same streamed layers as RAW bf16 (what the reference ships), same model object, re-tiered ----------
     ids_check = {}
     if rank == 0 and world == 1 and not is_llama and fmt and not a.no_raw_leg and n_gpu < shape.layers:
-        sched.pack12 = 0
+        sched.wire = 0
         t0 = time.time()
         ids_raw, lat_raw, logits_raw = generate(model, ids, max_steps=2 + a.raw_steps, return_logits=True, **gen_kwargs)
         out["value_raw_format"] = B / (sum(lat_raw[2:]) / len(lat_raw[2:]))
@@ -816,7 +816,7 @@ def main(argv=None):
                                  "note": "same model object re-placed from the packed wire format to raw bf16; first decode step untimed"}
         ids_check[f"{a.stream_format}_vs_raw_wire"] = first_divergence(out_ids, ids_raw, T, logits_raw)
         del logits_raw
-        sched.pack12 = fmt
+        sched.wire = fmt
 
     # ---- the prefill with the reference's K/V semantics: store_cache beside the prefill (modeling_opt.py:334-345), not deferred -----
     if rank == 0 and world == 1 and not is_llama and not a.no_defer_kv_leg and n_gpu < shape.layers and a.prefill_policy == 0 \
@@ -846,7 +846,7 @@ def main(argv=None):
             t0, thr_a = time.time(), hostinfo.cgroup_cpu_throttle()
             c0, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
                                             planner.Box(host_threads=host_threads,
-                                                        wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]))
+                                                        wire_ratio={"raw": 1.0, "pack10": 0.675}[a.stream_format]))
             # -1: the scheduler's online controller.  No explicit start: it begins on the count this box converged on last time
             # (scheduler.CoopStore, +-1 probes only) when there is one, else on the same plan as c0
             coop_kwargs = dict(gen_kwargs, cpu_layers=-1)
@@ -869,7 +869,7 @@ def main(argv=None):
                 t0, thr_a = time.time(), hostinfo.cgroup_cpu_throttle()
                 c3, _ = planner.plan_cpu_layers(shape, B, T, new, a.gpu_percentage,
                                                 planner.Box(host_threads=host_threads,
-                                                            wire_ratio={"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[a.stream_format]),
+                                                            wire_ratio={"raw": 1.0, "pack10": 0.675}[a.stream_format]),
                                                 kv_in_hbm=True)
                 kv_kwargs = dict(gen_kwargs, prefill_policy=3, decoding_policy=3, cpu_layers=-1)
                 ids_kv, lat_kv, logits_kv = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **kv_kwargs)

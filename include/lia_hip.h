@@ -204,45 +204,27 @@ int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, int T, int H,
 /* ---- decode step over a run of HBM-resident layers (build-defined fast path of the per-layer loop) ---------------------
  * The reference runs its resident layers one torch op at a time (lia/modeling_opt.py:1246-1260 -> decoder.py:172-335,
  * attentions.py:393-529: ~10 launches per layer).  These two entry points run n_layers CONSECUTIVE resident layers of one decode
- * step (T == 1, KV cache in HBM = policy 3 arithmetic) in ONE library call.  By default (lia_set_fused_decode(0)) that is the
- * per-op route -- lia_layer_forward(policy 3) / lia_llama_layer_forward layer by layer, every layer's closing norm chained into
- * the next -- which is the faster one as measured (results/r04_ab_*: 16.1 vs 16.9 ms per OPT-30B step, 7.7 vs 8.4 ms per
- * Llama-3-8B step).  With lia_set_fused_decode(1) / LIA_FUSED_DECODE=1 a layer is ONE attention launch and ONE persistent
- * "chain" launch (csrc/lia_chain.hip: out-proj, norm, MLP, the next layer's norm and q|k|v projection with their split-K
- * combines inside one kernel that keeps its weight stream running across the steps): same arithmetic and rounding points, bit
- * for bit (tests/test_gpu_chain.py); shapes or weight layouts the chain does not cover (rows > 128, q|k|v or gate|up not
- * adjacent) take the per-op route.
+ * step (T == 1, KV cache in HBM = policy 3 arithmetic) in ONE library call: lia_layer_forward(policy 3) /
+ * lia_llama_layer_forward layer by layer, every layer's closing norm chained into the next (lia_ctx_chain_next_norm), the
+ * hidden state alternating between y and a context-owned buffer so that x is never written.  (r04 also offered a persistent
+ * one-kernel-per-layer route behind a switch: bit-identical, measured 4-9 % slower per step, retired in r05 -- LABNOTES.md.)
  *   weights: n_layers x 16 (OPT) / n_layers x 9 (Llama) device pointers, layer-major;  kv: n_layers pointers to device caches
- *   x: [B, 1, H] input (never written);  y: [B, 1, H] result;  B <= cache batch, rows [0, B) of the caches are served
- * A grid barrier of a chain launch that cannot complete (bounded spins) makes the next lia_ctx_synchronize* fail with
- * LIA_ERR_HIP instead of handing garbage on. */
+ *   x: [B, 1, H] input (never written);  y: [B, 1, H] result;  B <= cache batch, rows [0, B) of the caches are served */
 int lia_decode_layers(lia_ctx* ctx, const lia_layer_desc* d, int n_layers, const void* const* weights, const lia_bf16* x,
                       lia_bf16* y, lia_kv* const* kv, int B, int pos0, void* stream);
 int lia_llama_decode_layers(lia_ctx* ctx, const lia_llama_desc* d, int n_layers, const void* const* weights, const lia_bf16* x,
                             lia_bf16* y, lia_kv* const* kv, const lia_bf16* cos_table, const lia_bf16* sin_table, int B, int pos0,
                             void* stream);
-/* A/B and test switches.  lia_set_fused_decode(1): the two entry points above take the persistent-chain route (also env
- * LIA_FUSED_DECODE=1; default 0).  lia_gemm_set_split_policy(1): the per-op decode GEMMs cut K exactly as the chain does for the same
- * shape, so that the two routes add the same products in the same order and agree bit for bit (0 = the per-launch
- * heuristics).  lia_chain_launch_count: chain launches since the library was loaded. */
-void lia_set_fused_decode(int on);
-void lia_gemm_set_split_policy(int policy);
-long lia_chain_launch_count(void);
-/* Which kernel runs the decode GEMMs of the per-op route (M <= 128): 0 (default) = lia_gemm_skinny2_kernel; 1 = the chain kernel as a one-step program, its slabs combined by the per-op combine kernels (measured 3-6 %
- * slower per decode step than skinny2 at the OPT-30B / Llama-3-8B shapes, results/r04_ab_*: kept as the A/B leg and for the
- * bit-identity tests).  Same bits under lia_gemm_set_split_policy(1).  lia_gemm_chain_engine_count: GEMMs the chain engine has
- * run since the library was loaded. */
-void lia_gemm_set_engine(int engine);
-long lia_gemm_chain_engine_count(void);
-/* Further A/B switches over implementations of the SAME arithmetic (bit-identical, tests/test_gpu_fused_combine.py):
- * fuse_combine(0): every post op of a split-K GEMM (norm, SiLU*up, RoPE) is a kernel of its own instead of riding the combine;
- * inlaunch_combine(1): the last-arriving K slice combines a tile's slabs inside the GEMM launch (measured slower at the decode
- * shapes); tiled_variant: 262 (default) phased prefill GEMM, 259-261 its other phase / LDS-DMA forms, 256-258 the r01 kernels.
- * lia_gemm_fused_combine_count(kind): fused combines launched per LIA_POST_* kind since the library was loaded. */
-void lia_gemm_set_fuse_combine(int on);
-void lia_gemm_set_inlaunch_combine(int on);
-void lia_gemm_set_tiled_variant(int variant);
-long lia_gemm_fused_combine_count(int kind);
+/* Per-context options and counters.  The library keeps no process-wide setting: two contexts of one process may differ.
+ *   LIA_OPT_FUSE_COMBINE (default 1): the split-K combine of a decode GEMM also runs the op behind it (LayerNorm / RMSNorm of the
+ *     finished row, SiLU(gate) * up, RoPE); 0: every such op is a kernel of its own -- the same device functions on the same
+ *     values, so the two routes agree bit for bit (tests/test_gpu_fused_combine.py).
+ *   lia_ctx_get_counter(ctx, LIA_CNT_FUSED_COMBINE + kind), kind = 1 LayerNorm, 2 RMSNorm, 3 SiLU*up, 4 RoPE: fused combines
+ *     launched through this context (tests assert the route was taken); -1 for an unknown key. */
+enum { LIA_OPT_FUSE_COMBINE = 1 };
+enum { LIA_CNT_FUSED_COMBINE = 100 };
+int lia_ctx_set_option(lia_ctx* ctx, int key, long value);
+long lia_ctx_get_counter(lia_ctx* ctx, int key);
 
 /* ---- host side of the cooperative policies -------------------------------------------------------
  * Indirect-access-KV masked MHA, csrc/cpu/aten/kernels/MaskedMultiHeadAttentionKrnl.cpp:513-842: fp32
@@ -271,9 +253,10 @@ int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, 
                     int N, int K, int relu, int n_threads);
 int lia_host_has_avx512_bf16(void);
 /* Per-thread scratch of the host kernels (fp32 C tiles of the linears, score rows of the attention) is refused above this many
- * bytes (0 = no limit, the default): the call that needed it returns LIA_ERR_MEMORY -- as it does when the allocation itself
- * fails in a worker thread -- instead of running the box out of memory. */
-void lia_host_set_scratch_limit(size_t bytes_per_thread);
+ * bytes (0 = no limit, the default) in lia_host_* calls made BY THE CALLING THREAD from now on: the call that needed it returns
+ * LIA_ERR_MEMORY -- as it does when the allocation itself fails in a worker thread -- instead of running the box out of memory.
+ * Thread-local, like lia_last_error: callers on other threads are not affected. */
+void lia_host_thread_scratch_limit(size_t bytes_per_thread);
 
 /* ---- weight streamer ------------------------------------------------------------------------------
  * Replaces load_layer / layer_copy under torch.cuda.stream(load_weight_stream) + device-wide syncs
@@ -291,25 +274,20 @@ int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t 
 int lia_stream_begin(lia_streamer* s, int slot);
 int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned);
 int lia_stream_mark_ready(lia_streamer* s, int slot);
-/* pack12: a lossless 12-bit wire format for the streamed bf16 layers (sign|mantissa byte + 4-bit exponent code, rare
- * values as escape records; lia_pack12.hip).  The host keeps / ships the encoded bytes (75 % of the raw layer), a kernel
- * on the copy stream rebuilds the exact bf16 layer in the slot.  Build-defined: the reference ships raw bf16. */
-size_t lia_pack12_bound(size_t n_values);
-int lia_pack12_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
-/* pack11: the denser sibling (3-bit primary exponent code in bit-planes + a 4-bit overflow stream located through a
- * per-1024-value offset table): 11.1 bits per value for N(0,sigma) weights.  n_values must be a multiple of 1024. */
-size_t lia_pack11_bound(size_t n_values);
-int lia_pack11_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
-/* pack10: three-level exponent code (2-bit level-1 planes for the three most frequent exponents, a compacted 2-bit
- * level 2 for the next three, pack12's 4-bit alphabet as level 3; two per-1024-value offset tables): 10.8 bits per value
- * for N(0,sigma) weights, against an exponent-entropy bound of 10.55.  n_values must be a multiple of 1024. */
+/* pack10: a lossless wire format for the streamed bf16 layers (lia_pack10.hip; build-defined: the reference ships raw bf16).  One
+ * byte sign|mantissa per value + a three-level exponent code (2-bit level-1 planes for the three most frequent exponents of a
+ * 65536-value region, a compacted 2-bit level 2 for the next three, a 4-bit level 3; two per-1024-value offset tables): 10.8 bits
+ * per value for N(0,sigma) weights, against an exponent-entropy bound of 10.55.  The host keeps / ships the encoded bytes, a kernel
+ * on a side stream rebuilds the exact bf16 layer in the slot.  n_values must be a multiple of 1024.  encode returns 0, or 1 when
+ * the layer does not fit the format and must travel raw. */
 size_t lia_pack10_bound(size_t n_values);
 int lia_pack10_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
 /* Rebuild the raw bf16 values of an encoded buffer (device -> device), asynchronous on `stream` (NULL = the default
  * stream): the kernels the streamer runs, exposed for re-tiering a layer that the host holds in a packed format
- * (model placement, lia/modeling_opt.py:229-268) and for the round-trip tests.  format: 10, 11 or 12. */
+ * (model placement, lia/modeling_opt.py:229-268) and for the round-trip tests.  format: 10 (the argument is kept so that a later
+ * format needs no new entry point). */
 int lia_pack_decode(const char* src_device, lia_bf16* dst_device, size_t n_values, int format, void* stream);
-/* format: 10, 11 or 12 */
+/* format: 10 */
 int lia_stream_prefetch_packed(lia_streamer* s, int slot, const void* host_ptr, size_t packed_bytes, size_t n_values, int format,
                                int pinned);
 int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned);

@@ -12,12 +12,11 @@
 
 #include "../../include/lia_hip.h"
 #include "lia_common.h"
-#include "lia_chain.h"
 
 // kernels' host launchers
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime,
+                               LiaGemmOpts* opts, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime,
                                const LiaPost* post, int* post_done);
 extern "C" void lia_layernorm_launch(const bf16_t* x, long ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, long ldy,
                                      long rows, int H, float eps, hipStream_t st);
@@ -84,7 +83,7 @@ struct lia_ctx {
   long prof_seen;
   long prof_host_attn_calls;
   double prof_host_attn_ms;
-  unsigned* gemm_tickets;    // 16384 zeroed split-K tile tickets (lia_gemm.hip: the in-launch combine re-arms them)
+  LiaGemmOpts gemm_opts;     // per-context switches / counters of the GEMM launcher (lia_ctx_set_option, lia_ctx_get_counter)
   std::vector<hipEvent_t>* deliver_events;   // lia_kv_deliver tickets (events on the d2h stream), recycled round-robin
   std::vector<char>* deliver_pending;
   hipEvent_t deliver_t0, deliver_t1;         // timing events on the d2h stream around one batch of deliveries (lia_kv_deliver_batch_ms)
@@ -101,17 +100,9 @@ struct lia_ctx {
   // on this context copies and decodes on it too, so every event handshake is trivially ordered.  Results must not change; if
   // they do, a cross-stream ordering is missing (the role torch.cuda.synchronize() plays at lia/modeling_opt.py:1339,1528).
   bool serialized;
-  // persistent decode chain (lia_chain.hip): barrier-counter blocks (one per launch, zeroed in bulk when the ring wraps), the
-  // host-mapped word a barrier that gave up sets, the CU count (= workgroups of a chain launch), a third hidden-state buffer
-  unsigned* chain_sync;
-  long chain_launches;
-  unsigned* chain_err_host;
-  int n_cu;
-  char* chain_tmp;
-  size_t chain_tmp_bytes;
-  unsigned long long* chain_gran;     // row statistics that cross workgroups inside a chain launch (tagged, never zeroed)
+  char* hidden_tmp;           // a third hidden-state buffer for lia_decode_layers (a layer never writes the buffer it reads)
+  size_t hidden_tmp_bytes;
 };
-#define LIA_CHAIN_SYNC_BLOCKS 256
 
 extern "C" int lia_ctx_chain_next_norm(lia_ctx* c, const lia_bf16* g, const lia_bf16* b) {
   if (!c || !g) return LIA_ERR_INVALID;
@@ -153,15 +144,7 @@ extern "C" int lia_ctx_create(int device, size_t workspace_bytes, lia_ctx** out)
   }
   c->ws_bytes = workspace_bytes;
   if (workspace_bytes) HIP_TRY(hipMalloc((void**)&c->ws, workspace_bytes));
-  HIP_TRY(hipMalloc((void**)&c->gemm_tickets, 16384 * sizeof(unsigned)));
-  HIP_TRY(hipMemset(c->gemm_tickets, 0, 16384 * sizeof(unsigned)));
-  HIP_TRY(hipMalloc((void**)&c->chain_sync, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES));
-  HIP_TRY(hipMemset(c->chain_sync, 0, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES));
-  HIP_TRY(hipMalloc((void**)&c->chain_gran, LIA_CHAIN_GRAN_BYTES));
-  HIP_TRY(hipMemset(c->chain_gran, 0, LIA_CHAIN_GRAN_BYTES));
-  HIP_TRY(hipHostMalloc((void**)&c->chain_err_host, 64, hipHostMallocMapped));
-  *c->chain_err_host = 0u;
-  c->n_cu = lia_chain_cu_count(device);
+  c->gemm_opts.fuse_combine = 1;
   *out = c;
   return LIA_OK;
 }
@@ -176,11 +159,7 @@ extern "C" void lia_ctx_destroy(lia_ctx* c) {
     (void)hipEventDestroy(c->slab_done[i]);
   }
   if (c->ws) (void)hipFree(c->ws);
-  if (c->gemm_tickets) (void)hipFree(c->gemm_tickets);
-  if (c->chain_sync) (void)hipFree(c->chain_sync);
-  if (c->chain_gran) (void)hipFree(c->chain_gran);
-  if (c->chain_err_host) (void)hipHostFree(c->chain_err_host);
-  if (c->chain_tmp) (void)hipFree(c->chain_tmp);
+  if (c->hidden_tmp) (void)hipFree(c->hidden_tmp);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->deliver_t0) { (void)hipEventDestroy(c->deliver_t0); (void)hipEventDestroy(c->deliver_t1); }
   if (c->deliver_events) {
@@ -208,28 +187,30 @@ static int ctx_wait(hipStream_t st) {
   return LIA_OK;
 }
 
-// a grid barrier of a persistent decode-chain launch gave up (lia_chain.hip: every spin is bounded): the step's results are
-// garbage -- fail loudly at the next synchronisation point instead of handing them on
-static int chain_check(lia_ctx* c) {
-  if (c->chain_err_host && *c->chain_err_host) {
-    lia_set_error("decode chain: grid barrier 0x%x timed out (a workgroup of the persistent launch was not resident?)", *c->chain_err_host);
-    *c->chain_err_host = 0u;
-    return LIA_ERR_HIP;
-  }
-  return LIA_OK;
-}
-
 extern "C" int lia_ctx_synchronize(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
   if (int rc = ctx_wait(c->compute)) return rc;
-  if (int rc = ctx_wait(c->d2h)) return rc;
-  return chain_check(c);
+  return ctx_wait(c->d2h);
 }
 
 extern "C" int lia_ctx_synchronize_compute(lia_ctx* c) {
   if (!c) return LIA_ERR_INVALID;
-  if (int rc = ctx_wait(c->compute)) return rc;
-  return chain_check(c);
+  return ctx_wait(c->compute);
+}
+
+// Per-context options and counters (r05: the A/B switches used to be process-wide setters -- lia_gemm_set_* -- although the
+// library promises that two contexts of one process are independent, include/lia_hip.h).
+extern "C" int lia_ctx_set_option(lia_ctx* c, int key, long value) {
+  if (!c) return LIA_ERR_INVALID;
+  switch (key) {
+    case LIA_OPT_FUSE_COMBINE: c->gemm_opts.fuse_combine = value ? 1 : 0; return LIA_OK;
+    default: lia_set_error("lia_ctx_set_option: unknown key %d", key); return LIA_ERR_INVALID;
+  }
+}
+extern "C" long lia_ctx_get_counter(lia_ctx* c, int key) {
+  if (!c) return -1;
+  if (key > LIA_CNT_FUSED_COMBINE && key <= LIA_CNT_FUSED_COMBINE + 4) return c->gemm_opts.fused_combines[key - LIA_CNT_FUSED_COMBINE];
+  return -1;
 }
 
 extern "C" int lia_ctx_set_host_threads(lia_ctx* c, int n) {
@@ -395,7 +376,7 @@ extern "C" int lia_layer_pack_offsets(const lia_layer_desc* d, size_t off[16], s
   put(14, H * F, true); put(15, H, true);
   put(0, H, true);      put(1, H, true);
   put(10, H, true);     put(11, H, true);
-  if (total) *total = align_up(p, 2048);   // 1024 bf16 values: the block size of the pack11 wire format
+  if (total) *total = align_up(p, 2048);   // 1024 bf16 values: the block size of the pack10 wire format
   return LIA_OK;
 }
 
@@ -468,7 +449,7 @@ static int gemm_checked(lia_ctx* ctx, const bf16_t* x, long ldx, const bf16_t* w
     e0 = (*ctx->prof_events)[2 * i];
     e1 = (*ctx->prof_events)[2 * i + 1];
   }
-  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, ctx ? ctx->gemm_tickets : nullptr, split, st, e0, e1, &regime, post, post_done);
+  int rc = lia_gemm_launch(x, ldx, w, (long)K, M, N, K, &ep, &om, ws, ws_bytes, ctx ? &ctx->gemm_opts : nullptr, split, st, e0, e1, &regime, post, post_done);
   if (timed && rc == 0 && regime != 0) {
     // algorithmic traffic of the op: the weight once, the activations in and out once
     double bytes = 2.0 * ((double)N * K + (double)M * K + (double)M * N);
@@ -1003,71 +984,20 @@ extern "C" int lia_llama_lm_head(lia_ctx* ctx, const lia_bf16* hidden, int B, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode step over a run of HBM-resident layers in one call: the per-op route layer by layer (default), or per layer ONE attention
-// launch and ONE persistent chain launch (lia_chain.hip)
+// decode step over a run of HBM-resident layers in one call, layer by layer through the per-op route, each layer's last combine
+// also computing the next layer's first norm (lia_ctx_chain_next_norm).  (r04 also had a persistent per-layer "chain" kernel
+// behind a switch here; bit-identical, measured 4-9 % slower per step -- a seam inside a launch costs what a kernel boundary
+// costs -- and retired in r05: LABNOTES.md, git history.)
 // ------------------------------------------------------------------------------------------------
-// Route switch: LIA_FUSED_DECODE=1 or lia_set_fused_decode(1) takes the persistent-chain route; the default (0) runs the same layers
-// through the per-layer entry points -- measured 4-9 % faster per step (r04, LABNOTES.md: a seam inside the launch costs what a
-// kernel boundary costs, and the per-op kernels need no 160 KB ring started cold)
-static int g_fused_decode = [] { const char* e = getenv("LIA_FUSED_DECODE"); return (e && !strcmp(e, "1")) ? 1 : 0; }();
-extern "C" void lia_set_fused_decode(int on) { g_fused_decode = on ? 1 : 0; }
-static long g_chain_launches = 0;      // chain launches since the library was loaded (tests assert the route was taken)
-extern "C" long lia_chain_launch_count(void) { return g_chain_launches; }
-
-static void ch_op_gemm(LiaChainOp& o, const LiaChainPlan& p, const bf16_t* x, long ldx, const bf16_t* W, int M, int N, int K, float* slab) {
-  memset(&o, 0, sizeof(o));
-  o.kind = LIA_CH_GEMM;
-  o.M = M; o.N = N; o.K = K;
-  o.x = x; o.ldx = ldx; o.W = W; o.ldw = K;
-  o.bn = p.bn; o.split = p.split; o.cps = p.cps; o.nchunks = K / 64;
-  o.n_items = ((N + p.bn - 1) / p.bn) * p.split;
-  o.direct = LIA_CH_DIRECT_NONE;
-  o.slab = slab; o.slices = p.split;
-}
-static void ch_op_reduce(LiaChainOp& o, int kind, const LiaChainOp& g, const LiaEpilogue& ep, const LiaOutMap& om, const LiaPost* post) {
-  memset(&o, 0, sizeof(o));
-  o.kind = kind;
-  o.M = g.M; o.N = g.N; o.K = g.K;
-  o.slab = g.slab; o.slices = g.slices;
-  o.ep = ep; o.om = om;
-  if (post) o.post = *post;
-}
-
-static int chain_submit(lia_ctx* ctx, const LiaChainProgram& prog, int M, int pos0, double w_bytes, double flops, hipStream_t st) {
-  const long n = ctx->chain_launches++;
-  const int blk = (int)(n % LIA_CHAIN_SYNC_BLOCKS);
-  if (n > 0 && blk == 0) HIP_TRY(hipMemsetAsync(ctx->chain_sync, 0, (size_t)LIA_CHAIN_SYNC_BLOCKS * LIA_CHAIN_SYNC_BYTES, st));   // every earlier launch is ahead of it on `st`
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = ctx->prof_on && ctx->prof_recs->size() < ctx->prof_cap && (ctx->prof_seen++ % ctx->prof_stride) == 0;
-  if (timed) {
-    const size_t i = ctx->prof_recs->size();
-    e0 = (*ctx->prof_events)[2 * i];
-    e1 = (*ctx->prof_events)[2 * i + 1];
-    HIP_TRY(hipEventRecord(e0, st));
-  }
-  if (lia_chain_launch(&prog, M, ctx->chain_sync + (size_t)blk * (LIA_CHAIN_SYNC_BYTES / 4), ctx->chain_err_host, pos0, ctx->n_cu, ctx->chain_gran,
-                       (unsigned)((n + 1) & 0x3ffffff), st)) {
-    lia_set_error("decode chain: launch refused (M=%d, %d steps)", M, prog.n_ops);
-    return LIA_ERR_INVALID;
-  }
-  if (timed) {
-    HIP_TRY(hipEventRecord(e1, st));
-    ctx->prof_recs->push_back({1, w_bytes, flops});
-  }
-  ++g_chain_launches;
-  HIP_TRY(hipGetLastError());
-  return LIA_OK;
-}
-
-static int chain_tmp_buffer(lia_ctx* ctx, size_t bytes, bf16_t** out) {
-  if (ctx->chain_tmp_bytes < bytes) {
+static int hidden_tmp_buffer(lia_ctx* ctx, size_t bytes, bf16_t** out) {
+  if (ctx->hidden_tmp_bytes < bytes) {
     HIP_TRY(hipStreamSynchronize(ctx->compute));
-    if (ctx->chain_tmp) (void)hipFree(ctx->chain_tmp);
-    ctx->chain_tmp = nullptr; ctx->chain_tmp_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&ctx->chain_tmp, bytes));
-    ctx->chain_tmp_bytes = bytes;
+    if (ctx->hidden_tmp) (void)hipFree(ctx->hidden_tmp);
+    ctx->hidden_tmp = nullptr; ctx->hidden_tmp_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&ctx->hidden_tmp, bytes));
+    ctx->hidden_tmp_bytes = bytes;
   }
-  *out = (bf16_t*)ctx->chain_tmp;
+  *out = (bf16_t*)ctx->hidden_tmp;
   return LIA_OK;
 }
 
@@ -1091,106 +1021,16 @@ extern "C" int lia_llama_decode_layers(lia_ctx* ctx, const lia_llama_desc* d, in
     for (int i = 0; i < 9; ++i)
       if (!weights[l * 9 + i]) { lia_set_error("lia_llama_decode_layers: weights[%d][%d] is NULL", l, i); return LIA_ERR_MISSING; }
   }
-  const int H = d->hidden, F = d->ffn, hd = H / d->heads, KD = d->kv_heads * hd, G = d->heads / d->kv_heads, M = B;
-  hipStream_t st = (hipStream_t)stream;
+  const int H = d->hidden, M = B;
   bf16_t* tmp = nullptr;
-  rc = chain_tmp_buffer(ctx, (size_t)M * H * 2, &tmp);
+  rc = hidden_tmp_buffer(ctx, (size_t)M * H * 2, &tmp);
   if (rc) return rc;
   const bf16_t* const* Wall = (const bf16_t* const*)weights;
 
-  // the fused route needs the packed layout of lia_llama_pack_offsets (q | k | v and gate | up adjacent, gate / up rows
-  // interleaved) and a geometry the chain kernels have; anything else runs layer by layer
-  bool fused = g_fused_decode && lia_chain_supported(M) == 0 && G + 2 <= LIA_OUT_SEGS && d->gu_block == LIA_GU_BLOCK && ctx->n_cu > 0;
-  for (int l = 0; fused && l < n_layers; ++l) {
-    const bf16_t* const* W = Wall + l * 9;
-    fused = W[2] == W[1] + (size_t)H * H && W[3] == W[2] + (size_t)KD * H && W[7] == W[6] + (size_t)F * H;
-  }
-  LiaChainPlan p_qkv, p_o, p_gu, p_down;
-  if (fused)
-    fused = !lia_chain_plan_gemm(M, H + 2 * KD, H, 0, ctx->n_cu, &p_qkv) && !lia_chain_plan_gemm(M, H, H, 0, ctx->n_cu, &p_o) &&
-            !lia_chain_plan_gemm(M, 2 * F, H, 1, ctx->n_cu, &p_gu) && !lia_chain_plan_gemm(M, H, F, 0, ctx->n_cu, &p_down);
-  if (!fused) {
-    for (int l = 0; l < n_layers; ++l) {
-      if (l + 1 < n_layers) lia_ctx_chain_next_norm(ctx, Wall[(l + 1) * 9], nullptr);
-      rc = llama_layer_forward_impl(ctx, d, (const void* const*)(Wall + l * 9), hidden_of(l, n_layers, x, y, tmp), hidden_of(l + 1, n_layers, x, y, tmp), kv[l],
-                                    cos_table, sin_table, B, 1, pos0, 0, stream, 0);
-      if (rc) return rc;
-    }
-    return LIA_OK;
-  }
-
-  const LlamaWs w = llama_ws(d, M);
-  if (w.total > ctx->ws_bytes) { lia_set_error("lia_llama_decode_layers: workspace %zu < %zu", ctx->ws_bytes, w.total); return LIA_ERR_MEMORY; }
-  char* ws = ctx->ws;
-  bf16_t *ln = (bf16_t*)(ws + w.ln), *qb = (bf16_t*)(ws + w.q), *ao = (bf16_t*)(ws + w.attn), *h1 = (bf16_t*)(ws + w.h1), *act = (bf16_t*)(ws + w.act);
-  float* slab = (float*)(ws + w.gemm);
-  ctx->normed_src = nullptr; ctx->chain_armed = false;
-  const LiaEpilogue none{nullptr, nullptr, 0, 0, 0};
-  const int NQ = H + 2 * KD;
-
-  auto qkv_steps = [&](LiaChainProgram& P, const bf16_t* const* W, lia_kv* c) {
-    // q | k | v projection of the layer with weights W from `ln`, RoPE on the q and k heads, k / v rows into the cache
-    LiaChainOp& g = P.op[P.n_ops++];
-    ch_op_gemm(g, p_qkv, ln, H, W[1], M, NQ, H, slab);
-    LiaOutMap om;
-    memset(&om, 0, sizeof(om));
-    for (int j = 0; j < G; ++j) { om.base[j] = qb + (size_t)j * KD; om.ld[j] = H; }
-    om.base[G] = c->k; om.base[G + 1] = c->v; om.ld[G] = om.ld[G + 1] = KD; om.cache_mode[G] = om.cache_mode[G + 1] = 1;
-    om.seg_n = KD; om.T = 1; om.Bc = c->batch; om.b0 = 0; om.pos0 = pos0;
-    LiaPost post{};
-    post.kind = LIA_POST_ROPE; post.cos_t = cos_table; post.sin_t = sin_table; post.rot_heads = d->heads + d->kv_heads; post.hd = hd;
-    post.pos0 = pos0; post.T = 1;
-    LiaChainOp& r = P.op[P.n_ops++];
-    ch_op_reduce(r, LIA_CH_REDUCE_MAP, g, none, om, &post);
-    r.use_pos0 = 1;
-  };
-  const double wb_qkv = 2.0 * NQ * H, wb_layer = 2.0 * ((double)H * H + 2.0 * F * H + (double)H * F);
-
-  // layer 0's input norm and q | k | v projection
-  lia_rmsnorm_launch(x, H, Wall[0], ln, H, M, H, d->rms_eps, st);
-  {
-    LiaChainProgram P;
-    memset(&P, 0, sizeof(P));
-    qkv_steps(P, Wall, kv[0]);
-    rc = chain_submit(ctx, P, M, pos0, wb_qkv, 2.0 * M * NQ * H, st);
-    if (rc) return rc;
-  }
   for (int l = 0; l < n_layers; ++l) {
-    const bf16_t* const* W = Wall + l * 9;
-    const bf16_t* hin = hidden_of(l, n_layers, x, y, tmp);
-    bf16_t* hout = hidden_of(l + 1, n_layers, x, y, tmp);
-    if (lia_attn_decode_launch(qb, H, kv[l]->k, kv[l]->v, ao, H, B, pos0 + 1, d->heads, d->kv_heads, hd, kv[l]->batch, 0, 1, st)) {
-      lia_set_error("llama attention: unsupported head_dim %d / S %d", hd, pos0 + 1);
-      return LIA_ERR_INVALID;
-    }
-    LiaChainProgram P;
-    memset(&P, 0, sizeof(P));
-    {  // o_proj + residual -> h1, post-attention RMSNorm -> ln
-      LiaChainOp& g = P.op[P.n_ops++];
-      ch_op_gemm(g, p_o, ao, H, W[4], M, H, H, slab);
-      LiaEpilogue ep{nullptr, hin, H, 0, 0};
-      LiaPost post{};
-      post.kind = LIA_POST_RMSNORM; post.g = W[5]; post.eps = d->rms_eps; post.out = ln; post.ldo = H;
-      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(h1, H, H), &post);
-    }
-    {  // gate | up in one slice, act = silu(gate) * up written by the tile's epilogue
-      LiaChainOp& g = P.op[P.n_ops++];
-      ch_op_gemm(g, p_gu, ln, H, W[6], M, 2 * F, H, nullptr);
-      g.direct = LIA_CH_DIRECT_GLU;
-      g.ep = none; g.ep.glu = 1;
-      g.om = plain_out(act, F, F);
-    }
-    {  // down_proj + residual -> the layer's output, and the NEXT layer's input RMSNorm -> ln
-      LiaChainOp& g = P.op[P.n_ops++];
-      ch_op_gemm(g, p_down, act, F, W[8], M, H, F, slab);
-      LiaEpilogue ep{nullptr, h1, H, 0, 0};
-      LiaPost post{};
-      if (l + 1 < n_layers) { post.kind = LIA_POST_RMSNORM; post.g = Wall[(l + 1) * 9]; post.eps = d->rms_eps; post.out = ln; post.ldo = H; }
-      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(hout, H, H), &post);
-    }
-    double wb = wb_layer, fl = 2.0 * M * ((double)H * H + 2.0 * F * H + (double)H * F);
-    if (l + 1 < n_layers) { qkv_steps(P, Wall + (l + 1) * 9, kv[l + 1]); wb += wb_qkv; fl += 2.0 * M * NQ * H; }
-    rc = chain_submit(ctx, P, M, pos0, wb, fl, st);
+    if (l + 1 < n_layers) lia_ctx_chain_next_norm(ctx, Wall[(l + 1) * 9], nullptr);
+    rc = llama_layer_forward_impl(ctx, d, (const void* const*)(Wall + l * 9), hidden_of(l, n_layers, x, y, tmp), hidden_of(l + 1, n_layers, x, y, tmp), kv[l],
+                                  cos_table, sin_table, B, 1, pos0, 0, stream, 0);
     if (rc) return rc;
   }
   return LIA_OK;
@@ -1214,102 +1054,15 @@ extern "C" int lia_decode_layers(lia_ctx* ctx, const lia_layer_desc* d, int n_la
     for (int i = 0; i < 16; ++i)
       if (!weights[l * 16 + i]) { lia_set_error("lia_decode_layers: weights[%d][%d] is NULL", l, i); return LIA_ERR_MISSING; }
   }
-  const int H = d->hidden, F = d->ffn, hd = H / d->heads, M = B;
-  hipStream_t st = (hipStream_t)stream;
+  const int H = d->hidden, M = B;
   bf16_t* tmp = nullptr;
-  rc = chain_tmp_buffer(ctx, (size_t)M * H * 2, &tmp);
+  rc = hidden_tmp_buffer(ctx, (size_t)M * H * 2, &tmp);
   if (rc) return rc;
   const bf16_t* const* Wall = (const bf16_t* const*)weights;
-  bool fused = g_fused_decode && lia_chain_supported(M) == 0 && ctx->n_cu > 0;
-  for (int l = 0; fused && l < n_layers; ++l) {
-    const bf16_t* const* W = Wall + l * 16;
-    fused = (W[4] == W[2] + (size_t)H * H) && (W[6] == W[4] + (size_t)H * H) && (W[5] == W[3] + H) && (W[7] == W[5] + H);
-  }
-  LiaChainPlan p_qkv, p_o, p_fc1, p_fc2;
-  if (fused)
-    fused = !lia_chain_plan_gemm(M, 3 * H, H, 0, ctx->n_cu, &p_qkv) && !lia_chain_plan_gemm(M, H, H, 0, ctx->n_cu, &p_o) &&
-            !lia_chain_plan_gemm(M, F, H, 0, ctx->n_cu, &p_fc1) && !lia_chain_plan_gemm(M, H, F, 0, ctx->n_cu, &p_fc2);
-  if (!fused) {
-    for (int l = 0; l < n_layers; ++l) {
-      if (l + 1 < n_layers) lia_ctx_chain_next_norm(ctx, Wall[(l + 1) * 16], Wall[(l + 1) * 16 + 1]);
-      rc = layer_forward_impl(ctx, d, 3, (const void* const*)(Wall + l * 16), hidden_of(l, n_layers, x, y, tmp), hidden_of(l + 1, n_layers, x, y, tmp), kv[l], B, 1,
-                              pos0, 0, stream, 0);
-      if (rc) return rc;
-    }
-    return LIA_OK;
-  }
-
-  const WsLayout w = ws_layout(d, M, M);
-  if (w.total > ctx->ws_bytes) { lia_set_error("lia_decode_layers: workspace %zu < %zu", ctx->ws_bytes, w.total); return LIA_ERR_MEMORY; }
-  for (int i = 0; i < 2; ++i)                       // a K/V delivery of an earlier (policy 0) call may still drain from the workspace
-    if (ctx->slab_used[i]) HIP_TRY(hipStreamWaitEvent(st, ctx->slab_done[i], 0));
-  ctx->last_rows = -1;
-  char* ws = ctx->ws;
-  bf16_t *ln = (bf16_t*)(ws + w.ln), *qb = (bf16_t*)(ws + w.q), *ao = (bf16_t*)(ws + w.attn), *h1 = (bf16_t*)(ws + w.h1), *f1 = (bf16_t*)(ws + w.f1);
-  float* slab = (float*)(ws + w.gemm);
-  ctx->normed_src = nullptr; ctx->chain_armed = false;
-  const float eps = d->ln_eps;
-
-  auto qkv_steps = [&](LiaChainProgram& P, const bf16_t* const* W, lia_kv* c) {
-    LiaChainOp& g = P.op[P.n_ops++];
-    ch_op_gemm(g, p_qkv, ln, H, W[2], M, 3 * H, H, slab);
-    LiaEpilogue ep{W[3], nullptr, 0, 0, 0};
-    LiaOutMap om;
-    memset(&om, 0, sizeof(om));
-    om.base[0] = qb; om.base[1] = c->k; om.base[2] = c->v;
-    om.ld[0] = om.ld[1] = om.ld[2] = H;
-    om.cache_mode[1] = om.cache_mode[2] = 1;
-    om.seg_n = H; om.T = 1; om.Bc = c->batch; om.b0 = 0; om.pos0 = pos0;
-    LiaChainOp& r = P.op[P.n_ops++];
-    ch_op_reduce(r, LIA_CH_REDUCE_MAP, g, ep, om, nullptr);
-    r.use_pos0 = 1;
-  };
-  const double wb_qkv = 2.0 * 3.0 * H * H, wb_layer = 2.0 * ((double)H * H + 2.0 * (double)F * H);
-
-  lia_layernorm_launch(x, H, Wall[0], Wall[1], ln, H, M, H, eps, st);
-  {
-    LiaChainProgram P;
-    memset(&P, 0, sizeof(P));
-    qkv_steps(P, Wall, kv[0]);
-    rc = chain_submit(ctx, P, M, pos0, wb_qkv, 2.0 * M * 3.0 * H * H, st);
-    if (rc) return rc;
-  }
   for (int l = 0; l < n_layers; ++l) {
-    const bf16_t* const* W = Wall + l * 16;
-    const bf16_t* hin = hidden_of(l, n_layers, x, y, tmp);
-    bf16_t* hout = hidden_of(l + 1, n_layers, x, y, tmp);
-    if (lia_attn_decode_launch(qb, H, kv[l]->k, kv[l]->v, ao, H, B, pos0 + 1, d->heads, d->heads, hd, kv[l]->batch, 0, 0, st)) {
-      lia_set_error("attention: unsupported head_dim %d / S %d", hd, pos0 + 1);
-      return LIA_ERR_INVALID;
-    }
-    LiaChainProgram P;
-    memset(&P, 0, sizeof(P));
-    {  // out-proj + bias, residual -> h1 (decoder.py:225-229); LN2 -> ln (:268-276)
-      LiaChainOp& g = P.op[P.n_ops++];
-      ch_op_gemm(g, p_o, ao, H, W[8], M, H, H, slab);
-      LiaEpilogue ep{W[9], hin, H, 0, 0};
-      LiaPost post{};
-      post.kind = LIA_POST_LAYERNORM; post.g = W[10]; post.b = W[11]; post.eps = eps; post.out = ln; post.ldo = H;
-      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(h1, H, H), &post);
-    }
-    {  // fc1 + bias + relu -> f1 (:282-285)
-      LiaChainOp& g = P.op[P.n_ops++];
-      ch_op_gemm(g, p_fc1, ln, H, W[12], M, F, H, slab);
-      LiaEpilogue ep{W[13], nullptr, 0, 1, 0};
-      if (p_fc1.split == 1) { g.direct = LIA_CH_DIRECT_PLAIN; g.slab = nullptr; g.ep = ep; g.om = plain_out(f1, F, F); }
-      else ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_MAP, g, ep, plain_out(f1, F, F), nullptr);
-    }
-    {  // fc2 + bias, residual -> the layer's output (:306-310); the NEXT layer's LN1 -> ln
-      LiaChainOp& g = P.op[P.n_ops++];
-      ch_op_gemm(g, p_fc2, f1, F, W[14], M, H, F, slab);
-      LiaEpilogue ep{W[15], h1, H, 0, 0};
-      LiaPost post{};
-      if (l + 1 < n_layers) { post.kind = LIA_POST_LAYERNORM; post.g = Wall[(l + 1) * 16]; post.b = Wall[(l + 1) * 16 + 1]; post.eps = eps; post.out = ln; post.ldo = H; }
-      ch_op_reduce(P.op[P.n_ops++], LIA_CH_REDUCE_NORM, g, ep, plain_out(hout, H, H), &post);
-    }
-    double wb = wb_layer, fl = 2.0 * M * ((double)H * H + 2.0 * (double)F * H);
-    if (l + 1 < n_layers) { qkv_steps(P, Wall + (l + 1) * 16, kv[l + 1]); wb += wb_qkv; fl += 2.0 * M * 3.0 * H * H; }
-    rc = chain_submit(ctx, P, M, pos0, wb, fl, st);
+    if (l + 1 < n_layers) lia_ctx_chain_next_norm(ctx, Wall[(l + 1) * 16], Wall[(l + 1) * 16 + 1]);
+    rc = layer_forward_impl(ctx, d, 3, (const void* const*)(Wall + l * 16), hidden_of(l, n_layers, x, y, tmp), hidden_of(l + 1, n_layers, x, y, tmp), kv[l], B, 1,
+                            pos0, 0, stream, 0);
     if (rc) return rc;
   }
   return LIA_OK;
@@ -1318,22 +1071,17 @@ extern "C" int lia_decode_layers(lia_ctx* ctx, const lia_layer_desc* d, int n_la
 // ------------------------------------------------------------------------------------------------
 // weight streamer
 // ------------------------------------------------------------------------------------------------
-extern "C" size_t lia_pack12_bound(size_t n_values);
-extern "C" size_t lia_pack11_bound(size_t n_values);
 extern "C" size_t lia_pack10_bound(size_t n_values);
-extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 
-#ifndef LIA_DECODE_CUS_DEFAULT
-#define LIA_DECODE_CUS_DEFAULT 0
-#endif
 struct lia_streamer {
   lia_ctx* ctx;
   int n_slots;
   size_t slot_bytes;
   char* slots;
-  char* staging;          // per-slot landing area of pack12-encoded layers (lazily allocated)
+  char* staging;          // per-slot landing area of pack10-encoded layers (lazily allocated)
   size_t staging_bytes;
-  hipStream_t decode;     // pack12 decode kernels run here, ordered after the slot's copy by an event
+  hipStream_t decode;     // the wire-format decode kernels run here, ordered after the slot's copy by an event
   std::vector<hipEvent_t> landed;
   std::vector<char> decoded_on_side;
   // live timing of the wire-format decode kernel (lia_stream_decode_stats): one event pair per slot around the MAIN decode kernel
@@ -1458,33 +1206,18 @@ extern "C" int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, c
   return LIA_OK;
 }
 
-// pack12 path: the encoded layer lands in the slot's staging area, then a kernel on the copy stream rebuilds the
-// bf16 layer in the slot itself (lia_pack12.hip).  begin -> copy_chunk_packed* -> decode_packed -> mark_ready.
+// packed path: the encoded layer lands in the slot's staging area, then a kernel on a side stream rebuilds the
+// bf16 layer in the slot itself (lia_pack10.hip).  begin -> copy_chunk_packed* -> decode_packed -> mark_ready.
 static int ensure_staging(lia_streamer* s) {
   if (s->staging) return LIA_OK;
-  s->staging_bytes = std::max({lia_pack12_bound(s->slot_bytes / 2), lia_pack11_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024),
-                               lia_pack10_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024)});
+  s->staging_bytes = lia_pack10_bound((s->slot_bytes / 2 + 1023) / 1024 * 1024);
   HIP_TRY(hipMalloc((void**)&s->staging, s->staging_bytes * s->n_slots));
-  // The wire-format decode has a whole layer's link time (~14 ms for OPT-30B) to rebuild a layer and needs ~1/30 of the chip for
-  // that, but launched on a plain stream its thousands of workgroups take every CU and whatever the compute stream launches
-  // next queues behind them (a prefill LayerNorm: 88 -> 600 us, 44 times per prefill): the decode stream is confined to
-  // LIA_DECODE_CUS_DEFAULT compute units with a CU mask (r02: the whole chip).
-  int decode_cus = LIA_DECODE_CUS_DEFAULT;
-  if (s->ctx->serialized) {
-    s->decode = s->ctx->compute;
-  } else if (decode_cus > 0) {
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->ctx->device));
-    const int total = prop.multiProcessorCount;
-    decode_cus = std::min(decode_cus, total);
-    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
-    // low bits first: the driver deals consecutive mask bits round-robin over the XCDs (and their shader engines), so n bits are
-    // n / 8 CUs on each of the 8 XCDs
-    for (int i = 0; i < decode_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-    HIP_TRY(hipExtStreamCreateWithCUMask(&s->decode, (uint32_t)mask.size(), mask.data()));
-  } else {
-    HIP_TRY(hipStreamCreateWithFlags(&s->decode, hipStreamNonBlocking));
-  }
+  // The wire-format decode runs on a stream of its own, ordered by events, so the copy engine moves on to the next layer at once.
+  // (r02-r04 could confine that stream to a few compute units with a CU mask: measured level or worse at every width -- k masked CUs
+  // for 256 / k times as long cost the prefill GEMM the same CU-milliseconds -- and removed in r05; what did pay was making the
+  // decode kernel itself cheaper, lia_pack10.hip.  LABNOTES.md r04 / r05.)
+  if (s->ctx->serialized) s->decode = s->ctx->compute;
+  else HIP_TRY(hipStreamCreateWithFlags(&s->decode, hipStreamNonBlocking));
   s->landed.resize(s->n_slots);
   s->decoded_on_side.assign(s->n_slots, 0);
   s->d0.resize(s->n_slots); s->d1.resize(s->n_slots);
@@ -1520,8 +1253,7 @@ extern "C" int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t of
 }
 
 extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_values, int format) {
-  if (!s || slot < 0 || slot >= s->n_slots || !s->staging || n_values * 2 > s->slot_bytes || (n_values % 16) ||
-      (format != 10 && format != 11 && format != 12) || (format != 12 && (n_values % 1024))) {
+  if (!s || slot < 0 || slot >= s->n_slots || !s->staging || n_values * 2 > s->slot_bytes || format != 10 || (n_values % 1024)) {
     lia_set_error("lia_stream_decode_packed: slot=%d n_values=%zu format=%d", slot, n_values, format);
     return LIA_ERR_INVALID;
   }
@@ -1532,7 +1264,7 @@ extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_valu
   HIP_TRY(hipEventRecord(s->landed[slot], s->copy));
   HIP_TRY(hipStreamWaitEvent(s->decode, s->landed[slot], 0));
   streamer_collect_decode(s, slot, true);                              // (the slot's previous decode finished long ago: its consumer released the slot)
-  lia_packed_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, format, s->decode,
+  lia_packed_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, s->decode,
                            s->d0[slot], s->d1[slot]);
   HIP_TRY(hipGetLastError());
   s->decode_in[slot] = (double)s->pending_bytes[slot];
@@ -1544,11 +1276,11 @@ extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_valu
 
 extern "C" int lia_pack_decode(const char* src_device, lia_bf16* dst_device, size_t n_values, int format, void* stream) {
   if (!src_device || !dst_device) { lia_set_error("lia_pack_decode: NULL buffer"); return LIA_ERR_MISSING; }
-  if ((format != 10 && format != 11 && format != 12) || (n_values % 16) || (format != 12 && (n_values % 1024))) {
+  if (format != 10 || (n_values % 1024)) {
     lia_set_error("lia_pack_decode: n_values=%zu format=%d", n_values, format);
     return LIA_ERR_INVALID;
   }
-  lia_packed_decode_launch(src_device, dst_device, n_values, format, (hipStream_t)stream, nullptr, nullptr);
+  lia_packed_decode_launch(src_device, dst_device, n_values, (hipStream_t)stream, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   return LIA_OK;
 }

@@ -107,12 +107,19 @@ struct LiaPost {
   int rot_heads, hd, pos0, T;
 };
 
+// Per-context switches and counters of the GEMM launcher (lia_gemm_launch's `opts`; owned by lia_ctx, set through
+// lia_ctx_set_option / read through lia_ctx_get_counter -- the library keeps no process-wide setting, two contexts may differ).
+struct LiaGemmOpts {
+  int fuse_combine;         // 1 (default): the split-K combine also runs the op behind the GEMM; 0: every op a kernel of its own (A/B tests)
+  long fused_combines[5];   // fused combines launched per LIA_POST_* kind (tests assert the route was taken)
+};
+
 // One output row per workgroup (16 waves' worth of threads: the row ops of a decode step are pure latency, and a combine that
 // reads 8 slabs x 28 KB per row wants every load of the row in flight at once).  The row is cut into 8-value pieces (packed
 // bf16); VIRTUAL thread v of LIA_ROW_THREADS holds pieces v, v + LIA_ROW_THREADS, ...  A workgroup of LIA_ROW_THREADS / VT real
 // threads runs VT virtual threads per thread (real thread t = virtual threads t + h * LIA_ROW_THREADS / VT, h < VT): the
-// stand-alone row kernels and the split-K combines use VT = 1, the 512-thread persistent decode chain (lia_chain.hip) VT = 2 --
-// every sum is taken over the same values in the same order, so the two give the same bits.
+// stand-alone row kernels and the split-K combines use VT = 1 (a 512-thread workgroup would run VT = 2: every sum is taken over
+// the same values in the same order, so the two give the same bits).
 #define LIA_ROW_WAVES 16
 #define LIA_ROW_THREADS (64 * LIA_ROW_WAVES)
 

@@ -18,7 +18,6 @@
 #include <cstring>
 #include "lia_common.h"
 #include "lia_epilogue.h"
-#include "lia_chain.h"
 
 #define GL_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
@@ -294,7 +293,6 @@ __device__ __forceinline__ void epilogue_via_lds(const f32x4 (&acc)[4][MB], char
 // at 4.2 TB/s.
 // ---------------------------------------------------------------------------------------------
 constexpr int S2_BK = 64;     // K per chunk: 128-byte rows
-constexpr int LIA_GEMM_MAX_TICKETS = 16384;   // split-K tile tickets a context provides (N / 128 tiles x up to 16 row blocks)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -327,8 +325,7 @@ template <int MT, int S, int NT, int WAVES, int RT = 1>
 __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                        const bf16_t* __restrict__ W, long ldw, int M, int N,
                                                                        int K, int chunks_per_split,
-                                                                       float* __restrict__ partial, unsigned* __restrict__ tickets,
-                                                                       LiaEpilogue ep, LiaOutMap om) {
+                                                                       float* __restrict__ partial, LiaEpilogue ep, LiaOutMap om) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 16 * WAVES * RT;               // W rows per workgroup (RT MFMA row tiles of 16 per wave)
   constexpr int RR = 8 * WAVES;                     // rows one LDS-DMA round of the workgroup covers (128 B each)
@@ -484,42 +481,10 @@ __global__ __launch_bounds__(64 * WAVES) void lia_gemm_skinny2_kernel(const bf16
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   S2_STAMP(4);
 #endif
-  if (partial == nullptr || tickets == nullptr) return;
-  // ---- in-launch split-K combine: the slice that arrives LAST at this tile's ticket adds the slabs (slice 0, 1, ... in that
-  // order, as lia_splitk_reduce_kernel does: same bits) and applies the epilogue; no second kernel, no launch boundary.
-  // Publication is the agent-scope hand-off of cdna_hip_programming.md ("In-launch split-K reduction"): every storing wave
-  // drains its stores, the workgroup meets, ONE lane releases (fence + the explicit vmcnt wait ROCm 7.2 may drop) and takes a
-  // ticket; the last arriver acquires once, the workgroup meets again, then plain loads.  Correct for any placement of a
-  // tile's slices over CUs / XCDs.  The last arriver also re-arms the ticket for the next launch.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int* const flag = (int*)smem;                      // the staging ring is dead now; one LDS object only (no second __shared__)
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned* tk = tickets + (blockIdx.z * gridDim.x + blockIdx.x);
-    const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = prev == gridDim.y - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    *flag = last;
-  }
-  __syncthreads();
-  if (!*flag) return;
-  const int S_ = gridDim.y;
-  constexpr int QN = BN / 4;                         // quads per tile row
-  const int rows_here = min(XR, Mloc);
-  for (int q = tid; q < rows_here * QN; q += 64 * WAVES) {
-    const int m = m_base + q / QN;
-    const int n = n_tile + (q % QN) * 4;
-    if (n >= N) continue;
-    f32x4 a = *(const f32x4*)(partial + (long)m * N + n);
-    for (int s_ = 1; s_ < S_; ++s_) a += *(const f32x4*)(partial + ((long)s_ * M + m) * N + n);
-    store_quad(a, m, n, ep, om);
-  }
+  // (r02-r04 could also combine the split-K slabs inside this launch -- the last-arriving slice of a tile, found by a ticket --;
+  // bit-identical and measured SLOWER at every decode shape: the last arriver reads 3-8 x 64 KB alone while its CU's neighbours
+  // still stream, and every slice pays an agent-scope release.  Removed in r05; the slabs are combined by the small second
+  // kernel, which also runs the op behind the GEMM.)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -634,6 +599,25 @@ __device__ __forceinline__ void t2_stage(const bf16_t* __restrict__ g, long ld, 
   }
 }
 
+// XCD-aware tile order of the 256^2 kernels: blocks that share an XCD (same blockIdx % 8) walk a contiguous run of tiles, and runs
+// sweep GM m-tiles per n-tile so the W panel and the x panels stay in that XCD's L2
+#ifdef LIA_GM
+constexpr int T2_GM = LIA_GM;
+#else
+constexpr int T2_GM = 4;   // m-tiles per XCD group: 2 / 4 / 8 / 16 / 32 measured, 4 is 1-4 % ahead of 8 on three of the four OPT-30B shapes
+#endif
+__device__ __forceinline__ void t2_tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  const int group = lin / (T2_GM * tiles_n);
+  const int first_m = group * T2_GM;
+  const int gsz = min(tiles_m - first_m, T2_GM);
+  const int in_g = lin - group * T2_GM * tiles_n;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
+
 __global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                  const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
                                                                  int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
@@ -642,20 +626,8 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __
   const int l15 = lane & 15, lq = lane >> 4;
   const int wn = wave & 3, wm = wave >> 2;   // wave tile: n rows [64 wn, +64), m rows [128 wm, +128)
 
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-#ifdef LIA_GM
-  constexpr int GM = LIA_GM;
-#else
-  constexpr int GM = 4;   // m-tiles per XCD group: 2 / 4 / 8 / 16 / 32 measured, 4 is 1-4 % ahead of 8 on three of the four OPT-30B shapes
-#endif
-  const int group = lin / (GM * tiles_n);
-  const int first_m = group * GM;
-  const int gsz = min(tiles_m - first_m, GM);
-  const int in_g = lin - group * GM * tiles_n;
-  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  int tm, tn;
+  t2_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * T2_BM, n0 = tn * T2_BN;
 
   f32x4 acc[4][8];  // [n-block][m-block]
@@ -704,233 +676,28 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// tiled regime, large, staggered ("ping-pong") schedule.  Same 256 x 256 x 64 tile, wave layout, swizzle idea and
-// epilogue as lia_gemm_tiled256_kernel, but the K-tile is staged as two 32-deep halves (64-byte LDS rows) and the
-// two wave groups (waves 0-3 = m rows 0-127, waves 4-7 = m rows 128-255; waves w and w+4 share a SIMD) run half a
-// phase apart: while one group issues the 32 MFMAs of a k-step the other reads its 12 fragments and issues LDS-DMA,
-// so the MFMA pipe of every SIMD always has a wave to serve.  Four raw s_barriers per K-tile, no vmcnt(0) drain:
-//   R(t,0): ds_read k-step 0 | LDS-DMA pieces 4-7 of my half of tile t+1 | lgkmcnt(0) | barrier
-//   M(t,0): 32 MFMA | barrier
-//   R(t,1): ds_read k-step 1 | lgkmcnt(0) | barrier
-//   M(t,1): LDS-DMA pieces 0-3 of my half of tile t+2 | 32 MFMA | vmcnt(4): tile t+1 has landed | barrier
-// Group 0 stages the k-step-0 halves, group 1 the k-step-1 halves; group 1 starts one barrier late.
-// Ordering (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"):
-//   RAW  a half is read at the earliest in the interval after the barrier that follows its stager's vmcnt;
-//   WAR  a region is re-staged only after a barrier that every reader passed with lgkmcnt(0) already done.
-// LDS: 2 buffers x 2 halves x (W 256 rows x 64 B + x 256 rows x 64 B) = 128 KB.
-// ---------------------------------------------------------------------------------------------
-constexpr int T3_HALF_BYTES = 2 * 256 * 64;   // one k-half of a tile: W part 16 KB + x part 16 KB
-#ifdef LIA_GEMM_STAMPS
-__device__ unsigned long long g_t3_stamps[2 * 4096];
-#endif
-
-template <int DBG, int NSLOT>
-__global__ __launch_bounds__(512) void lia_gemm_tiled256s_kernel(const bf16_t* __restrict__ x, long ldx,
-                                                                  const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
-                                                                  int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buffer][half][W rows | x rows], 64-byte rows
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int wn = wave & 3, wm = wave >> 2;   // wave tile: n rows [64 wn, +64), m rows [128 wm, +128)
-  const int grp = wm;                        // stagger group = the half of the tile's m rows
-  const int wg = wave & 3;                   // wave index inside its group
-
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-#ifdef LIA_GM
-  constexpr int GM = LIA_GM;
-#else
-  constexpr int GM = 4;
-#endif
-  const int group = lin / (GM * tiles_n);
-  const int first_m = group * GM;
-  const int gsz = min(tiles_m - first_m, GM);
-  const int in_g = lin - group * GM * tiles_n;
-  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
-  const int m0 = tm * T2_BM, n0 = tn * T2_BN;
-
-  f32x4 acc[4][8];  // [n-block][m-block]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // -- staging: piece p (0..7) of a half = 64 rows of W (p < 4) or x (p >= 4); my wave moves rows [16 wg, +16) of
-  // it.  A lane carries 16 B: row lane>>2, LDS slot lane&3, which holds global chunk slot ^ swz(row), swz(row) =
-  // (-(row>>2)) & 3 (rows are 64 B, four to a 256-byte bank row; see the bank check at the fragment reads).
-  const int srow = wg * 16 + (lane >> 2);
-  const int schunk = (lane & 3) ^ ((-(lane >> 4)) & 3);
-  const long khalf = grp * 32 + schunk * 8;    // my group's k-half + the lane's chunk, in elements
-  const bf16_t* const wsrc0 = W + (long)min(n0 + srow, N - 1) * ldw + khalf;
-  const bf16_t* const wsrc1 = W + (long)min(n0 + 64 + srow, N - 1) * ldw + khalf;
-  const bf16_t* const wsrc2 = W + (long)min(n0 + 128 + srow, N - 1) * ldw + khalf;
-  const bf16_t* const wsrc3 = W + (long)min(n0 + 192 + srow, N - 1) * ldw + khalf;
-  const bf16_t* const xsrc0 = x + (long)min(m0 + srow, M - 1) * ldx + khalf;
-  const bf16_t* const xsrc1 = x + (long)min(m0 + 64 + srow, M - 1) * ldx + khalf;
-  const bf16_t* const xsrc2 = x + (long)min(m0 + 128 + srow, M - 1) * ldx + khalf;
-  const bf16_t* const xsrc3 = x + (long)min(m0 + 192 + srow, M - 1) * ldx + khalf;
-  char* const my_lane_base = smem + wg * 1024;      // + slot * T3_HALF_BYTES: unit u = 2 t + half lives in slot u % NSLOT
-  // (macros, not lambdas: a lambda that captures the fragment / accumulator arrays sends them to scratch)
-#define T3_STAGE_W(t, slot)                                                                                              \
-  do {                                                                                                                    \
-    char* dst_ = my_lane_base + (slot) * T3_HALF_BYTES;                                                                   \
-    const long k0_ = (long)(t) * T2_BK;                                                                                   \
-    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc0 + k0_), LDS_AS3(dst_), 16, 0, 0);                                       \
-    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc1 + k0_), LDS_AS3(dst_ + 4096), 16, 0, 0);                                \
-    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc2 + k0_), LDS_AS3(dst_ + 8192), 16, 0, 0);                                \
-    __builtin_amdgcn_global_load_lds(GL_AS1(wsrc3 + k0_), LDS_AS3(dst_ + 12288), 16, 0, 0);                               \
-  } while (0)
-#define T3_STAGE_X(t, slot)                                                                                              \
-  do {                                                                                                                    \
-    char* dst_ = my_lane_base + (slot) * T3_HALF_BYTES + 16384;                                                           \
-    const long k0_ = (long)(t) * T2_BK;                                                                                   \
-    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc0 + k0_), LDS_AS3(dst_), 16, 0, 0);                                       \
-    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc1 + k0_), LDS_AS3(dst_ + 4096), 16, 0, 0);                                \
-    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc2 + k0_), LDS_AS3(dst_ + 8192), 16, 0, 0);                                \
-    __builtin_amdgcn_global_load_lds(GL_AS1(xsrc3 + k0_), LDS_AS3(dst_ + 12288), 16, 0, 0);                               \
-  } while (0)
-
-  // -- fragment reads: lane (l15, lq) reads chunk lq of row 16 i + l15: slot lq ^ swz(row).  ds_read_b128 lane groups
-  // hold rows {0-3, 12-15} with chunk c and rows {4-11} with chunk c ^ 1; 16-byte slot in the bank row =
-  // 4 (row & 3) + (chunk ^ swz), and swz = (0, 3, 2, 1) per row quad makes the four quads land on four different slots.
-  const int frag_off = l15 * 64 + ((lq ^ ((-(l15 >> 2)) & 3)) << 4);
-  const char* const wfrag = smem + wn * 4096 + frag_off;
-  const char* const xfrag = smem + 16384 + wm * 8192 + frag_off;
-  bf16x8 a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7;
-#define T3_LD(p) __builtin_bit_cast(bf16x8, *(const uint4*)(p))
-#define T3_READ(slot)                                                                                                    \
-  do {                                                                                                                    \
-    const int off_ = (slot) * T3_HALF_BYTES;                                                                              \
-    a0 = T3_LD(wfrag + off_); a1 = T3_LD(wfrag + off_ + 1024); a2 = T3_LD(wfrag + off_ + 2048); a3 = T3_LD(wfrag + off_ + 3072); \
-    b0 = T3_LD(xfrag + off_); b1 = T3_LD(xfrag + off_ + 1024); b2 = T3_LD(xfrag + off_ + 2048); b3 = T3_LD(xfrag + off_ + 3072); \
-    b4 = T3_LD(xfrag + off_ + 4096); b5 = T3_LD(xfrag + off_ + 5120); b6 = T3_LD(xfrag + off_ + 6144); b7 = T3_LD(xfrag + off_ + 7168); \
-  } while (0)
-#define T3_ROW(i, ai)                                                                                                    \
-  acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b0, acc[i][0], 0, 0, 0);                                        \
-  acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b1, acc[i][1], 0, 0, 0);                                        \
-  acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b2, acc[i][2], 0, 0, 0);                                        \
-  acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b3, acc[i][3], 0, 0, 0);                                        \
-  acc[i][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b4, acc[i][4], 0, 0, 0);                                        \
-  acc[i][5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b5, acc[i][5], 0, 0, 0);                                        \
-  acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b6, acc[i][6], 0, 0, 0);                                        \
-  acc[i][7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b7, acc[i][7], 0, 0, 0);
-#define T3_MMA()                                                                                                         \
-  do {                                                                                                                    \
-    __builtin_amdgcn_s_setprio(1);                                                                                        \
-    T3_ROW(0, a0) T3_ROW(1, a1) T3_ROW(2, a2) T3_ROW(3, a3)                                                               \
-    __builtin_amdgcn_s_setprio(0);                                                                                        \
-  } while (0)
-#ifdef LIA_GEMM_STAMPS
-  // tools/gemm_bench.hip -DLIA_GEMM_STAMPS: cycle stamps before / after every barrier from waves 0 and 4 of workgroup 0
-  unsigned long long* stamp_p = (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) ? g_t3_stamps + (wave >> 2) * 4096 : nullptr;
-  int stamp_n = 0;
-#define T3_STAMP() do { if (stamp_p && stamp_n < 4096) stamp_p[stamp_n++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define T3_STAMP() do { } while (0)
-#endif
-#define T3_BARRIER() do { __builtin_amdgcn_sched_barrier(0); T3_STAMP(); __builtin_amdgcn_s_barrier(); T3_STAMP(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define T3_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-  const int nk = K / T2_BK;
-  // unit u = 2 t + half lives in ring slot u % NSLOT.  NSLOT = 4: the two-buffer scheme described above.
-  // NSLOT = 5 (160 KB): the LDS-DMA window is what bounds this kernel -- ablation (tools/gemm_bench -DLIA_GEMM_ABLATE): the
-  // loop without MFMAs takes as long as with them, without LDS-DMA 1.6 PFLOP/s; every sharer of an operand chunk asks for
-  // it at the same moment, so all of them see the L2-miss latency (~1.7 us) and a CU's fill rate is (LDS bytes that may be
-  // in flight) / latency = 64 KB / 1.7 us = 37 GB/s, i.e. 1.2 PFLOP/s at 128 flop/B.  The fifth slot lets my half of tile
-  // t+2 leave one k-step after the slot's previous unit was last read: pieces 0-3 in M(t,0), 4-7 in R(t,1), retired by
-  // vmcnt(8) at the end of M(t+1,1) -- 96-128 KB in flight instead of 64.
-  int u0 = 0;                                        // slot of unit 2 t
-#define T3_SLOT(d) ((u0 + (d)) % NSLOT)
-  if (NSLOT == 4) {
-    T3_STAGE_W(0, grp); T3_STAGE_X(0, grp);
-    if (nk > 1) { T3_STAGE_W(1, 2 + grp); wait_vmcnt<4>(); } else wait_vmcnt<0>();
-  } else {
-    T3_STAGE_W(0, grp); T3_STAGE_X(0, grp);
-    if (nk > 1) { T3_STAGE_W(1, 2 + grp); T3_STAGE_X(1, 2 + grp); wait_vmcnt<8>(); } else wait_vmcnt<0>();
-  }
-  T3_BARRIER();
-  if (grp == 1) T3_BARRIER();      // the stagger
-  for (int t = 0; t < nk; ++t) {
-    // R(t,0)
-    if (!(DBG & 2) || t == 0) T3_READ(T3_SLOT(0));
-    if (NSLOT == 4 && !(DBG & 1) && t + 1 < nk) T3_STAGE_X(t + 1, T3_SLOT(2 + grp));
-    T3_LGKM0();
-    T3_BARRIER();
-    // M(t,0)
-    if (NSLOT == 5 && !(DBG & 1) && t + 2 < nk) T3_STAGE_W(t + 2, T3_SLOT(4 + grp));
-    if (!(DBG & 4)) T3_MMA();
-    T3_BARRIER();
-    // R(t,1)
-    if (!(DBG & 2)) T3_READ(T3_SLOT(1));
-    if (NSLOT == 5 && !(DBG & 1) && t + 2 < nk) T3_STAGE_X(t + 2, T3_SLOT(4 + grp));
-    T3_LGKM0();
-    T3_BARRIER();
-    // M(t,1)
-    if (NSLOT == 4 && !(DBG & 1) && t + 2 < nk) T3_STAGE_W(t + 2, T3_SLOT(4 + grp));
-    if (!(DBG & 4)) T3_MMA();        // (never inside a branch on a runtime value: hipcc then copies the accumulators and spills)
-    if (NSLOT == 4) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
-    else { if (t + 2 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
-    if (t + 1 < nk || grp == 0) T3_BARRIER();
-    u0 = (u0 + 2) % NSLOT;
-  }
-#undef T3_SLOT
-#undef T3_BARRIER
-#undef T3_STAMP
-#undef T3_LGKM0
-#undef T3_MMA
-#undef T3_ROW
-#undef T3_READ
-#undef T3_LD
-#undef T3_STAGE_W
-#undef T3_STAGE_X
-  // group 0's last barrier is group 1's R(nk-1,1) barrier: every LDS read of the workgroup is complete, no LDS-DMA is
-  // pending, and each wave's epilogue region is its own
-  epilogue_via_lds<8>(acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, M, N, ep, om, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// tiled regime, large, PHASED schedule (r02).  Same 256 x 256 x 64 tile, LDS image ([W 256 rows | x 256 rows] x 128 B,
-// XOR-swizzled chunks, two buffers = 128 KB), fragment convention and accumulation order (k ascending inside every
-// accumulator: outputs are bit-identical to lia_gemm_tiled256_kernel) -- what changes is WHEN bytes move:
-//   * the K-tile is staged as four half-tiles of 128 rows (W0 = W rows 0-127, W1, X0 = x rows 0-127, X1), ONE per phase,
-//     four phases per K-tile, so the LDS-DMA queue carries a steady 16 KB per phase instead of a 64 KB burst per K-tile
-//     that every CU of the chip fires at the same moment;
-//   * a wave's 128 x rows are 64 rows of X0 + 64 rows of X1 (m-blocks 0-3 / 4-7) and each phase multiplies one quadrant
-//     (2 W row-blocks x 4 x row-blocks x K 64 = 16 MFMA), in the order (Wq0,X0) (Wq1,X0) (Wq1,X1) (Wq0,X1): X0 is last
-//     read in phase 1, W in phase 2, X1 in phase 3, so their regions can be re-staged for tile t+2 from phases 3 / 4 / 1' /
-//     2' on -- up to FOUR half-tiles (64 KB) in flight behind counted vmcnt waits, never a drain inside the loop
-//     (cdna_hip_programming.md "The 256^2 8-phase template"; the one-barrier kernel above drains vmcnt(0) per K-tile and
-//     so exposes one full load latency, ~1.7 us, per 64-deep K-step: 1.2 PFLOP/s);
+// tiled regime, large, PHASED schedule (r02; r05: the one form that is launched -- the four-phase / global_load_lds / debug
+// template forms it was selected from are in the git history, LABNOTES.md has their measurements).  Same 256 x 256 x 64 tile, LDS
+// image ([W 256 rows | x 256 rows] x 128 B, XOR-swizzled chunks, two buffers = 128 KB), fragment convention and accumulation
+// order (k ascending inside every accumulator: outputs are bit-identical to lia_gemm_tiled256_kernel) -- what changes is
+// WHEN bytes move:
+//   * the K-tile is staged as four half-tiles of 128 rows (W0 = W rows 0-127, W1, X0 = x rows 0-127, X1); a wave's 128 x rows
+//     are 64 rows of X0 + 64 rows of X1 (m-blocks 0-3 / 4-7) and a K-tile is TWO phases of 32 MFMA:
+//       PA(t): read all W + the X0 part (16)   stage X1(t+1) -> other buffer        vmcnt(8): X1(t) has landed      MFMA acc0
+//       PB(t): read the X1 part (8)            stage X0, W0, W1 (t+2) -> this one   vmcnt(8): X0, W0, W1 (t+1)      MFMA acc1
+//     so every half-tile has one full K-tile time between its LDS-DMA and the counted vmcnt that retires it, up to four (64 KB)
+//     are in flight, and there is never a drain inside the loop (cdna_hip_programming.md "The 256^2 8-phase template"; the
+//     one-barrier kernel above drains vmcnt(0) per K-tile and so exposes one full load latency, ~1.7 us, per 64-deep K-step);
 //   * waves 0-3 (x rows wm = 0) and waves 4-7 run half a phase apart (one extra barrier for group 1): while one wave of a
-//     SIMD issues its 16 MFMAs the other reads its fragments and issues LDS-DMA.
-// Phase = [ds_read fragments | LDS-DMA one half-tile | (counted vmcnt) | barrier | lgkmcnt(0) | 16 MFMA | barrier].
-//   P1(t): read Wq0 + X0 part (12)   stage W1(t+1)                  MFMA acc0[0..1]
-//   P2(t): read Wq1 (4)              stage X1(t+1)   vmcnt(8)       MFMA acc0[2..3]     (X1(t) landed: read in P3)
-//   P3(t): read X1 part (8)          stage X0(t+2)                  MFMA acc1[2..3]
-//   P4(t): --                        stage W0(t+2)   vmcnt(6)       MFMA acc1[0..1]     (X0, W0, W1 of t+1 landed: P1(t+1))
-// Ordering: RAW -- a half-tile is read one phase after the wait that retires it, and both groups pass their wait and a
-// barrier in between; WAR -- a region is re-staged two phases after its last read, i.e. after a barrier every reader
-// crossed with lgkmcnt(0) done (group 1 lags half a phase: still a full phase of margin).
+//     SIMD issues its MFMAs the other reads its fragments and issues LDS-DMA;
+//   * the LDS-DMA goes through buffer_load ... lds with a per-tile resource, a per-lane 32-bit row offset and the K offset in
+//     an SGPR -- no 64-bit address arithmetic per piece (cdna_hip_programming.md T8).
+// Ordering: RAW -- a half-tile is read one phase after the wait that retires it, and both groups pass their wait and a barrier
+// in between; WAR -- a region is re-staged ONE phase after its last read, which is legal because the reading phase waits
+// lgkmcnt(0) BEFORE its first barrier (group 1 lags half a phase).
 // ---------------------------------------------------------------------------------------------
 constexpr int T4_BUF_BYTES = 65536;   // one K-tile: W rows 0-255 at row * 128, x rows at 32768 + row * 128
-#ifdef LIA_GEMM_STAMPS
-__device__ unsigned long long g_t4_stamps[8192 * 8];   // per workgroup: start, after the prologue, after the K loop, after the epilogue (100 MHz ticks)
-#define T4_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_t4_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define T4_STAMP(i) do { } while (0)
-#endif
 
-// DBG (tools/gemm_bench.hip only; 0 in the product): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMA (timing-only,
-// wrong results); 8 no stagger, 16 no s_setprio around the MFMA clusters (correct results)
-// PH = 4: the four-phase schedule above.  PH = 2: two phases per K-tile (32 MFMA each, four barriers per K-tile instead of
-// eight): PA reads all W fragments + the X0 part (16 reads), stages W1(t+1), X1(t+1), waits vmcnt(8), multiplies acc0; PB
-// reads the X1 part (8), stages X0(t+2), W0(t+2), waits vmcnt(6), multiplies acc1.  A region is then re-staged ONE phase
-// after its last read, which is legal because the reading phase waits lgkmcnt(0) BEFORE its first barrier.
-// BUF = 1: the LDS-DMA goes through buffer_load ... lds with a per-tile resource, a per-lane 32-bit row offset and the K
-// offset in an SGPR -- no 64-bit address arithmetic per piece (cdna_hip_programming.md T8).
-template <int DBG, int PH, int BUF>
 __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
@@ -939,20 +706,8 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
   const int l15 = lane & 15, lq = lane >> 4;
   const int wn = wave & 3, wm = wave >> 2;   // wave tile: W rows [64 wn, +64) x (x rows [64 wm, +64) and [128 + 64 wm, +64))
 
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-#ifdef LIA_GM
-  constexpr int GM = LIA_GM;
-#else
-  constexpr int GM = 4;
-#endif
-  const int group = lin / (GM * tiles_n);
-  const int first_m = group * GM;
-  const int gsz = min(tiles_m - first_m, GM);
-  const int in_g = lin - group * GM * tiles_n;
-  const int tm = (DBG & 32) ? 0 : first_m + in_g % gsz, tn = (DBG & 32) ? 0 : in_g / gsz;   // DBG 32: every workgroup reads tile (0, 0)
+  int tm, tn;
+  t2_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * T2_BM, n0 = tn * T2_BN;
 
   f32x4 acc0[4][4], acc1[4][4];   // [W row-block][x row-block]: acc0 = the X0 part of the wave's x rows, acc1 = the X1 part
@@ -963,32 +718,22 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
 
   // -- staging: a half-tile = two LDS-DMA rounds of the whole workgroup, 64 rows each; my lane moves chunk (tid & 7) of
   // row 64 q + (tid >> 3) of the 256-row operand tile, q = 2 half + round, into LDS slot tid & 7 of that row (linear
-  // destination, swizzle on the source: rule 21)
+  // destination, swizzle on the source: rule 21).  Resources over the tile's first row; voffset = (clamped row - first row)
+  // * ld * 2 + chunk * 16 (< 2^31: 256 rows)
   const int srow = tid >> 3;
   const int sck = ((tid & 7) ^ tl_swz(srow)) << 3;
-  const bf16_t* const ws0 = W + (long)min(n0 + srow, N - 1) * ldw + sck;
-  const bf16_t* const ws1 = W + (long)min(n0 + 64 + srow, N - 1) * ldw + sck;
-  const bf16_t* const ws2 = W + (long)min(n0 + 128 + srow, N - 1) * ldw + sck;
-  const bf16_t* const ws3 = W + (long)min(n0 + 192 + srow, N - 1) * ldw + sck;
-  const bf16_t* const xs0 = x + (long)min(m0 + srow, M - 1) * ldx + sck;
-  const bf16_t* const xs1 = x + (long)min(m0 + 64 + srow, M - 1) * ldx + sck;
-  const bf16_t* const xs2 = x + (long)min(m0 + 128 + srow, M - 1) * ldx + sck;
-  const bf16_t* const xs3 = x + (long)min(m0 + 192 + srow, M - 1) * ldx + sck;
   char* const sdst = smem + wave * 1024;
-  // BUF: resources over the tile's first row; voffset = (clamped row - first row) * ld * 2 + chunk * 16 (< 2^31: 256 rows)
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * ldw), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)m0 * ldx), 0, 0x7fffffff, 0x00020000);
   const int wv0 = (int)((min(n0 + srow, N - 1) - n0) * ldw + sck) * 2, wv1 = (int)((min(n0 + 64 + srow, N - 1) - n0) * ldw + sck) * 2;
   const int wv2 = (int)((min(n0 + 128 + srow, N - 1) - n0) * ldw + sck) * 2, wv3 = (int)((min(n0 + 192 + srow, N - 1) - n0) * ldw + sck) * 2;
   const int xv0 = (int)((min(m0 + srow, M - 1) - m0) * ldx + sck) * 2, xv1 = (int)((min(m0 + 64 + srow, M - 1) - m0) * ldx + sck) * 2;
   const int xv2 = (int)((min(m0 + 128 + srow, M - 1) - m0) * ldx + sck) * 2, xv3 = (int)((min(m0 + 192 + srow, M - 1) - m0) * ldx + sck) * 2;
-#define T4_GLDS(src, dst) __builtin_amdgcn_global_load_lds(GL_AS1(src), LDS_AS3(dst), 16, 0, 0)
-#define T4_BLDS(rs, vo, so, dst) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_AS3(dst), 16, vo, so, 0, 0)
-#define T4_PIECE(rs, vo, ptr, t, dst) do { const int t_ = (DBG & 128) ? 0 : (int)(t); if (BUF) T4_BLDS(rs, vo, t_ * (T2_BK * 2), dst); else T4_GLDS((ptr) + (long)t_ * T2_BK, dst); } while (0)
-#define T4_STAGE_W0(t, buf) do { T4_PIECE(rsw, wv0, ws0, t, sdst + (buf) * T4_BUF_BYTES);         T4_PIECE(rsw, wv1, ws1, t, sdst + (buf) * T4_BUF_BYTES + 8192); } while (0)
-#define T4_STAGE_W1(t, buf) do { T4_PIECE(rsw, wv2, ws2, t, sdst + (buf) * T4_BUF_BYTES + 16384); T4_PIECE(rsw, wv3, ws3, t, sdst + (buf) * T4_BUF_BYTES + 24576); } while (0)
-#define T4_STAGE_X0(t, buf) do { T4_PIECE(rsx, xv0, xs0, t, sdst + (buf) * T4_BUF_BYTES + 32768); T4_PIECE(rsx, xv1, xs1, t, sdst + (buf) * T4_BUF_BYTES + 40960); } while (0)
-#define T4_STAGE_X1(t, buf) do { T4_PIECE(rsx, xv2, xs2, t, sdst + (buf) * T4_BUF_BYTES + 49152); T4_PIECE(rsx, xv3, xs3, t, sdst + (buf) * T4_BUF_BYTES + 57344); } while (0)
+#define T4_PIECE(rs, vo, t, dst) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_AS3(dst), 16, vo, (int)(t) * (T2_BK * 2), 0, 0)
+#define T4_STAGE_W0(t, buf) do { T4_PIECE(rsw, wv0, t, sdst + (buf) * T4_BUF_BYTES);         T4_PIECE(rsw, wv1, t, sdst + (buf) * T4_BUF_BYTES + 8192); } while (0)
+#define T4_STAGE_W1(t, buf) do { T4_PIECE(rsw, wv2, t, sdst + (buf) * T4_BUF_BYTES + 16384); T4_PIECE(rsw, wv3, t, sdst + (buf) * T4_BUF_BYTES + 24576); } while (0)
+#define T4_STAGE_X0(t, buf) do { T4_PIECE(rsx, xv0, t, sdst + (buf) * T4_BUF_BYTES + 32768); T4_PIECE(rsx, xv1, t, sdst + (buf) * T4_BUF_BYTES + 40960); } while (0)
+#define T4_STAGE_X1(t, buf) do { T4_PIECE(rsx, xv2, t, sdst + (buf) * T4_BUF_BYTES + 49152); T4_PIECE(rsx, xv3, t, sdst + (buf) * T4_BUF_BYTES + 57344); } while (0)
 
   // -- fragment reads: lane (l15, lq) reads chunk 4 ks + lq of row base + l15, stored in slot chunk ^ swz(row);
   // swz(row) = (row >> 1) & 7 depends on l15 only (row bases are multiples of 16), and the two k-steps differ in bit 6
@@ -1010,90 +755,45 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
     b[3][0] = T4_LD(xf0 + (buf) * T4_BUF_BYTES + (part) * 16384 + 6144); b[3][1] = T4_LD(xf1 + (buf) * T4_BUF_BYTES + (part) * 16384 + 6144); \
   } while (0)
 #define T4_MMA(ACC, i0) do {                                                                                             \
-    if (DBG & 4) {   /* keep the fragment reads alive without the MFMAs */                                                \
-      _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                               \
-        _Pragma("unroll") for (int i_ = (i0); i_ < (i0) + 2; ++i_) asm volatile("" :: "v"(a[i_][ks_]));                   \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) asm volatile("" :: "v"(b[j_][ks_]));                             \
-      }                                                                                                                   \
-      break;                                                                                                              \
-    }                                                                                                                     \
-    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                                        \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                                   \
       _Pragma("unroll") for (int i_ = (i0); i_ < (i0) + 2; ++i_)                                                          \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                  \
           ACC[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i_][ks_], b[j_][ks_], ACC[i_][j_], 0, 0, 0);            \
-    if (!(DBG & 16)) __builtin_amdgcn_s_setprio(0);                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                        \
   } while (0)
 #define T4_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define T4_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-  // one K-tile.  S12: tile t+1 exists (stage its W1, X1); S34: tile t+2 exists (stage its X0, W0); W2 / W4: the vmcnt
-  // immediates of the two waits (-1 = no wait); LAST: group 1 skips the closing barrier (it entered one barrier late)
-#define T4_TILE(t, buf, S12, S34, W2, W4, LAST) do {                                                                     \
-    if (!(DBG & 2) || (t) == 0) { T4_READ_W(buf, 0); T4_READ_X(buf, 0); }                                                 \
-    if ((S12) && !(DBG & 1)) T4_STAGE_W1((t) + 1, (buf) ^ 1);                                                             \
-    T4_BARRIER(); T4_LGKM0(); T4_MMA(acc0, 0); T4_BARRIER();                                                              \
-    if (!(DBG & 2) || (t) == 0) T4_READ_W(buf, 2);                                                                        \
-    if ((S12) && !(DBG & 1)) T4_STAGE_X1((t) + 1, (buf) ^ 1);                                                             \
-    if (DBG & 1) wait_vmcnt<0>(); else wait_vmcnt<W2>();                                                                  \
-    T4_BARRIER(); T4_LGKM0(); T4_MMA(acc0, 2); T4_BARRIER();                                                              \
-    if (!(DBG & 2)) T4_READ_X(buf, 1);                                                                                    \
-    if ((S34) && !(DBG & 1)) T4_STAGE_X0((t) + 2, buf);                                                                   \
-    T4_BARRIER(); T4_LGKM0(); T4_MMA(acc1, 2); T4_BARRIER();                                                              \
-    if ((S34) && !(DBG & 1)) T4_STAGE_W0((t) + 2, buf);                                                                   \
-    if (DBG & 1) wait_vmcnt<0>(); else if (W4 >= 0) wait_vmcnt<(W4 >= 0 ? W4 : 0)>();                                     \
-    T4_BARRIER(); T4_MMA(acc1, 0);                                                                                        \
-    if (!(LAST) || wm == 0 || (DBG & 8)) T4_BARRIER();                                                                    \
-  } while (0)
-
-  // two-phase K-tile (PH = 2).  Every half-tile gets two phases (one K-tile time) between its LDS-DMA and the wait that
-  // retires it: W1 is staged with X0 and W0 in PB, one phase after the last read of those regions in PA (with W1 issued in PA,
-  // as in the four-phase order, it had ONE phase and the kernel ran 20 % slower when the waits were tightened further).
-  //   PA(t): read all W + the X0 part (16)   stage X1(t+1) -> other buffer        vmcnt(8): X1(t) has landed
-  //   PB(t): read the X1 part (8)            stage X0, W0, W1 (t+2) -> this one   vmcnt(8): X0, W0, W1 (t+1) have landed
+  // one K-tile.  S12: tile t+1 exists (stage its X1); S34: tile t+2 exists (stage its X0, W0, W1); W2 / W4: the vmcnt
+  // immediates of the two waits (-1 = no wait); LAST: group 1 skips the closing barrier (it entered one barrier late).
+  // W1 is staged with X0 and W0 in PB, one phase after the last read of those regions in PA (with W1 issued in PA it had ONE
+  // phase of flight and the kernel ran 20 % slower when the waits were tightened further).
 #define T4_TILE2(t, buf, S12, S34, W2, W4, LAST) do {                                                                    \
-    if (!(DBG & 2) || (t) == 0) { T4_READ_W(buf, 0); T4_READ_W(buf, 2); T4_READ_X(buf, 0); }                              \
-    if ((S12) && !(DBG & 1)) T4_STAGE_X1((t) + 1, (buf) ^ 1);                                                             \
-    if (DBG & 1) wait_vmcnt<0>(); else if (DBG & 256) wait_vmcnt<(W2 >= 4 ? 4 : W2)>(); else wait_vmcnt<W2>();             \
+    T4_READ_W(buf, 0); T4_READ_W(buf, 2); T4_READ_X(buf, 0);                                                              \
+    if (S12) T4_STAGE_X1((t) + 1, (buf) ^ 1);                                                                             \
+    wait_vmcnt<W2>();                                                                                                     \
     T4_LGKM0(); T4_BARRIER(); T4_MMA(acc0, 0); T4_MMA(acc0, 2); T4_BARRIER();                                             \
-    if (!(DBG & 2)) T4_READ_X(buf, 1);                                                                                    \
-    if ((S34) && !(DBG & 1)) { T4_STAGE_X0((t) + 2, buf); T4_STAGE_W0((t) + 2, buf); T4_STAGE_W1((t) + 2, buf); }         \
-    if (DBG & 1) wait_vmcnt<0>(); else if ((DBG & 256) && W4 >= 2) wait_vmcnt<2>(); else if (W4 >= 0) wait_vmcnt<(W4 >= 0 ? W4 : 0)>(); \
+    T4_READ_X(buf, 1);                                                                                                    \
+    if (S34) { T4_STAGE_X0((t) + 2, buf); T4_STAGE_W0((t) + 2, buf); T4_STAGE_W1((t) + 2, buf); }                         \
+    if (W4 >= 0) wait_vmcnt<(W4 >= 0 ? W4 : 0)>();                                                                        \
     T4_LGKM0(); T4_BARRIER(); T4_MMA(acc1, 2); T4_MMA(acc1, 0);                                                           \
-    if (!(LAST) || wm == 0 || (DBG & 8)) T4_BARRIER();                                                                    \
+    if (!(LAST) || wm == 0) T4_BARRIER();                                                                                 \
   } while (0)
 
   const int nk = K / T2_BK;      // even and >= 4 (the launcher falls back to the one-barrier kernel otherwise)
-  T4_STAMP(0);
-  if (PH == 4) {
-    T4_STAGE_X0(0, 0); T4_STAGE_W0(0, 0); T4_STAGE_W1(0, 0); T4_STAGE_X1(0, 0);
-    T4_STAGE_X0(1, 1); T4_STAGE_W0(1, 1);
-    wait_vmcnt<6>();             // X0, W0, W1 of tile 0 have landed (X1(0) is waited for in P2)
-  } else {
-    T4_STAGE_X0(0, 0); T4_STAGE_W0(0, 0); T4_STAGE_W1(0, 0); T4_STAGE_X1(0, 0);
-    T4_STAGE_X0(1, 1); T4_STAGE_W0(1, 1); T4_STAGE_W1(1, 1);
-    wait_vmcnt<8>();             // X0, W0, W1 of tile 0 have landed (X1(0) is waited for in PA)
-  }
+  T4_STAGE_X0(0, 0); T4_STAGE_W0(0, 0); T4_STAGE_W1(0, 0); T4_STAGE_X1(0, 0);
+  T4_STAGE_X0(1, 1); T4_STAGE_W0(1, 1); T4_STAGE_W1(1, 1);
+  wait_vmcnt<8>();             // X0, W0, W1 of tile 0 have landed (X1(0) is waited for in PA)
   T4_BARRIER();
-  T4_STAMP(1);
-  if (wm == 1 && !(DBG & 8)) T4_BARRIER();     // the stagger
+  if (wm == 1) T4_BARRIER();     // the stagger
   int t = 0;
-  if (PH == 4) {
-    for (; t + 2 < nk; t += 2) {
-      T4_TILE(t, 0, true, true, 8, 6, false);
-      T4_TILE(t + 1, 1, true, true, 8, 6, false);
-    }
-    T4_TILE(t, 0, true, false, 8, 2, false);
-    T4_TILE(t + 1, 1, false, false, 0, -1, true);
-  } else {
-    for (; t + 2 < nk; t += 2) {
-      T4_TILE2(t, 0, true, true, 8, 8, false);
-      T4_TILE2(t + 1, 1, true, true, 8, 8, false);
-    }
-    T4_TILE2(t, 0, true, false, 8, 2, false);
-    T4_TILE2(t + 1, 1, false, false, 0, -1, true);
+  for (; t + 2 < nk; t += 2) {
+    T4_TILE2(t, 0, true, true, 8, 8, false);
+    T4_TILE2(t + 1, 1, true, true, 8, 8, false);
   }
+  T4_TILE2(t, 0, true, false, 8, 2, false);
+  T4_TILE2(t + 1, 1, false, false, 0, -1, true);
 #undef T4_TILE2
-#undef T4_TILE
 #undef T4_LGKM0
 #undef T4_BARRIER
 #undef T4_MMA
@@ -1105,40 +805,21 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
 #undef T4_STAGE_W1
 #undef T4_STAGE_W0
 #undef T4_PIECE
-#undef T4_BLDS
-#undef T4_GLDS
   // group 0's closing barrier is the one group 1 crossed before its last MFMAs: every LDS read of the workgroup has been
-  // retired (P4 reads nothing, P3's reads were waited for), no LDS-DMA is pending (the last wait was vmcnt(0)), and each
-  // wave's epilogue region is its own
-  T4_STAMP(2);
-  // the residual rows of BOTH halves of the wave tile are requested before the first store: vmcnt retires in order, so a
-  // residual load issued behind the first half's stores would wait for them as well (the fragment registers are free now)
-  if (!(DBG & 64) || acc0[0][0][0] == 12345.678f || acc1[3][3][1] == 12345.678f) {     // DBG 64: no epilogue (timing only)
-    uint4 rres0[8], rres1[8];
-    epilogue_load_residual<4>(rres0, m0 + wm * 64, n0 + wn * 64, M, N, ep, lane);
-    epilogue_load_residual<4>(rres1, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, lane);
-    T4_STAMP(4);
-    epilogue_via_lds_part<4, 0, 4>(acc0, rres0, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
-    T4_STAMP(5);
-    epilogue_via_lds_part<4, 0, 4>(acc1, rres1, smem + wave * 16384 + 8192, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
-    T4_STAMP(6);
-  }
-#ifdef LIA_GEMM_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  T4_STAMP(3);
+  // retired (PB's reads were waited for), no LDS-DMA is pending (the last wait was vmcnt(0)), and each wave's epilogue region
+  // is its own.  The residual rows of BOTH halves of the wave tile are requested before the first store: vmcnt retires in
+  // order, so a residual load issued behind the first half's stores would wait for them as well (the fragment registers are
+  // free now)
+  uint4 rres0[8], rres1[8];
+  epilogue_load_residual<4>(rres0, m0 + wm * 64, n0 + wn * 64, M, N, ep, lane);
+  epilogue_load_residual<4>(rres1, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, lane);
+  epilogue_via_lds_part<4, 0, 4>(acc0, rres0, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
+  epilogue_via_lds_part<4, 0, 4>(acc1, rres1, smem + wave * 16384 + 8192, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------------------------
-// 262 (default): phased kernel, two phases per K-tile, buffer-load LDS-DMA; 259 / 260 / 261: its four-phase and global_load_lds
-// forms; 256: the one-barrier-per-K-tile kernel of r01 (also the fallback for K / 64 odd or < 4); 257 / 258: r01's staggered
-// k-half kernel.  All produce bit-identical outputs (tests/test_gpu_fused_combine.py); lia_gemm_set_tiled_variant selects one
-// for A/B runs (tools/gemm_bench.hip).
-static int g_tiled_variant = 262;
-extern "C" void lia_gemm_set_tiled_variant(int v) { g_tiled_variant = v; }
-
 extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
   // worst case split-K = 8 fp32 slabs of a skinny problem
   if (M > 256) return 0;
@@ -1147,30 +828,24 @@ extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
 
 template <int MT, int S, int NT, int WAVES, int RT = 1>
 static void launch_skinny2(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K, int split, int cps,
-                           float* partial, unsigned* tickets, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
+                           float* partial, const LiaEpilogue& ep, const LiaOutMap& om, hipStream_t st) {
   constexpr int BN = 16 * WAVES * RT, RR = 8 * WAVES;
   constexpr int XL = (16 * MT + RR - 1) / RR;
   dim3 grid((N + BN - 1) / BN, split, (M + 16 * MT - 1) / (16 * MT));
   size_t lds = (size_t)S * (BN * 128 + XL * RR * 128);
-  static bool attr_set = false;
+  static bool attr_set = false;          // (an idempotent driver call made once per process, not a setting)
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)lia_gemm_skinny2_kernel<MT, S, NT, WAVES, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL((lia_gemm_skinny2_kernel<MT, S, NT, WAVES, RT>), grid, dim3(64 * WAVES), lds, st, x, ldx, W, ldw, M, N, K, cps,
-                     split > 1 ? partial : nullptr, tickets, ep, om);
+                     split > 1 ? partial : nullptr, ep, om);
 }
-
-// A/B switch (tests, tools): lia_gemm_set_fuse_combine(0) keeps every post op a kernel of its own
-static int g_fuse_combine = 1;
-extern "C" void lia_gemm_set_fuse_combine(int on) { g_fuse_combine = on; }
-static long g_fused_combines[5];     // launches per LIA_POST_* kind since the library was loaded (tests assert the route was taken)
-extern "C" long lia_gemm_fused_combine_count(int kind) { return (kind >= 0 && kind < 5) ? g_fused_combines[kind] : -1; }
 
 // the combine kernel that also runs `post`, if this shape has one; false: nothing launched
 static bool launch_fused_combine(const float* ws, int split, int M, int N, const LiaEpilogue& ep, const LiaOutMap& om, const LiaPost& post,
-                                 hipStream_t st) {
-  if (!g_fuse_combine) return false;
+                                 LiaGemmOpts* opts, hipStream_t st) {
+  if (opts && !opts->fuse_combine) return false;
   if (post.kind == LIA_POST_LAYERNORM || post.kind == LIA_POST_RMSNORM) {
     if (om.seg_n != N || om.cache_mode[0] || (N & 7) || (N >> 3) > LIA_ROW_THREADS * 2 || (om.ld[0] & 7) || (post.ldo & 7) || !post.g || !post.out) return false;
     if (post.kind == LIA_POST_LAYERNORM && !post.b) return false;
@@ -1181,57 +856,32 @@ static bool launch_fused_combine(const float* ws, int split, int M, int N, const
     } while (0)
     if (post.kind == LIA_POST_LAYERNORM) LIA_NORM_COMBINE(LIA_POST_LAYERNORM); else LIA_NORM_COMBINE(LIA_POST_RMSNORM);
 #undef LIA_NORM_COMBINE
-    ++g_fused_combines[post.kind];
+    if (opts) ++opts->fused_combines[post.kind];
     return true;
   }
   if (post.kind == LIA_POST_SILU_MUL) {
     if ((N & 7) || (post.ldo & 3) || !post.out || (post.gu_block && (post.gu_block != LIA_GU_BLOCK || (N % (2 * LIA_GU_BLOCK))))) return false;
     const long nq = (long)M * (N >> 3);
     hipLaunchKernelGGL(lia_splitk_reduce_silu_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, ws, split, M, N, ep, post);
-    ++g_fused_combines[post.kind];
+    if (opts) ++opts->fused_combines[post.kind];
     return true;
   }
   if (post.kind == LIA_POST_ROPE) {
     if (post.hd <= 0 || (post.hd & 7) || N % post.hd || om.seg_n % post.hd || post.T <= 0 || !post.cos_t || !post.sin_t) return false;
     const long nt = (long)M * (N / post.hd) * (post.hd >> 3);
     hipLaunchKernelGGL(lia_splitk_reduce_rope_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, ws, split, M, N, ep, om, post);
-    ++g_fused_combines[post.kind];
+    if (opts) ++opts->fused_combines[post.kind];
     return true;
   }
   return false;
 }
 
-// experiment knob (tools/gemm_bench.hip): 0 = production choice, 1 = force 128-row workgroups, 2 = force 256-row,
-// 3 = force the two-block x cut at 64 < M <= 128, 4 = forbid it
-static int g_inlaunch_combine = 0;
-extern "C" void lia_gemm_set_inlaunch_combine(int on) { g_inlaunch_combine = on ? 1 : 0; }
-static int g_skinny_variant = 0;
-extern "C" void lia_gemm_set_skinny_variant(int v) { g_skinny_variant = v; }
-
-// Test / A-B knob: 1 = cut K into the slices the persistent decode chain uses for the same shape (lia_chain_plan_gemm).  The two
-// routes then add the same products in the same order and must agree bit for bit (tests/test_gpu_chain.py); 0 (default) = the
-// per-launch heuristics below.
-static int g_split_policy = 0;
-extern "C" void lia_gemm_set_split_policy(int v) { g_split_policy = v; }
-
-// Which kernel runs a decode GEMM with M <= 128: 0 (default) = lia_gemm_skinny2_kernel; 1 (lia_gemm_set_engine(1)) = the persistent
-// chain kernel as a one-step program (lia_chain.hip), its split-K slabs combined by the same kernels as before.  Measured (r04,
-// LABNOTES.md): the chain's steady-state loop is the faster one (7.0 TB/s on OPT-30B's fc1 at M = 64 against 6.0, 52 against 60 us
-// on Llama-3-8B's gate|up at M = 128), but as a launch of its own it pays a cold 160 KB ring and ~1 us rounds at every item
-// boundary: q|k|v / o 19-23 us against 16.7, lm_head 306 against 246 -- whole steps 3-6 % slower.  Kept for A/B runs and as a
-// second implementation to compare bits with: same products in the same order per K slice, so with
-// lia_gemm_set_split_policy(1) the two engines agree bit for bit.
-static int g_gemm_engine = 0;
-extern "C" void lia_gemm_set_engine(int v) { g_gemm_engine = v ? 1 : 0; }
-static long g_chain_gemms = 0;
-extern "C" long lia_gemm_chain_engine_count(void) { return g_chain_gemms; }
-
 // Returns 0 on success, -1 on unsupported shape.  workspace is only touched when split-K is chosen.
-// tickets: LIA_GEMM_MAX_TICKETS zero-initialised counters owned by the caller's context (one per output tile of a split-K
-// launch; the kernel leaves them zero again).  NULL: the slabs are combined by a second kernel as in r01.
+// opts (nullable = defaults): the per-context switches and counters (LiaGemmOpts, lia_common.h; lia_ctx_set_option) -- the
+// library keeps no process-wide setting.
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
-                               unsigned* tickets, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime,
+                               LiaGemmOpts* opts, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime,
                                const LiaPost* post, int* post_done) {
   // post (nullable): the op that follows this GEMM in the decode layer; when the GEMM is split over K its combine kernel does
   // that op too and *post_done = 1 -- otherwise *post_done = 0 and the caller launches the stand-alone kernel.
@@ -1241,16 +891,10 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   if (regime) *regime = 0;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N % 16) != 0 || (om->seg_n % 4) != 0) return -1;
+  const bool fuse = !opts || opts->fuse_combine;
   if (M <= 256 && (K % (2 * S2_BK)) == 0) {
     constexpr int WAVES = 8;
     const int nchunks = K / S2_BK;
-    const int caller_split = force_split;                      // (the split policy below may set force_split; the engine choice looks at the caller's)
-    if (g_split_policy == 1 && force_split <= 0 && M <= 128) {
-      static const int n_cu = [] { int dev = 0; (void)hipGetDevice(&dev); return lia_chain_cu_count(dev); }();
-      LiaChainPlan cp;
-      const int glu = post && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK;
-      if (n_cu > 0 && lia_chain_plan_gemm(M, N, K, glu, n_cu, &cp) == 0) force_split = cp.split;
-    }
     // Two workgroup shapes.  RT = 1: 128 weight rows, LDS-DMA moves (128 + 16 MT)/128 bytes per weight byte, two
     // workgroups per CU up to M = 64.  RT = 2 (32 < M <= 128): 256 weight rows per workgroup halve the x share of
     // the LDS-DMA traffic (OPT-30B fc1 at M = 64: 4.9 -> 5.5 TB/s) but leave a quarter as many workgroups, so it is
@@ -1265,22 +909,20 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
       const double fill2 = waves2 / (double)(int)(waves2 + 0.999999);
       const bool fits = (size_t)split2 * M * N * sizeof(float) <= workspace_bytes || split2 == 1;
       if (M > 32 && M <= 128 && fill2 >= 0.85 && nchunks / split2 >= 32 && fits && force_split <= 0) { rt = 2; split = split2; }
-      if (g_skinny_variant == 1) rt = 1;
-      if (g_skinny_variant == 2 && M > 32 && M <= 128) { rt = 2; split = split2; }
     }
     // 64 < M <= 128 with 128-row workgroups: cut the x rows into two blocks of 64 (grid.z = 2, MT = 4).  Each
     // workgroup then stages half the x bytes, two fit a CU, and the second read of a weight tile comes from L2 / the
-    // Infinity Cache.  Worth it when the one-block grid cannot fill the chip (Llama-3-8B q/k/v, o, down at B = 128).
+    // Infinity Cache.  Worth it when the one-block grid cannot fill the chip (Llama-3-8B q/k/v, o at B = 128).
     bool mcut = false;
     if (rt == 1) {
       const int BN = 16 * WAVES;
       int tiles = (N + BN - 1) / BN;
       // ... unless K is long: with >= 24 chunks per slice at eight slices the one-block workgroups (every weight byte read once)
       // finish sooner than the two-block ones (Llama-3-8B down-proj, K = 14336, B = 128: 41.4 -> 37.7 us with the combine)
-      const bool long_k = M > 64 && M <= 128 && force_split <= 0 && tiles * 8 <= 256 && nchunks / 8 >= 24 && g_skinny_variant == 0 &&
+      const bool long_k = M > 64 && M <= 128 && force_split <= 0 && tiles * 8 <= 256 && nchunks / 8 >= 24 &&
                           (size_t)8 * M * N * sizeof(float) <= workspace_bytes;
       if (long_k) force_split = 8;
-      if (M > 64 && M <= 128 && force_split <= 0 && (tiles * 4 <= 256 || g_skinny_variant == 3) && g_skinny_variant != 4) {
+      if (M > 64 && M <= 128 && force_split <= 0 && tiles * 4 <= 256) {
         mcut = true;
         tiles *= 2;
       }
@@ -1300,104 +942,44 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     // r03: a gate | up projection (LIA_POST_SILU_MUL over interleaved rows) whose 128-row tiles alone fill >= 3/4 of the chip runs as
     // ONE slice of 128-row workgroups: no fp32 slabs (29 MB written and read back for Llama-3-8B at B = 128), no combine launch, and
     // the kernel's epilogue pairs the columns itself -- 72 -> 64 us per launch against two 256-row slices + the fused combine
-    // (tools/gemm_bench, cold weights).  The same split is used when the fusion is switched off (LIA_FUSE_COMBINE=0: plain store,
-    // then the stand-alone SiLU kernel), so both routes add the same products in the same order.
+    // (tools/gemm_bench, cold weights).  The same split is used when the fusion is switched off (plain store, then the stand-alone
+    // SiLU kernel), so both routes add the same products in the same order.
     LiaEpilogue ep_s = *ep;
     LiaOutMap om_s = *om;
     const bool glu_shape = post && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK && (N % (2 * LIA_GU_BLOCK)) == 0 &&
-                           M > 64 && M <= 128 && force_split <= 0 && (N + 127) / 128 >= 192 && g_skinny_variant == 0 && !ep->residual;
+                           M > 64 && M <= 128 && force_split <= 0 && (N + 127) / 128 >= 192 && !ep->residual;
     if (glu_shape) {
       rt = 1; mcut = false; split = 1;
-      if (post_done && g_fuse_combine && post->out && (post->ldo & 3) == 0) {
+      if (post_done && fuse && post->out && (post->ldo & 3) == 0) {
         ep_s.glu = 1;
         memset(&om_s, 0, sizeof(om_s));
         om_s.base[0] = post->out; om_s.ld[0] = post->ldo; om_s.seg_n = N / 2; om_s.T = 1;
         *post_done = 1;
-        ++g_fused_combines[LIA_POST_SILU_MUL];
+        if (opts) ++opts->fused_combines[LIA_POST_SILU_MUL];
       }
       ep = &ep_s;
       om = &om_s;
-    }
-    // ---- the chain kernel as the GEMM engine (see g_gemm_engine) ----
-    if (g_gemm_engine == 1 && M <= 128 && caller_split <= 0 && lia_chain_supported(M) == 0) {
-      static const int n_cu = [] { int dev = 0; (void)hipGetDevice(&dev); return lia_chain_cu_count(dev); }();
-      static unsigned* dummy_sync = nullptr;                      // a one-step program has no barrier; the kernel still wants a pointer
-      if (!dummy_sync && hipMalloc((void**)&dummy_sync, LIA_CHAIN_SYNC_BYTES) == hipSuccess) (void)hipMemset(dummy_sync, 0, LIA_CHAIN_SYNC_BYTES);
-      const bool want_glu = post && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK && (N % (2 * LIA_GU_BLOCK)) == 0 && post_done &&
-                            g_fuse_combine && post->out && (post->ldo & 3) == 0 && !ep->residual && !ep->bias && !ep->relu;
-      LiaChainPlan cp;
-      bool ok = n_cu > 0 && dummy_sync != nullptr;
-      bool glu_direct = false;
-      if (ok && want_glu && lia_chain_plan_gemm(M, N, K, 1, n_cu, &cp) == 0) glu_direct = true;
-      else if (ok) ok = lia_chain_plan_gemm(M, N, K, 0, n_cu, &cp) == 0;
-      if (ok && cp.split > 1 && (size_t)cp.split * M * N * sizeof(float) > workspace_bytes) ok = false;
-      if (ok && ep->glu && !glu_direct) ok = false;             // (the one-slice gate|up route above already redirected the output: skinny2 finishes it)
-      const bool glu_counted = ep->glu != 0;
-      if (ok) {
-        LiaChainProgram prog;
-        memset(&prog, 0, sizeof(prog));
-        prog.n_ops = 1;
-        LiaChainOp& o = prog.op[0];
-        o.kind = LIA_CH_GEMM;
-        o.M = M; o.N = N; o.K = K;
-        o.x = x; o.ldx = ldx; o.W = W; o.ldw = ldw;
-        o.bn = cp.bn; o.split = cp.split; o.cps = cp.cps; o.nchunks = nchunks;
-        o.n_items = ((N + cp.bn - 1) / cp.bn) * cp.split;
-        o.slices = cp.split;
-        if (glu_direct) {
-          o.direct = LIA_CH_DIRECT_GLU;
-          o.ep = *ep; o.ep.glu = 1;
-          memset(&o.om, 0, sizeof(o.om));
-          o.om.base[0] = post->out; o.om.ld[0] = post->ldo; o.om.seg_n = N / 2; o.om.T = 1;
-        } else if (cp.split == 1) {
-          o.direct = LIA_CH_DIRECT_PLAIN;
-          o.ep = *ep; o.om = *om;
-        } else {
-          o.direct = LIA_CH_DIRECT_NONE;
-          o.slab = workspace;
-        }
-        if (regime) *regime = 1;
-        if (ev0) (void)hipEventRecord(ev0, st);
-        if (lia_chain_launch(&prog, M, dummy_sync, nullptr, 0, n_cu, nullptr, 0u, st) == 0) {
-          if (ev1) (void)hipEventRecord(ev1, st);
-          ++g_chain_gemms;
-          if (glu_direct) { *post_done = 1; if (!glu_counted) ++g_fused_combines[LIA_POST_SILU_MUL]; return 0; }
-          if (cp.split > 1) {
-            if (post && post_done && launch_fused_combine(workspace, cp.split, M, N, *ep, *om, *post, st)) { *post_done = 1; return 0; }
-            long nq = (long)M * (N / 4);
-            hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace, cp.split, M, N, *ep, *om);
-          }
-          return 0;
-        }
-      }
     }
     if (split > nchunks) split = nchunks;
     if (split > 1 && (size_t)split * M * N * sizeof(float) > workspace_bytes) split = 1;
     int cps = (nchunks + split - 1) / split;
     split = (nchunks + cps - 1) / cps;
     if (regime) *regime = 1;
-    // How the split-K slabs are combined.  Default: the small second kernel.  lia_gemm_set_inlaunch_combine(1): by the last-arriving
-    // slice inside the launch (bit-identical, tests/test_gpu_fused_combine.py) -- measured on MI355X it is SLOWER at these sizes: a tile's
-    // slabs are 3-8 x 64 KB, the last arriver reads them alone while its CU's neighbours still stream, and every slice pays an
-    // agent-scope release (L2 write-back): OPT-30B M = 64 qkv 58 -> 78 us, fc2 77 -> 104 us, Llama-3-8B M = 128 qkv 23 -> 38 us
-    // (the two-kernel figures include the 5 us combine kernel).  cdna_hip_programming.md says as much: in-launch pays only
-    // when split x slab bytes per tile is a few tens of KB.
-    unsigned* tk = (split > 1 && tickets && g_inlaunch_combine && (long)((N + 127) / 128) * 16 <= LIA_GEMM_MAX_TICKETS) ? tickets : nullptr;
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
-    else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
+    if (M <= 16) launch_skinny2<1, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+    else if (M <= 32) launch_skinny2<2, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     else if (M <= 64) {
-      if (rt == 2) launch_skinny2<4, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
-      else launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
+      if (rt == 2) launch_skinny2<4, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+      else launch_skinny2<4, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     } else if (M <= 128) {
-      if (rt == 2) launch_skinny2<8, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
-      else if (mcut) launch_skinny2<4, 3, 0, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);   // default cache policy: the other x block re-reads W
-      else launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
+      if (rt == 2) launch_skinny2<8, 3, 1, WAVES, 2>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
+      else if (mcut) launch_skinny2<4, 3, 0, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);   // default cache policy: the other x block re-reads W
+      else launch_skinny2<8, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     }
-    else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, tk, *ep, *om, st);
+    else launch_skinny2<16, 3, 1, WAVES>(x, ldx, W, ldw, M, N, K, split, cps, workspace, *ep, *om, st);
     if (ev1) (void)hipEventRecord(ev1, st);
-    if (split > 1 && tk == nullptr) {
-      if (post && post_done && launch_fused_combine(workspace, split, M, N, *ep, *om, *post, st)) { *post_done = 1; return 0; }
+    if (split > 1) {
+      if (post && post_done && launch_fused_combine(workspace, split, M, N, *ep, *om, *post, opts, st)) { *post_done = 1; return 0; }
       long nq = (long)M * (N / 4);
       hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace,
                          split, M, N, *ep, *om);
@@ -1410,87 +992,31 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   // [M, 2F] intermediate of a prefill (7.5 GB per Llama-3-8B layer at B 128 x T 1024) is never written nor read back
   LiaEpilogue ep_t = *ep;
   LiaOutMap om_t = *om;
-  if (post && post_done && g_fuse_combine && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK &&
+  if (post && post_done && fuse && post->kind == LIA_POST_SILU_MUL && post->gu_block == LIA_GU_BLOCK &&
       (N % (2 * LIA_GU_BLOCK)) == 0 && post->out && (post->ldo & 7) == 0 && !ep->residual) {
     ep_t.glu = 1;
     memset(&om_t, 0, sizeof(om_t));
     om_t.base[0] = post->out; om_t.ld[0] = post->ldo; om_t.seg_n = N / 2; om_t.T = 1;
     *post_done = 1;
-    ++g_fused_combines[LIA_POST_SILU_MUL];
+    if (opts) ++opts->fused_combines[LIA_POST_SILU_MUL];
   }
   ep = &ep_t;
   om = &om_t;
-  if (M >= 1024 && N >= 512 && (g_tiled_variant == 257 || g_tiled_variant == 258)) {
-    int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
+  if (M >= 1024 && N >= 512) {
+    // 256 x 256 tiles: the phased kernel, or -- K / 64 odd or < 4 -- the one-barrier-per-K-tile kernel (same bits)
+    const int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
+    const bool phased = (K / T2_BK) >= 4 && ((K / T2_BK) & 1) == 0;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T3_HALF_BYTES);
-      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * T3_HALF_BYTES);
-      attr_set = true;
-    }
-    if (ev0) (void)hipEventRecord(ev0, st);
-#ifdef LIA_GEMM_ABLATE
-    // tools/gemm_bench.hip -DLIA_GEMM_ABLATE: timing-only variants (wrong results): 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA
-    static int abl = [] { const char* e = getenv("ABLATE"); return e ? atoi(e) : 0; }();
-#define T3_ABL(n) if (abl == n) { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<n, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T3_HALF_BYTES); \
-      hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<n, 4>), dim3(tiles_m * tiles_n), dim3(512), 4 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); \
-      if (ev1) (void)hipEventRecord(ev1, st); return 0; }
-    T3_ABL(1) T3_ABL(2) T3_ABL(3) T3_ABL(4) T3_ABL(5) T3_ABL(6) T3_ABL(7)
-    if (abl == 16 || abl == 14) {   // 5-slot ring: 16 = DMA only (no reads, no MFMA), 14 = reads + DMA, no MFMA
-      if (abl == 16) { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<6, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * T3_HALF_BYTES);
-        hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<6, 5>), dim3(tiles_m * tiles_n), dim3(512), 5 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); }
-      else { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256s_kernel<4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * T3_HALF_BYTES);
-        hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<4, 5>), dim3(tiles_m * tiles_n), dim3(512), 5 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); }
-      if (ev1) (void)hipEventRecord(ev1, st);
-      return 0;
-    }
-#endif
-    if (g_tiled_variant == 258)
-      hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<0, 5>), dim3(tiles_m * tiles_n), dim3(512), 5 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N,
-                         K, tiles_m, tiles_n, *ep, *om);
-    else
-      hipLaunchKernelGGL((lia_gemm_tiled256s_kernel<0, 4>), dim3(tiles_m * tiles_n), dim3(512), 4 * T3_HALF_BYTES, st, x, ldx, W, ldw, M, N,
-                         K, tiles_m, tiles_n, *ep, *om);
-    if (ev1) (void)hipEventRecord(ev1, st);
-    return 0;
-  }
-  if (M >= 1024 && N >= 512 && g_tiled_variant >= 259 && g_tiled_variant <= 262 && (K / T2_BK) >= 4 && ((K / T2_BK) & 1) == 0) {
-    int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
-    if (ev0) (void)hipEventRecord(ev0, st);
-#define T4_LAUNCH(D, PH, BUF) do {                                                                                         \
-      static bool set_ = false;                                                                                           \
-      if (!set_) { (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256p_kernel<D, PH, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF_BYTES); set_ = true; } \
-      hipLaunchKernelGGL((lia_gemm_tiled256p_kernel<D, PH, BUF>), dim3(tiles_m * tiles_n), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); \
-    } while (0)
-#ifdef LIA_GEMM_ABLATE
-    static int dbg = [] { const char* e = getenv("T4_DBG"); return e ? atoi(e) : 0; }();
-    if (g_tiled_variant == 259) switch (dbg) {
-      case 1: T4_LAUNCH(1, 4, 0); break; case 4: T4_LAUNCH(4, 4, 0); break; case 5: T4_LAUNCH(5, 4, 0); break; case 6: T4_LAUNCH(6, 4, 0); break;
-      case 8: T4_LAUNCH(8, 4, 0); break; default: T4_LAUNCH(0, 4, 0); break;
-    } else switch (dbg) {
-      case 1: T4_LAUNCH(1, 2, 1); break; case 4: T4_LAUNCH(4, 2, 1); break; case 5: T4_LAUNCH(5, 2, 1); break; case 6: T4_LAUNCH(6, 2, 1); break;
-      case 8: T4_LAUNCH(8, 2, 1); break; case 38: T4_LAUNCH(38, 2, 1); break; case 32: T4_LAUNCH(32, 2, 1); break; case 64: T4_LAUNCH(64, 2, 1); break; case 128: T4_LAUNCH(128, 2, 1); break; case 256: T4_LAUNCH(256, 2, 1); break; case 192: T4_LAUNCH(192, 2, 1); break; default: T4_LAUNCH(0, 2, 1); break;
-    }
-#else
-    if (g_tiled_variant == 259) T4_LAUNCH(0, 4, 0);
-    else if (g_tiled_variant == 260) T4_LAUNCH(0, 2, 0);
-    else if (g_tiled_variant == 261) T4_LAUNCH(0, 4, 1);
-    else T4_LAUNCH(0, 2, 1);
-#endif
-#undef T4_LAUNCH
-    if (ev1) (void)hipEventRecord(ev1, st);
-    return 0;
-  }
-  if (M >= 1024 && N >= 512 && (g_tiled_variant == 256 || (g_tiled_variant >= 259 && g_tiled_variant <= 262))) {
-    int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
-    static bool attr_set = false;
-    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF_BYTES);
       (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_TILE_BYTES);
       attr_set = true;
     }
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(lia_gemm_tiled256_kernel, dim3(tiles_m * tiles_n), dim3(512), 4 * T2_TILE_BYTES, st, x, ldx, W, ldw, M, N,
-                       K, tiles_m, tiles_n, *ep, *om);
+    if (phased)
+      hipLaunchKernelGGL(lia_gemm_tiled256p_kernel, dim3(tiles_m * tiles_n), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om);
+    else
+      hipLaunchKernelGGL(lia_gemm_tiled256_kernel, dim3(tiles_m * tiles_n), dim3(512), 4 * T2_TILE_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om);
     if (ev1) (void)hipEventRecord(ev1, st);
     return 0;
   }

@@ -54,32 +54,49 @@ static inline void team_barrier(LiaTeamBarrier& b, int& local_sense) {
 static inline int team_size() { return omp_in_parallel() ? omp_get_num_threads() : omp_get_max_threads(); }
 
 // a scratch block per thread that only grows (fp32 tiles of the linears, score rows of the attention)
-// A worker whose block cannot grow gets nullptr: it raises g_scratch_failed and SKIPS its share of the loop (every thread
+// A worker whose block cannot grow gets nullptr: it raises the CALL's failure flag and SKIPS its share of the loop (every thread
 // still meets every worksharing construct and team barrier, so the region ends normally); the entry point that opened the region
-// returns LIA_ERR_MEMORY afterwards (scratch_failed()).  g_scratch_limit: bytes per thread above which a request is refused
-// (lia_host_set_scratch_limit; 0 = no limit) -- a cap for memory-tight containers, and how the tests reach this path.
-static std::atomic<int> g_scratch_failed{0};
-static std::atomic<size_t> g_scratch_limit{0};
+// returns LIA_ERR_MEMORY afterwards.  State is per call and per thread, never per process (r05): a HostCall lives on the stack of
+// the exported entry point, the team's threads point at it for the length of the region (team_enter / team_leave), and the limit
+// it carries is the CALLING thread's (lia_host_thread_scratch_limit: bytes per thread above which a request is refused, 0 = none
+// -- a cap for memory-tight containers, and how the tests reach this path).  Two callers on two threads cannot see each other.
+struct HostCall {
+  std::atomic<int> failed{0};
+  size_t limit = 0;
+};
+static thread_local size_t tl_scratch_limit = 0;
+static thread_local HostCall* tl_call = nullptr;
+struct HostCallScope {          // on the calling thread; an entry point reached from another one (layer -> attention) joins its call
+  HostCall own;
+  const bool outer;
+  HostCallScope() : outer(tl_call == nullptr) {
+    if (outer) { own.limit = tl_scratch_limit; tl_call = &own; }
+  }
+  ~HostCallScope() { if (outer) tl_call = nullptr; }
+  HostCall* call() const { return tl_call; }
+  int result(const char* who) {
+    if (!tl_call->failed.exchange(0, std::memory_order_acq_rel)) return LIA_OK;
+    lia_set_error("%s: out of host memory (a worker thread could not get its scratch block)", who);
+    return LIA_ERR_MEMORY;
+  }
+};
+static inline HostCall* team_enter(HostCall* c) { HostCall* prev = tl_call; tl_call = c; return prev; }
+static inline void team_leave(HostCall* prev) { tl_call = prev; }
 static inline float* thread_scratch(size_t floats) {
   struct Block { float* p = nullptr; size_t n = 0; ~Block() { free(p); } };
   static thread_local Block blk;
+  HostCall* const call = tl_call;
   const size_t bytes = ((floats * sizeof(float)) + 63) & ~(size_t)63;
-  const size_t limit = g_scratch_limit.load(std::memory_order_relaxed);
-  if (limit && bytes > limit) { g_scratch_failed.store(1, std::memory_order_relaxed); return nullptr; }
+  if (call && call->limit && bytes > call->limit) { call->failed.store(1, std::memory_order_relaxed); return nullptr; }
   if (blk.n < floats) {
     free(blk.p);
     blk.p = (float*)aligned_alloc(64, bytes);
     blk.n = blk.p ? floats : 0;
-    if (!blk.p) { g_scratch_failed.store(1, std::memory_order_relaxed); return nullptr; }
+    if (!blk.p) { if (call) call->failed.store(1, std::memory_order_relaxed); return nullptr; }
   }
   return blk.p;
 }
-static inline int scratch_failed(const char* who) {
-  if (!g_scratch_failed.exchange(0, std::memory_order_acq_rel)) return LIA_OK;
-  lia_set_error("%s: out of host memory (a worker thread could not get its scratch block)", who);
-  return LIA_ERR_MEMORY;
-}
-extern "C" void lia_host_set_scratch_limit(size_t bytes_per_thread) { g_scratch_limit.store(bytes_per_thread, std::memory_order_relaxed); }
+extern "C" void lia_host_thread_scratch_limit(size_t bytes_per_thread) { tl_scratch_limit = bytes_per_thread; }
 
 // ------------------------------------------------------------------------------------------------
 // host attention
@@ -207,9 +224,15 @@ extern "C" int lia_host_attention(const lia_bf16* q, const lia_bf16* k, const li
     return LIA_ERR_INVALID;
   }
   if (n_threads <= 0) n_threads = omp_get_max_threads();
+  HostCallScope scope;
+  HostCall* const call = scope.call();
 #pragma omp parallel num_threads(n_threads)
-  host_attention_team(q, k, v, kcache, vcache, out, B, T, pos0, heads, head_dim, cache_batch, b0);
-  return scratch_failed("lia_host_attention");
+  {
+    HostCall* const prev = team_enter(call);
+    host_attention_team(q, k, v, kcache, vcache, out, B, T, pos0, heads, head_dim, cache_batch, b0);
+    team_leave(prev);
+  }
+  return scope.result("lia_host_attention");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,8 +570,13 @@ static void host_linear_skinny_team(const lia_bf16* x, const lia_bf16* w, const 
 }
 static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                                int M, int N, int K, int relu) {
+  HostCall* const call = tl_call;          // (the exported entry point's HostCallScope)
 #pragma omp parallel
-  host_linear_skinny_team(x, w, bias, residual, y, M, N, K, relu);
+  {
+    HostCall* const prev = team_enter(call);
+    host_linear_skinny_team(x, w, bias, residual, y, M, N, K, relu);
+    team_leave(prev);
+  }
 }
 
 // y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.
@@ -628,8 +656,9 @@ extern "C" int lia_host_linear(const lia_bf16* x, const lia_bf16* w, const lia_b
   if (M < 0 || N <= 0 || K <= 0 || K % 32) { lia_set_error("lia_host_linear: K=%d must be a multiple of 32", K); return LIA_ERR_INVALID; }
   if (int rc = host_isa_ok("lia_host_linear")) return rc;
   if (n_threads > 0) omp_set_num_threads(n_threads);
+  HostCallScope scope;
   host_linear(x, w, bias, residual, y, M, N, K, relu);
-  return scratch_failed("lia_host_linear");
+  return scope.result("lia_host_linear");
 }
 
 // the intermediates of a host layer (ln, q, k, v, attention output, h1: M x H each; f1: M x F), one growing block per CALLING thread
@@ -686,6 +715,7 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   if (n_threads > 0) omp_set_num_threads(n_threads);
   const lia_bf16* const* W = (const lia_bf16* const*)weights;
   const long M = (long)B * T;
+  HostCallScope scope;
   // the intermediates live in one scratch block per calling thread that only ever grows: std::vector zero-filled 9 MB per
   // decode call at the OPT-30B shape (single-threaded, ~3 % of the layer) and paid the page faults again after every free
   const size_t mh = ((size_t)M * H + 31) & ~(size_t)31, mf = ((size_t)M * F + 31) & ~(size_t)31, need = 6 * mh + mf;
@@ -697,12 +727,15 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
     // decode: the whole layer in ONE parallel region, the ops separated by a spinning barrier (see LiaTeamBarrier)
     LiaTeamBarrier bar;
     lia_bf16* const sc = scratch.p;          // (thread_local: the workers must see the CALLER's block, not their own)
+    HostCall* const call = scope.call();
 #pragma omp parallel
     {
+      HostCall* const prev = team_enter(call);
       int sense = 0;
       host_layer_team(d, W, x, y, kcache, vcache, cache_batch, B, T, pos0, b0, sc, mh, bar, sense);
+      team_leave(prev);
     }
-    return scratch_failed("lia_host_layer_forward");
+    return scope.result("lia_host_layer_forward");
   }
   host_layernorm(x, W[0], W[1], ln, M, H, d->ln_eps);
   host_linear(ln, W[4], W[5], nullptr, k, M, H, H, 0);
@@ -715,7 +748,7 @@ extern "C" int lia_host_layer_forward(const lia_layer_desc* d, const void* const
   host_linear(ln, W[12], W[13], nullptr, f1, M, F, H, 1);
   host_linear(f1, W[14], W[15], h1, y, M, H, F, 0);
   if (scratch.n * sizeof(lia_bf16) > ((size_t)64 << 20)) { free(scratch.p); scratch.p = nullptr; scratch.n = 0; }
-  return scratch_failed("lia_host_layer_forward");
+  return scope.result("lia_host_layer_forward");
 }
 
 // n_layers consecutive decode-sized layers (policy 1's decode step: every layer on the host) in ONE parallel region: the hidden
@@ -744,8 +777,11 @@ extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, co
   lia_bf16* const sc = layer_scratch(6 * mh + mf).p;     // (fetched by the caller: thread_local)
   if (!sc) { lia_set_error("lia_host_layers_forward: out of host memory"); return LIA_ERR_MEMORY; }
   LiaTeamBarrier bar;
+  HostCallScope scope;
+  HostCall* const call = scope.call();
 #pragma omp parallel
   {
+    HostCall* const prev = team_enter(call);
     int sense = 0;
     lia_bf16 *in = x, *out = y;
     for (int l = 0; l < n_layers; ++l) {
@@ -754,8 +790,9 @@ extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, co
       team_barrier(bar, sense);
       lia_bf16* t = in; in = out; out = t;
     }
+    team_leave(prev);
   }
-  if (int rc = scratch_failed("lia_host_layers_forward")) return rc;
+  if (int rc = scope.result("lia_host_layers_forward")) return rc;
   return n_layers & 1;
 }
 

@@ -1,214 +1,19 @@
-// "pack12": a lossless 12-bit wire format for streamed bf16 weights.
+// "pack10": a lossless wire format for streamed bf16 weights, 10.8 bits per value.
 //
-// The path is bound by the host link: 54.27 GB of OPT-30B weights cross PCIe on every forward at gpu%=10
-// (SURVEY.md section 8d).  Trained (and N(0, sigma) initialised) weights use only a handful of the 256 bf16
-// exponents, so each value is re-encoded as  sign(1) | mantissa(7)  +  a 4-bit exponent code:
-//     code 0..13 : exponent = e0 + code        (e0 = start of the best 14-binade window of this layer)
-//     code 14    : the value is +-0
-//     code 15    : escape -- the raw bf16 lives in a side list of {index, value} records
-// i.e. 12 bits instead of 16 (75 % of the bytes) for every value inside the window, and the decode is exact: the
-// streamer moves the packed bytes with the same pinned hipMemcpyAsync and a kernel on the copy stream rebuilds the
-// bf16 layer in the HBM slot (reads 0.75 B, writes 2 B per value: ~0.4 ms per OPT-30B layer, hidden behind the
-// next layer's copy).  The reference moves raw (TPP-blocked) bf16, load_layer lia/modeling_opt.py:270-293.
+// The path is bound by the host link: 54.27 GB of OPT-30B weights cross PCIe on every forward at gpu%=10.
+// Trained (and N(0, sigma) initialised) weights use only a handful of the 256 bf16 exponents, so each value is re-encoded as one
+// byte  sign(1) | mantissa(7)  (incompressible) + an entropy-coded exponent, and the decode is exact: the streamer moves the
+// encoded bytes with the same pinned hipMemcpyAsync into a per-slot staging area and a kernel on a side stream rebuilds the bf16
+// layer in the HBM slot (0.39 ms per OPT-30B layer, hidden behind the next layer's copy).  The reference moves raw (TPP-blocked)
+// bf16, load_layer lia/modeling_opt.py:270-293.
 //
-// Buffer: [header 256 B][plane A: n bytes sign|mantissa][plane B: n/2 bytes, two codes per byte][escapes: 8 B each]
+// History: pack12 (r01: one 4-bit code per value against a 14-binade window, 12 bits) and pack11 (r01: a 3-bit code in bit-planes
+// + a 4-bit overflow stream, 11.13 bits) were the first two generations; pack10 replaced them as the default in r02 and they were
+// removed in r05 (git history; LABNOTES.md has their measurements: 88.7 / 95.7 / 98.6 decode tokens/s for 12 / 11 / 10).
 #include "lia_common.h"
 #include <string.h>
 
-struct LiaPack12Header {
-  uint32_t magic;        // 'LP12'
-  uint32_t e0;           // first exponent of the window
-  uint64_t n;            // bf16 values (multiple of 16)
-  uint32_t n_esc;        // escape records that follow plane B
-  uint32_t esc_cap;      // records the buffer has room for (encode only)
-  uint64_t off_a, off_b, off_esc;
-  uint32_t overflow;     // encode: more escapes than room -> the caller must ship the layer raw
-  uint32_t pad[51];
-};
-static_assert(sizeof(LiaPack12Header) == 256, "header is 256 bytes");
-
-constexpr uint32_t LP12_MAGIC = 0x3231504cu;
-
-__global__ __launch_bounds__(256) void lia_pack12_hist_kernel(const bf16_t* __restrict__ src, size_t n, unsigned* __restrict__ hist) {
-  __shared__ unsigned h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (; i < n; i += stride) atomicAdd(&h[(src[i] >> 7) & 0xff], 1u);
-  __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void lia_pack12_encode_kernel(const bf16_t* __restrict__ src, char* __restrict__ dst) {
-  LiaPack12Header* hd = (LiaPack12Header*)dst;
-  const size_t n16 = hd->n / 16;
-  const uint32_t e0 = hd->e0;
-  uint8_t* pa = (uint8_t*)(dst + hd->off_a);
-  uint8_t* pb = (uint8_t*)(dst + hd->off_b);
-  uint2* esc = (uint2*)(dst + hd->off_esc);
-  size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (; g < n16; g += stride) {
-    const uint4 v0 = *(const uint4*)(src + g * 16), v1 = *(const uint4*)(src + g * 16 + 8);
-    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    uint32_t a[4] = {0, 0, 0, 0}, b[2] = {0, 0};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t x = (w[k >> 1] >> ((k & 1) * 16)) & 0xffff;
-      const uint32_t ex = (x >> 7) & 0xff;
-      uint32_t code = ex - e0;   // wraps for ex < e0 -> large -> escape
-      if ((x & 0x7fff) == 0) code = 14;
-      else if (code > 13) {
-        code = 15;
-        unsigned slot = atomicAdd(&hd->n_esc, 1u);
-        if (slot < hd->esc_cap) esc[slot] = uint2{(uint32_t)(g * 16 + k), x};
-        else hd->overflow = 1;
-      }
-      a[k >> 2] |= (((x >> 8) & 0x80) | (x & 0x7f)) << ((k & 3) * 8);
-      b[k >> 3] |= code << ((k & 7) * 4);
-    }
-    *(uint4*)(pa + g * 16) = uint4{a[0], a[1], a[2], a[3]};
-    *(uint2*)(pb + g * 8) = uint2{b[0], b[1]};
-  }
-}
-
-__global__ __launch_bounds__(256) void lia_pack12_decode_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
-  const LiaPack12Header* hd = (const LiaPack12Header*)src;
-  const size_t n16 = hd->n / 16;
-  const uint32_t e0 = hd->e0;
-  const uint8_t* pa = (const uint8_t*)(src + hd->off_a);
-  const uint8_t* pb = (const uint8_t*)(src + hd->off_b);
-  size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (; g < n16; g += stride) {
-    const uint4 av = *(const uint4*)(pa + g * 16);
-    const uint2 bv = *(const uint2*)(pb + g * 8);
-    const uint32_t a[4] = {av.x, av.y, av.z, av.w}, b[2] = {bv.x, bv.y};
-    uint32_t o[8];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t sm = (a[k >> 2] >> ((k & 3) * 8)) & 0xff;
-      const uint32_t code = (b[k >> 3] >> ((k & 7) * 4)) & 0xf;
-      uint32_t x = ((sm & 0x80) << 8);
-      if (code < 14) x |= ((e0 + code) << 7) | (sm & 0x7f);
-      if (k & 1) o[k >> 1] |= x << 16; else o[k >> 1] = x;
-    }
-    *(uint4*)(dst + g * 16) = uint4{o[0], o[1], o[2], o[3]};
-    *(uint4*)(dst + g * 16 + 8) = uint4{o[4], o[5], o[6], o[7]};
-  }
-}
-
-__global__ __launch_bounds__(256) void lia_pack12_patch_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
-  const LiaPack12Header* hd = (const LiaPack12Header*)src;
-  const uint2* esc = (const uint2*)(src + hd->off_esc);
-  const unsigned n = hd->n_esc;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    uint2 r = esc[i];
-    dst[r.x] = (bf16_t)r.y;
-  }
-}
-
 static inline size_t lp12_align(size_t v) { return (v + 255) / 256 * 256; }
-
-// room an encode of n values may need (escape capacity n/16 records)
-extern "C" size_t lia_pack12_bound(size_t n_values) {
-  return 256 + lp12_align(n_values) + lp12_align(n_values / 2) + lp12_align((n_values / 16) * 8);
-}
-
-// Encode n_values bf16 (device) into dst (device, >= lia_pack12_bound).  Synchronous (model placement time).
-// *out_bytes = bytes to ship (header + planes + the escape records actually used).  Returns 0, or 1 if the layer
-// does not fit the format (too many escapes) and must travel raw.
-extern "C" int lia_pack12_encode(const bf16_t* src, size_t n_values, char* dst, size_t dst_capacity, size_t* out_bytes) {
-  if (!src || !dst || !out_bytes || (n_values % 16) || dst_capacity < lia_pack12_bound(n_values)) return -1;
-  unsigned* hist = nullptr;
-  if (hipMalloc((void**)&hist, 256 * sizeof(unsigned)) != hipSuccess) return -2;
-  (void)hipMemset(hist, 0, 256 * sizeof(unsigned));
-  hipLaunchKernelGGL(lia_pack12_hist_kernel, dim3(1024), dim3(256), 0, 0, src, n_values, hist);
-  unsigned h[256];
-  if (hipMemcpy(h, hist, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(hist); return -3; }
-  (void)hipFree(hist);
-  unsigned long long best = 0, cur = 0;
-  int e0 = 1;
-  for (int e = 1; e <= 255 - 14; ++e) {   // exponent 0 (zero / denormals) is never inside the window
-    cur = 0;
-    for (int k = 0; k < 14; ++k) cur += h[e + k];
-    if (cur > best) { best = cur; e0 = e; }
-  }
-  LiaPack12Header hd;
-  memset(&hd, 0, sizeof(hd));
-  hd.magic = LP12_MAGIC; hd.e0 = (uint32_t)e0; hd.n = n_values; hd.n_esc = 0; hd.esc_cap = (uint32_t)(n_values / 16);
-  hd.off_a = 256; hd.off_b = hd.off_a + lp12_align(n_values); hd.off_esc = hd.off_b + lp12_align(n_values / 2);
-  if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
-  hipLaunchKernelGGL(lia_pack12_encode_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
-  if (hipMemcpy(&hd, dst, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) return -3;
-  if (hd.overflow || hd.n_esc > hd.esc_cap) return 1;
-  *out_bytes = (size_t)hd.off_esc + lp12_align((size_t)hd.n_esc * 8);
-  return 0;
-}
-
-// Rebuild the bf16 values: asynchronous on `st`.  src/dst are device pointers; the header is read on the device.
-extern "C" void lia_pack12_decode_launch(const char* src, bf16_t* dst, size_t n_values, hipStream_t st) {
-  size_t n16 = n_values / 16;
-  unsigned blocks = (unsigned)((n16 + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  if (blocks == 0) return;
-  hipLaunchKernelGGL(lia_pack12_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
-  hipLaunchKernelGGL(lia_pack12_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
-}
-
-// =====================================================================================================
-// "pack11": the denser sibling.  Same sign|mantissa byte, but the exponent code is 3 bits (the best 7-binade
-// window of the layer, 97.6 % of N(0, sigma) weights) stored as three bit-planes; code 7 sends the value to an
-// overflow stream of 4-bit codes (14-binade window / +-0 / escape record, exactly pack12's alphabet).  A table with
-// one 32-bit overflow offset per 1024 values makes the decode embarrassingly parallel: a wave handles 1024 values,
-// each lane 16, the lane's position in the overflow stream is the table entry plus a wave prefix sum of popcounts.
-// 8 + 3 + 0.0244*4 + 0.03 = 11.13 bits per value for N(0, sigma) weights = 69.6 % of the raw bytes.
-// Buffer: [header 256][plane A: n][b0: n/8][b1: n/8][b2: n/8][table: n/1024 u32][overflow nibbles][escapes 8 B each]
-// =====================================================================================================
-struct LiaPack11Header {
-  uint32_t magic;        // 'LP11'
-  uint32_t e0;           // first exponent of the 7-binade primary window
-  uint32_t e1;           // first exponent of the 14-binade overflow window
-  uint32_t n_esc;
-  uint64_t n;            // values, multiple of 1024
-  uint64_t n_ovf;        // overflow nibbles
-  uint64_t off_a, off_b0, off_b1, off_b2, off_tab, off_ovf, off_esc;
-  uint32_t esc_cap;
-  uint32_t overflow;
-  uint64_t ovf_cap;      // nibbles the buffer has room for
-  uint32_t pad[38];
-};
-static_assert(sizeof(LiaPack11Header) == 256, "header is 256 bytes");
-constexpr uint32_t LP11_MAGIC = 0x3131504cu;
-
-__device__ __forceinline__ uint32_t lp11_codes(const uint32_t (&w)[8], uint32_t e0, uint32_t e1, uint32_t (&a)[4], uint32_t& b0,
-                                               uint32_t& b1, uint32_t& b2, uint64_t& nibs, uint32_t& esc_mask) {
-  // returns the overflow mask (bit k = value k uses the overflow stream); nibs = its 4-bit codes packed in order
-  b0 = b1 = b2 = 0; nibs = 0; esc_mask = 0;
-  a[0] = a[1] = a[2] = a[3] = 0;
-  uint32_t ovf = 0;
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const uint32_t x = (w[k >> 1] >> ((k & 1) * 16)) & 0xffff;
-    const uint32_t ex = (x >> 7) & 0xff;
-    uint32_t c = ex - e0;
-    const bool zero = (x & 0x7fff) == 0;
-    if (zero || c > 6) {
-      c = 7;
-      uint32_t nib = ex - e1;
-      if (zero) nib = 14;
-      else if (nib > 13) { nib = 15; esc_mask |= 1u << k; }
-      nibs |= (uint64_t)nib << (4 * cnt);
-      ++cnt;
-      ovf |= 1u << k;
-    }
-    b0 |= (c & 1) << k; b1 |= ((c >> 1) & 1) << k; b2 |= ((c >> 2) & 1) << k;
-    a[k >> 2] |= (((x >> 8) & 0x80) | (x & 0x7f)) << ((k & 3) * 8);
-  }
-  return ovf;
-}
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
   int inc = v;
@@ -221,162 +26,6 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
   return inc - v;
 }
 
-// pass 1: overflow nibbles per 1024-value block
-__global__ __launch_bounds__(256) void lia_pack11_count_kernel(const bf16_t* __restrict__ src, char* __restrict__ dst) {
-  LiaPack11Header* hd = (LiaPack11Header*)dst;
-  const size_t nblk = hd->n / 1024;
-  uint32_t* tab = (uint32_t*)(dst + hd->off_tab);
-  const int lane = threadIdx.x & 63;
-  size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const size_t stride = (size_t)gridDim.x * 4;
-  for (; blk < nblk; blk += stride) {
-    const bf16_t* p = src + blk * 1024 + lane * 16;
-    const uint4 v0 = *(const uint4*)p, v1 = *(const uint4*)(p + 8);
-    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    uint32_t a[4], b0, b1, b2, em;
-    uint64_t nibs;
-    uint32_t ovf = lp11_codes(w, hd->e0, hd->e1, a, b0, b1, b2, nibs, em);
-    int total;
-    (void)wave_excl_scan(__popc(ovf), lane, total);
-    if (lane == 0) tab[blk] = (uint32_t)total;
-  }
-}
-
-// exclusive scan of the block counts in place (one workgroup; n/1024 entries), total -> header
-__global__ __launch_bounds__(1024) void lia_pack11_scan_kernel(char* __restrict__ dst) {
-  LiaPack11Header* hd = (LiaPack11Header*)dst;
-  const size_t nblk = hd->n / 1024;
-  uint32_t* tab = (uint32_t*)(dst + hd->off_tab);
-  __shared__ uint32_t wsum[16];
-  __shared__ unsigned long long carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (size_t base = 0; base < nblk; base += 1024) {
-    const size_t i = base + threadIdx.x;
-    int v = i < nblk ? (int)tab[i] : 0;
-    int wtot;
-    int ex = wave_excl_scan(v, lane, wtot);
-    if (lane == 63) wsum[wave] = (uint32_t)wtot;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int k = 0; k < wave; ++k) woff += wsum[k];
-    const unsigned long long c = carry;
-    if (i < nblk) tab[i] = (uint32_t)(c + woff + ex);
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = c + woff + ex + v;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) hd->n_ovf = carry;
-}
-
-// pass 2: write the planes, the overflow nibbles (atomicOr into a zeroed stream) and the escape records
-__global__ __launch_bounds__(256) void lia_pack11_encode_kernel(const bf16_t* __restrict__ src, char* __restrict__ dst) {
-  LiaPack11Header* hd = (LiaPack11Header*)dst;
-  const size_t nblk = hd->n / 1024;
-  uint8_t* pa = (uint8_t*)(dst + hd->off_a);
-  uint16_t *p0 = (uint16_t*)(dst + hd->off_b0), *p1 = (uint16_t*)(dst + hd->off_b1), *p2 = (uint16_t*)(dst + hd->off_b2);
-  const uint32_t* tab = (const uint32_t*)(dst + hd->off_tab);
-  uint32_t* ovfw = (uint32_t*)(dst + hd->off_ovf);
-  uint2* esc = (uint2*)(dst + hd->off_esc);
-  const int lane = threadIdx.x & 63;
-  size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const size_t stride = (size_t)gridDim.x * 4;
-  for (; blk < nblk; blk += stride) {
-    const size_t g = blk * 64 + lane;           // 16-value group index
-    const bf16_t* p = src + g * 16;
-    const uint4 v0 = *(const uint4*)p, v1 = *(const uint4*)(p + 8);
-    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    uint32_t a[4], b0, b1, b2, em;
-    uint64_t nibs;
-    const uint32_t ovf = lp11_codes(w, hd->e0, hd->e1, a, b0, b1, b2, nibs, em);
-    *(uint4*)(pa + g * 16) = uint4{a[0], a[1], a[2], a[3]};
-    p0[g] = (uint16_t)b0; p1[g] = (uint16_t)b1; p2[g] = (uint16_t)b2;
-    const int cnt = __popc(ovf);
-    int total;
-    const int ex = wave_excl_scan(cnt, lane, total);
-    if (cnt) {
-      const uint64_t off = (uint64_t)tab[blk] + ex;        // nibble offset of this lane's first overflow code
-      if (off + cnt > hd->ovf_cap) hd->overflow = 1;
-      else {
-        // up to 16 nibbles = 64 bits, starting at any nibble: spread over up to three 32-bit words
-        const uint64_t word = off >> 3;
-        const int sh = (int)(off & 7) * 4;
-        atomicOr(&ovfw[word], (uint32_t)(nibs << sh));
-        const uint64_t rest = sh ? (nibs >> (32 - sh)) : (nibs >> 32);
-        if (cnt * 4 + sh > 32) atomicOr(&ovfw[word + 1], (uint32_t)rest);
-        if (cnt * 4 + sh > 64) atomicOr(&ovfw[word + 2], (uint32_t)(rest >> 32));
-      }
-    }
-    uint32_t m = em;
-    while (m) {
-      const int k = __ffs(m) - 1;
-      m &= m - 1;
-      const uint32_t x = (w[k >> 1] >> ((k & 1) * 16)) & 0xffff;
-      unsigned slot = atomicAdd(&hd->n_esc, 1u);
-      if (slot < hd->esc_cap) esc[slot] = uint2{(uint32_t)(g * 16 + k), x};
-      else hd->overflow = 1;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void lia_pack11_decode_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
-  const LiaPack11Header* hd = (const LiaPack11Header*)src;
-  const size_t nblk = hd->n / 1024;
-  const uint32_t e0 = hd->e0, e1 = hd->e1;
-  const uint8_t* pa = (const uint8_t*)(src + hd->off_a);
-  const uint16_t *p0 = (const uint16_t*)(src + hd->off_b0), *p1 = (const uint16_t*)(src + hd->off_b1), *p2 = (const uint16_t*)(src + hd->off_b2);
-  const uint32_t* tab = (const uint32_t*)(src + hd->off_tab);
-  const uint32_t* ovfw = (const uint32_t*)(src + hd->off_ovf);
-  const int lane = threadIdx.x & 63;
-  size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const size_t stride = (size_t)gridDim.x * 4;
-  for (; blk < nblk; blk += stride) {
-    const size_t g = blk * 64 + lane;
-    const uint4 av = *(const uint4*)(pa + g * 16);
-    const uint32_t a[4] = {av.x, av.y, av.z, av.w};
-    const uint32_t b0 = p0[g], b1 = p1[g], b2 = p2[g];
-    const uint32_t ovf = b0 & b1 & b2;
-    const int cnt = __popc(ovf);
-    int total;
-    const int ex = wave_excl_scan(cnt, lane, total);
-    uint64_t nibs = 0;
-    if (cnt) {
-      const uint64_t off = (uint64_t)tab[blk] + ex;
-      const uint64_t word = off >> 3;
-      const int sh = (int)(off & 7) * 4;
-      const uint64_t lo = (uint64_t)ovfw[word] | ((uint64_t)ovfw[word + 1] << 32);
-      nibs = lo >> sh;
-      if (sh && cnt * 4 + sh > 64) nibs |= (uint64_t)ovfw[word + 2] << (64 - sh);
-    }
-    uint32_t o[8];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t sm = (a[k >> 2] >> ((k & 3) * 8)) & 0xff;
-      const uint32_t c = ((b0 >> k) & 1) | (((b1 >> k) & 1) << 1) | (((b2 >> k) & 1) << 2);
-      uint32_t x = (sm & 0x80) << 8;
-      if (c < 7) x |= ((e0 + c) << 7) | (sm & 0x7f);
-      else {
-        const uint32_t nib = (uint32_t)(nibs & 0xf);
-        nibs >>= 4;
-        if (nib < 14) x |= ((e1 + nib) << 7) | (sm & 0x7f);
-      }
-      if (k & 1) o[k >> 1] |= x << 16; else o[k >> 1] = x;
-    }
-    *(uint4*)(dst + g * 16) = uint4{o[0], o[1], o[2], o[3]};
-    *(uint4*)(dst + g * 16 + 8) = uint4{o[4], o[5], o[6], o[7]};
-  }
-}
-
-__global__ __launch_bounds__(256) void lia_pack11_patch_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
-  const LiaPack11Header* hd = (const LiaPack11Header*)src;
-  const uint2* esc = (const uint2*)(src + hd->off_esc);
-  const unsigned n = hd->n_esc;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    uint2 r = esc[i];
-    dst[r.x] = (bf16_t)r.y;
-  }
-}
 
 // Move `bytes` at dst+from down to dst+to (to <= from) on the device; overlapping ranges go through a temporary
 // (a device-to-device hipMemcpy of overlapping ranges is undefined).
@@ -391,63 +40,10 @@ static bool lp_move_down(char* dst, size_t to, size_t from, size_t bytes) {
   return ok;
 }
 
-// room an encode may need: overflow capacity n/4 nibbles (25 % of the values), escapes n/16 records
-extern "C" size_t lia_pack11_bound(size_t n_values) {
-  return 256 + lp12_align(n_values) + 3 * lp12_align(n_values / 8) + lp12_align((n_values / 1024) * 4 + 16) +
-         lp12_align(n_values / 8 + 16) + lp12_align((n_values / 16) * 8);
-}
-
-// Same contract as lia_pack12_encode; n_values must be a multiple of 1024.  Returns 1 when the layer does not fit.
-extern "C" int lia_pack11_encode(const bf16_t* src, size_t n_values, char* dst, size_t dst_capacity, size_t* out_bytes) {
-  if (!src || !dst || !out_bytes || (n_values % 1024) || dst_capacity < lia_pack11_bound(n_values)) return -1;
-  unsigned* hist = nullptr;
-  if (hipMalloc((void**)&hist, 256 * sizeof(unsigned)) != hipSuccess) return -2;
-  (void)hipMemset(hist, 0, 256 * sizeof(unsigned));
-  hipLaunchKernelGGL(lia_pack12_hist_kernel, dim3(1024), dim3(256), 0, 0, src, n_values, hist);
-  unsigned h[256];
-  if (hipMemcpy(h, hist, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(hist); return -3; }
-  (void)hipFree(hist);
-  auto best_window = [&](int width) {
-    unsigned long long best = 0;
-    int e = 1;
-    for (int s = 1; s <= 255 - width; ++s) {
-      unsigned long long cur = 0;
-      for (int k = 0; k < width; ++k) cur += h[s + k];
-      if (cur > best) { best = cur; e = s; }
-    }
-    return e;
-  };
-  LiaPack11Header hd;
-  memset(&hd, 0, sizeof(hd));
-  hd.magic = LP11_MAGIC; hd.e0 = (uint32_t)best_window(7); hd.e1 = (uint32_t)best_window(14); hd.n = n_values;
-  hd.esc_cap = (uint32_t)(n_values / 16); hd.ovf_cap = n_values / 4;
-  hd.off_a = 256; hd.off_b0 = hd.off_a + lp12_align(n_values); hd.off_b1 = hd.off_b0 + lp12_align(n_values / 8);
-  hd.off_b2 = hd.off_b1 + lp12_align(n_values / 8); hd.off_tab = hd.off_b2 + lp12_align(n_values / 8);
-  hd.off_ovf = hd.off_tab + lp12_align((n_values / 1024) * 4 + 16);
-  const size_t ovf_bytes = lp12_align(n_values / 8 + 16);
-  hd.off_esc = hd.off_ovf + ovf_bytes;   // provisional: escapes are moved right behind the used overflow bytes below
-  if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
-  (void)hipMemset(dst + hd.off_ovf, 0, ovf_bytes);
-  hipLaunchKernelGGL(lia_pack11_count_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
-  hipLaunchKernelGGL(lia_pack11_scan_kernel, dim3(1), dim3(1024), 0, 0, dst);
-  hipLaunchKernelGGL(lia_pack11_encode_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
-  if (hipMemcpy(&hd, dst, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) return -3;
-  if (hd.overflow || hd.n_esc > hd.esc_cap || hd.n_ovf > hd.ovf_cap) return 1;
-  // compact: escape records directly after the overflow nibbles actually used
-  const size_t used_ovf = lp12_align((size_t)((hd.n_ovf + 1) / 2) + 16);
-  const size_t new_esc = hd.off_ovf + used_ovf;
-  if (!lp_move_down(dst, new_esc, hd.off_esc, (size_t)hd.n_esc * 8)) return -3;
-  hd.off_esc = new_esc;
-  if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
-  *out_bytes = (size_t)hd.off_esc + lp12_align((size_t)hd.n_esc * 8);
-  return 0;
-}
-
 // =====================================================================================================
-// "pack10": three-level exponent code, the closest of the three to the exponent entropy (10.55 bits per value for
-// N(0, sigma) weights).  Level 1: 2 bits per value as two bit-planes - codes 0..2 = the three most frequent
+// The format: a three-level exponent code, close to the exponent entropy (10.55 bits per value for N(0, sigma) weights).  Level 1: 2 bits per value as two bit-planes - codes 0..2 = the three most frequent
 // exponents, 3 = "see level 2".  Level 2: 2 bits per level-1 escape, compacted in value order - codes
-// 0..2 = the next three exponents, 3 = "see level 3".  Level 3: pack12's 4-bit alphabet per level-2 escape (14-binade
+// 0..2 = the next three exponents, 3 = "see level 3".  Level 3: a 4-bit code per level-2 escape (14-binade
 // window, 14 = exponent 0 i.e. +-0 and denormals, 15 = escape record).  The symbol sets are arbitrary exponents, so +-0
 // and denormals need no special case.
 // The symbol sets are PER REGION of 65536 values (a table of {sym1, sym2, e3} entries behind the header, built on the
@@ -897,7 +493,9 @@ extern "C" size_t lia_pack10_bound(size_t n_values) {
          2 * lp12_align(n_values / 4 + 16) + lp12_align((n_values / 16) * 8);
 }
 
-// Same contract as lia_pack12_encode; n_values must be a multiple of 1024.  Returns 1 when the layer does not fit.
+// Encode n_values bf16 (device; a multiple of 1024) into dst (device, >= lia_pack10_bound).  Synchronous (model placement time).
+// *out_bytes = bytes to ship (header + tables + planes + the level-2 / level-3 streams and escape records actually used).
+// Returns 0, 1 if the layer does not fit the format (too many escapes) and must travel raw, negative on error.
 extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, size_t dst_capacity, size_t* out_bytes) {
   if (!src || !dst || !out_bytes || (n_values % 1024) || dst_capacity < lia_pack10_bound(n_values)) return -1;
   LiaPack10Header hd;
@@ -936,28 +534,13 @@ extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, 
 // Decode either format (the header's magic says which); asynchronous on `st`.
 // ev0 / ev1 (nullable): recorded on `st` immediately around the MAIN decode kernel (lia_stream_decode_stats; the patch kernel
 // behind it -- a few hundred escape records -- is outside the bracket, as a profiler's per-kernel duration would have it).
-extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, int format, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-  if (format == 10) {
-    size_t nblk = n_values / 1024;
-    unsigned blocks = (unsigned)((nblk + 3) / 4);
-    if (blocks > LP10_DECODE_GRID) blocks = LP10_DECODE_GRID;
-    if (blocks == 0) return;
-    if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(lia_pack10_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
-    if (ev1) (void)hipEventRecord(ev1, st);
-    hipLaunchKernelGGL(lia_pack10_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
-  } else if (format == 11) {
-    size_t nblk = n_values / 1024;
-    unsigned blocks = (unsigned)((nblk + 3) / 4);
-    if (blocks > 8192) blocks = 8192;
-    if (blocks == 0) return;
-    if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(lia_pack11_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
-    if (ev1) (void)hipEventRecord(ev1, st);
-    hipLaunchKernelGGL(lia_pack11_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
-  } else {
-    if (ev0) (void)hipEventRecord(ev0, st);
-    lia_pack12_decode_launch(src, dst, n_values, st);
-    if (ev1) (void)hipEventRecord(ev1, st);
-  }
+extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  const size_t nblk = n_values / 1024;
+  unsigned blocks = (unsigned)((nblk + 3) / 4);
+  if (blocks > LP10_DECODE_GRID) blocks = LP10_DECODE_GRID;
+  if (blocks == 0) return;
+  if (ev0) (void)hipEventRecord(ev0, st);
+  hipLaunchKernelGGL(lia_pack10_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
+  if (ev1) (void)hipEventRecord(ev1, st);
+  hipLaunchKernelGGL(lia_pack10_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
 }

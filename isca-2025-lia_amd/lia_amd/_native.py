@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "liblia_hip.so")
 
 LIA_OK, LIA_ERR_INVALID, LIA_ERR_MEMORY, LIA_ERR_HIP, LIA_ERR_MISSING = 0, -1, -2, -3, -4
+LIA_OPT_FUSE_COMBINE = 1           # lia_ctx_set_option keys (include/lia_hip.h)
+LIA_CNT_FUSED_COMBINE = 100        # lia_ctx_get_counter(ctx, LIA_CNT_FUSED_COMBINE + kind), kind = 1 LayerNorm, 2 RMSNorm, 3 SiLU*up, 4 RoPE
 
 c_void_p, c_int, c_long, c_size_t, c_float, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t,
                                                          ctypes.c_float, ctypes.c_double)
@@ -88,21 +90,14 @@ SIGNATURES = {
     "lia_decode_layers": (c_int, [c_void_p, ctypes.POINTER(LayerDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lia_llama_decode_layers": (c_int, [c_void_p, ctypes.POINTER(LlamaDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_void_p]),
-    "lia_set_fused_decode": (None, [c_int]),
-    "lia_gemm_set_split_policy": (None, [c_int]),
-    "lia_chain_launch_count": (c_long, []),
-    "lia_gemm_set_engine": (None, [c_int]),
-    "lia_gemm_set_fuse_combine": (None, [c_int]),
-    "lia_gemm_set_inlaunch_combine": (None, [c_int]),
-    "lia_gemm_set_tiled_variant": (None, [c_int]),
-    "lia_gemm_fused_combine_count": (ctypes.c_long, [c_int]),
-    "lia_gemm_chain_engine_count": (c_long, []),
+    "lia_ctx_set_option": (c_int, [c_void_p, c_int, c_long]),
+    "lia_ctx_get_counter": (c_long, [c_void_p, c_int]),
     "lia_host_layer_forward": (c_int, [ctypes.POINTER(LayerDesc), ctypes.POINTER(c_void_p * 16), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "lia_host_layers_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "lia_host_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_int]),
-    "lia_host_set_scratch_limit": (None, [ctypes.c_size_t]),
+    "lia_host_thread_scratch_limit": (None, [ctypes.c_size_t]),
     "lia_host_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int]),
     "lia_host_has_avx512_bf16": (c_int, []),
     "lia_stream_create": (c_int, [c_void_p, c_int, c_size_t, ctypes.POINTER(c_void_p)]),
@@ -112,13 +107,9 @@ SIGNATURES = {
     "lia_stream_begin": (c_int, [c_void_p, c_int]),
     "lia_stream_copy_chunk": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, c_int]),
     "lia_stream_mark_ready": (c_int, [c_void_p, c_int]),
-    "lia_pack12_bound": (c_size_t, [c_size_t]),
-    "lia_pack12_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
     "lia_blit": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "lia_pack10_bound": (c_size_t, [c_size_t]),
     "lia_pack10_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
-    "lia_pack11_bound": (c_size_t, [c_size_t]),
-    "lia_pack11_encode": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
     "lia_pack_decode": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "lia_stream_prefetch_packed": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_size_t, c_int, c_int]),
     "lia_stream_copy_chunk_packed": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, c_int]),

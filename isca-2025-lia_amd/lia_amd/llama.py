@@ -113,7 +113,7 @@ class LiaLlamaModel:
 
     @classmethod
     def random_init(cls, shape, seed=0, n_gpu_layers=None, pin_weight=True, pack=0):
-        """pack = 0 / 10 / 11 / 12: wire format of the pinned streamed layers (lia_pack12.hip), as for the OPT model"""
+        """pack = 0 / 10: wire format of the pinned streamed layers (lia_pack10.hip), as for the OPT model"""
         self = cls(shape)
         n_gpu = shape.layers if n_gpu_layers is None else n_gpu_layers
         from . import hostinfo
@@ -187,7 +187,7 @@ class LlamaScheduler:
         from .scheduler import default_stream_format
         self.model, self.device, self.n_slots = model, device, n_slots
         fmt = default_stream_format() if pack is None else pack
-        self.pack = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, 0: 0, 10: 10, 11: 11, 12: 12, False: 0, True: 12}[fmt]
+        self.pack = {"raw": 0, "pack10": 10, 0: 0, 10: 10, False: 0, True: 10}[fmt]
         self.ctx = self.pipe = None
         self.hidden, self.resident, self.tables = {}, {}, None
         self.prefill_tail = True      # last layer of a prefill: last position only behind q|k|v (False: every position)

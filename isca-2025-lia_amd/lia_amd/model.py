@@ -136,7 +136,7 @@ class LayerStore:
     def __init__(self, desc, offsets, total_bytes):
         self.desc, self.offsets, self.nbytes = desc, offsets, total_bytes
         self.tier = None          # "device" | "pinned" | "cxl" | "mapped" | "pageable" | "remote"
-        self.packed = 0           # 0: host copy is raw bf16; 10 / 11 / 12: it holds that lossless encoding (lia_pack12.hip)
+        self.packed = 0           # 0: host copy is raw bf16; 10: it holds the lossless pack10 encoding (lia_pack10.hip)
         self.shard = None         # (rank, world, slice bytes) when the host copy is one slice of the wire bytes
         self.stream_bytes = total_bytes   # bytes that cross the host link per use
         self.want_fmt = 0         # wire format asked for by the last to_pinned / to_cxl (a layer that does not fit stays raw)
@@ -243,9 +243,9 @@ class LayerStore:
                 return None
         else:
             return None
-        bound, encode = {10: (self._lib.lia_pack10_bound, self._lib.lia_pack10_encode),
-                         11: (self._lib.lia_pack11_bound, self._lib.lia_pack11_encode),
-                         12: (self._lib.lia_pack12_bound, self._lib.lia_pack12_encode)}[fmt]
+        if fmt != 10:
+            raise ValueError(f"unknown wire format {fmt!r}: 0 (raw bf16) or 10 (pack10)")
+        bound, encode = self._lib.lia_pack10_bound, self._lib.lia_pack10_encode
         cap = bound(self.nbytes // 2)
         enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
         out = ctypes.c_size_t()
@@ -260,16 +260,16 @@ class LayerStore:
 
     @staticmethod
     def _fmt_of(pack):
-        return {False: 0, True: 12, None: 0}.get(pack, pack)          # accepts False / True (= 12) / 0 / 10 / 11 / 12
+        return {False: 0, True: 10, None: 0, "raw": 0, "pack10": 10}.get(pack, pack)          # accepts False / True (= 10) / 0 / 10 / the names
 
-    def to_pinned(self, pack12=False, shard=None, keep_raw=False):
+    def to_pinned(self, wire=False, shard=None, keep_raw=False):
         """Tensor.pin_memory() for all 16 tensors at once (lia/modeling_opt.py:207-227); with a packed format the pinned copy
         is that lossless encoding (67-75 % of the bytes).  shard = (r, G): keep only the r-th of G equal slices of the wire
         bytes (data-parallel "allgather" streaming: every rank pulls its slice over its own link).  keep_raw (with a packed
         format): also keep a raw pinned copy for the host cores (a host-computed layer streams packed in the prefill and is
         read raw in decode); dropped silently when the container has no room for it -- the layer then stays raw only.
         A layer already pinned in ANOTHER format (or tier) is re-encoded: nothing is sticky."""
-        fmt = self._fmt_of(pack12)
+        fmt = self._fmt_of(wire)
         if shard is not None and shard[1] > 1:
             if self.tier == "pinned" and self.shard and self.shard[:2] == tuple(shard) and self.want_fmt == fmt:
                 return
@@ -348,7 +348,7 @@ class LayerStore:
 
     def to_cxl(self, pack=0):
         """realloc_to_numa (lia/modeling_opt.py:168-175) + hipHostRegister so the copy engine can DMA from it
-        (the reference leaves the CXL copy pageable, lia/cxl/numa_alloc.py:49).  pack = 10 / 11 / 12: the tier holds
+        (the reference leaves the CXL copy pageable, lia/cxl/numa_alloc.py:49).  pack = 10: the tier holds
         that lossless wire format instead of raw bf16 (fewer bytes in the tier AND on the link)."""
         fmt = self._fmt_of(pack)
         if self.tier == "cxl" and self.want_fmt == fmt:
@@ -499,7 +499,7 @@ class LiaOPTModel:
 
     @classmethod
     def random_init(cls, shape, seed=0, init="normal", n_gpu_layers=0, pin_weight=True, enable_cxl=False,
-                    host_owner=True, pack12=False, raw_layers=(), shard=None):
+                    host_owner=True, wire=False, raw_layers=(), shard=None):
         """Random-init weights of the exact architecture, generated ON THE GPU one layer at a time and
         moved straight to their tier (an OPT-30B would take minutes to draw on the CPU).
         init="normal": HF _init_weights (lia/modeling_opt.py:895-904): Linear/Embedding ~ N(0, 0.02), zero
@@ -511,7 +511,7 @@ class LiaOPTModel:
         self = cls(shape)
         if host_owner:
             from . import hostinfo
-            hostinfo.check_host_allocation(int(self.streamed_bytes(n_gpu_layers) * (0.76 if pack12 else 1.0) / (shard[1] if shard else 1)),
+            hostinfo.check_host_allocation(int(self.streamed_bytes(n_gpu_layers) * (0.69 if wire else 1.0) / (shard[1] if shard else 1)),
                                            f"{shape.name}: {shape.layers - n_gpu_layers} streamed layers")
         self.embed_tokens, self.embed_positions, self.final_ln_w, self.final_ln_b = draw_head(shape, seed, init)
         for li, st in enumerate(self.layers):
@@ -521,7 +521,7 @@ class LiaOPTModel:
             flat = draw_layer(shape, self.offsets, self.layer_bytes, li, seed, init)
             st.set_from_device(flat.view(torch.uint8))
             if li >= n_gpu_layers:
-                fmt = LayerStore._fmt_of(pack12)
+                fmt = LayerStore._fmt_of(wire)
                 if enable_cxl and pin_weight:        # the reference consults enable_cxl only inside pin_memory (:1214-1217)
                     st.to_cxl(0 if li in raw_layers else fmt)
                 elif pin_weight:
@@ -529,24 +529,24 @@ class LiaOPTModel:
                 else:
                     st.to_pageable()
         torch.cuda.synchronize()
-        self.placed_for = self._place_key(n_gpu_layers, pin_weight, enable_cxl, pack12, raw_layers, shard)
+        self.placed_for = self._place_key(n_gpu_layers, pin_weight, enable_cxl, wire, raw_layers, shard)
         return self
 
     # -- placement (first forward, and again whenever the flags change) -------------------------------
     @staticmethod
-    def _place_key(n_gpu_layers, pin_weight, enable_cxl, pack12, raw_layers, shard):
-        return (int(n_gpu_layers), bool(pin_weight), bool(enable_cxl), LayerStore._fmt_of(pack12), frozenset(raw_layers or ()),
+    def _place_key(n_gpu_layers, pin_weight, enable_cxl, wire, raw_layers, shard):
+        return (int(n_gpu_layers), bool(pin_weight), bool(enable_cxl), LayerStore._fmt_of(wire), frozenset(raw_layers or ()),
                 tuple(shard) if shard else None)
 
-    def place(self, n_gpu_layers, pin_weight, enable_cxl, pack12=False, raw_layers=(), shard=None):
+    def place(self, n_gpu_layers, pin_weight, enable_cxl, wire=False, raw_layers=(), shard=None):
         """Tier assignment, idempotent per flag set: move_gpu_layer / pin_memory of the reference (lia/modeling_opt.py:1182-1184,
         1214-1217) run on the first forward of a process; here a later call with other flags (policy 1 needs raw host copies,
         another gpu%, another wire format, the CXL tier) RE-PLACES the layers instead of failing -- every LayerStore can be
         rebuilt on the device from whatever it holds."""
-        key = self._place_key(n_gpu_layers, pin_weight, enable_cxl, pack12, raw_layers, shard)
+        key = self._place_key(n_gpu_layers, pin_weight, enable_cxl, wire, raw_layers, shard)
         if self.placed_for == key:
             return
-        fmt = LayerStore._fmt_of(pack12)
+        fmt = LayerStore._fmt_of(wire)
         from . import hostinfo
         if pin_weight:
             moving = sum(st.nbytes for i, st in enumerate(self.layers) if i >= n_gpu_layers and st.tier in ("pageable", "device"))

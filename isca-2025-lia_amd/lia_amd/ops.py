@@ -59,6 +59,14 @@ class Context:
     def set_host_threads(self, n):
         N.check(self.lib.lia_ctx_set_host_threads(self.handle, n))
 
+    def set_option(self, key, value):
+        """lia_ctx_set_option: a switch of THIS context (N.LIA_OPT_*); other contexts of the process are not affected"""
+        N.check(self.lib.lia_ctx_set_option(self.handle, key, value), "lia_ctx_set_option")
+
+    def fused_combines(self, kind):
+        """fused split-K combines of LIA_POST_* kind (1 LayerNorm, 2 RMSNorm, 3 SiLU*up, 4 RoPE) launched through this context"""
+        return self.lib.lia_ctx_get_counter(self.handle, N.LIA_CNT_FUSED_COMBINE + kind)
+
     def chain_next_norm(self, g_ptr, b_ptr=None):
         """lia_ctx_chain_next_norm: the next layer call also computes the first norm (weights g, b) of the layer after it."""
         N.check(self.lib.lia_ctx_chain_next_norm(self.handle, ctypes.c_void_p(g_ptr), ctypes.c_void_p(b_ptr) if b_ptr else None),

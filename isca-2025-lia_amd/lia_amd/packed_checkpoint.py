@@ -147,10 +147,10 @@ def main(argv=None):
     ap.add_argument("--save_dir", type=str, required=True)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--init", default="uniform01", choices=["uniform01", "normal", "trained-like"])
-    ap.add_argument("--wire", default="pack10", choices=["raw", "pack10", "pack11", "pack12"])
+    ap.add_argument("--wire", default="pack10", choices=["raw", "pack10"])
     a = ap.parse_args(argv)
     shape = resolve_shape(a.model)
-    wire = {"raw": 0, "pack10": 10, "pack11": 11, "pack12": 12}[a.wire]
+    wire = {"raw": 0, "pack10": 10}[a.wire]
     total = [0]
 
     def progress(li, n):

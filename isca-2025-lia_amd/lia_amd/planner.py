@@ -26,7 +26,7 @@ class Box:
     # host-computed layers, threads pinned to the NUMA node that holds the weights (bench.py / run_generation.py do that):
     host_linear_gbs_per_thread: float = 7.0   # policy-1 linears at M = 64 beside the running weight stream (7.3 alone; r02's kernel: 4.4 / 4.9; 3.6 unpinned)
     host_attn_beside_stream: float = 0.8      # share of its rate the host attention keeps beside the stream (0.55 unpinned)
-    wire_ratio: float = 0.675         # bytes shipped per weight byte: pack10 0.675, pack11 0.696, pack12 0.751, raw 1.0
+    wire_ratio: float = 0.675         # bytes shipped per weight byte: pack10 0.675, raw 1.0
     host_threads: int = 0
     host_mem_gb: float = 0.0
     calibrated: dict = None           # set by calibrate(): the measured numbers, for the log

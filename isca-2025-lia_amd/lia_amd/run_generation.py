@@ -46,7 +46,7 @@ def build_parser():
     p.add_argument("--num-minibatch", default=1, type=int)
     p.add_argument("--enable-cxl", action="store_true")
     # build-specific
-    p.add_argument("--stream-format", default=None, choices=["raw", "pack12", "pack11", "pack10"],
+    p.add_argument("--stream-format", default=None, choices=["raw", "pack10"],
                    help="wire format of the pinned streamed layers: a lossless packed format (default pack10, or $LIA_STREAM_FORMAT; same "
                         "results bit for bit, fewer bytes over the host link; layers that do not pack are pinned raw) or raw bf16 (what the "
                         "reference ships); a model directory in the build's packed format defaults to the format on disk")
@@ -125,7 +125,7 @@ def auto_plan(args, out=print):
         box.hbm_gb = float(args.plan_hbm_gb)
     max_pct = int(args.plan_max_gpu_percentage)    # what-if / tests: cap the resident share
     fmt = args.stream_format or default_stream_format()
-    box.wire_ratio = {"raw": 1.0, "pack12": 0.751, "pack11": 0.696, "pack10": 0.675}[fmt]
+    box.wire_ratio = {"raw": 1.0, "pack10": 0.675}[fmt]
     shape = model_shape(args)
     pl = planner.plan(shape, args.batch_size, int(args.input_tokens), args.max_new_tokens, box, max_gpu_percentage=max_pct)
     args.gpu_percentage, args.prefill_policy, args.decoding_policy = pl.gpu_percentage, pl.prefill_policy, pl.decoding_policy
@@ -163,19 +163,19 @@ def load_model(args):
             shape_layers = man["shape"]["layers"]
             if args.stream_format is None:       # stream what is on disk, as it is
                 wires = [e["wire"] for e in man["layers"]]
-                args.stream_format = {0: "raw", 10: "pack10", 11: "pack11", 12: "pack12"}[max(set(wires), key=wires.count)]
+                args.stream_format = {0: "raw", 10: "pack10"}[max(set(wires), key=wires.count)]
             return packed_checkpoint.load_packed(args.model_id, n_gpu_layers=int(shape_layers * args.gpu_percentage / 100))
         from .checkpoint import load_hf_opt
         return load_hf_opt(args.model_id)
     shape = resolve_shape(args.model_id)
     n_gpu = int(shape.layers * args.gpu_percentage / 100)
-    fmt = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}[args.stream_format or default_stream_format()]
+    fmt = {"raw": 0, "pack10": 10}[args.stream_format or default_stream_format()]
     if args.prefill_policy == 1 or args.decoding_policy == 1:
         fmt = 0                      # the host path reads the raw copy in place
     from .scheduler import OffloadScheduler
     raw = OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, args.cpu_layers) if (args.cpu_layers and args.decoding_policy == 2) else ()
     return LiaOPTModel.random_init(shape, seed=args.seed, init=args.init, n_gpu_layers=n_gpu,
-                                   pin_weight=args.pin_weight, enable_cxl=args.enable_cxl, pack12=fmt, raw_layers=raw)
+                                   pin_weight=args.pin_weight, enable_cxl=args.enable_cxl, wire=fmt, raw_layers=raw)
 
 
 def summarize(total_time, num_iter, num_warmup, total_list, batch_size, out=print):
@@ -264,7 +264,7 @@ def main(argv=None):
     if args.stream_format is None:
         args.stream_format = default_stream_format()
     from .scheduler import OffloadScheduler
-    model._lia_scheduler = OffloadScheduler(model, pack12=args.stream_format)     # generate() drives this scheduler
+    model._lia_scheduler = OffloadScheduler(model, wire=args.stream_format)     # generate() drives this scheduler
     generate_kwargs = dict(do_sample=False, num_beams=1, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
                            token_latency=args.token_latency, prefill_policy=args.prefill_policy,
                            decoding_policy=args.decoding_policy, no_overlap=args.no_overlap, pin_weight=args.pin_weight,

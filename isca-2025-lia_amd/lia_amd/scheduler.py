@@ -51,7 +51,7 @@ class WeightPipeline:
             self.slot_tensors = [RawDeviceBuffer(p, model.layer_bytes).tensor() for p in self.slot_ptrs]
             self.copy_stream = torch.cuda.ExternalStream(self.lib.lia_stream_copy_stream(h))
             self.staging_tensors = None
-            # the root tells every rank which layers travel pack12-encoded and how many bytes each one ships
+            # the root tells every rank which layers travel pack10-encoded and how many bytes each one ships
             # (gloo validation runs without a GPU -- tests/test_dp_gloo.py -- keep the table on the host)
             meta = torch.zeros((len(model.layers), 2), dtype=torch.int64, device="cuda" if torch.cuda.is_available() else "cpu")
             if dp_group.is_root:
@@ -117,8 +117,7 @@ class WeightPipeline:
     def _staging(self):
         if self.staging_tensors is None:
             from .dp import RawDeviceBuffer
-            cap = max(self.lib.lia_pack12_bound(self.model.layer_bytes // 2), self.lib.lia_pack11_bound(self.model.layer_bytes // 2),
-                      self.lib.lia_pack10_bound(self.model.layer_bytes // 2))
+            cap = self.lib.lia_pack10_bound(self.model.layer_bytes // 2)
             self.staging_tensors = [RawDeviceBuffer(self.lib.lia_stream_staging_ptr(self.handle, s), cap).tensor()
                                     for s in range(self.n_slots)]
         return self.staging_tensors
@@ -270,8 +269,8 @@ def default_stream_format():
     transfer; a layer whose values do not pack (encoding >= raw size, or too many out-of-window values) is pinned raw by itself
     (LayerStore._encode_packed).  `raw` = what the reference ships (Tensor.pin_memory of the bf16 tensors, modeling_opt.py:207-227)."""
     fmt = os.environ.get("LIA_STREAM_FORMAT", DEFAULT_STREAM_FORMAT).lower()
-    if fmt not in ("raw", "pack10", "pack11", "pack12"):
-        raise ValueError(f"LIA_STREAM_FORMAT={fmt!r}: expected raw, pack10, pack11 or pack12")
+    if fmt not in ("raw", "pack10"):
+        raise ValueError(f"LIA_STREAM_FORMAT={fmt!r}: expected raw or pack10")
     return fmt
 
 
@@ -554,13 +553,13 @@ class CoopController:
 class OffloadScheduler:
     """forward(input_ids, kv_state, **lia flags) -> (logits [B,vocab], next_ids [B]) on the device."""
 
-    def __init__(self, model, device=0, n_slots=None, dp_group=None, pack12=None):
+    def __init__(self, model, device=0, n_slots=None, dp_group=None, wire=None):
         import os
         self.model, self.device, self.dp = model, device, dp_group
         self.n_slots = n_slots or 4
-        # wire format of the streamed layers: "pack12" (lossless 12-bit encoding, lia_pack12.hip) or "raw" bf16
-        fmt = default_stream_format() if pack12 is None else pack12
-        self.pack12 = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10, False: 0, True: 12, 0: 0, 10: 10, 11: 11, 12: 12}[fmt]
+        # wire format of the streamed layers: "pack10" (the lossless encoding of lia_pack10.hip) or "raw" bf16
+        fmt = default_stream_format() if wire is None else wire
+        self.wire = {"raw": 0, "pack10": 10, False: 0, True: 10, 0: 0, 10: 10}[fmt]
         self.ctx = None
         self.ws_rows = 0
         self.pipe = None
@@ -753,7 +752,7 @@ class OffloadScheduler:
                 for i in getattr(kv_state, "dual", {}):                  # an empty cache changes sides for free
                     kv_state.move_cache(N.lib(), i, to_device=(i not in need_host))
         shard = (self.dp.rank, self.dp.world) if (self.dp is not None and self.dp.world > 1 and self.dp.mode == "allgather") else None
-        wire = self.pack12 if (s.prefill_policy != 1 and decoding_policy != 1) else 0
+        wire = self.wire if (s.prefill_policy != 1 and decoding_policy != 1) else 0
         if m.placed_for != m._place_key(n_gpu, pin_weight, enable_cxl, wire, cpu_set, shard):
             # the flags changed since the last placement: the model re-tiers its layers (policy 1 wants raw host copies,
             # another gpu%, wire format or host tier).  Copies in flight read host buffers that are about to be freed and
@@ -924,7 +923,7 @@ class OffloadScheduler:
                 from . import hostinfo, planner
                 start, _ = planner.plan_cpu_layers(self.model.shape, B, T, max_new_tokens or 32, gpu_percentage,
                                                    planner.Box(host_threads=self.host_threads or hostinfo.default_host_threads(1),
-                                                               wire_ratio={0: 1.0, 12: 0.751, 11: 0.696, 10: 0.675}[self.pack12]),
+                                                               wire_ratio={0: 1.0, 10: 0.675}[self.wire]),
                                                    kv_in_hbm=(decoding_policy == 3))
             order = self.cpu_layer_order(n_gpu, L)
             sh = self.model.shape
@@ -934,7 +933,7 @@ class OffloadScheduler:
             tiers = sorted({st.tier for st in getattr(self.model, "layers", [])[n_gpu:] if getattr(st, "tier", None) not in ("device", None)}) or ["-"]
             t_bucket = 1 << max(0, int(T) - 1).bit_length()
             store_key = "|".join(str(v) for v in (sh.name, sh.hidden, sh.ffn, L, n_gpu, B, f"T<={t_bucket}", f"new{max_new_tokens or 0}", decoding_policy,
-                                                  self.pack12, "+".join(tiers), self.host_threads or hostinfo.default_host_threads(1)))
+                                                  self.wire, "+".join(tiers), self.host_threads or hostinfo.default_host_threads(1)))
             kept = CoopStore.load(store_key) if seeded_ok else None
             if kept is not None:
                 start = max(0, min(kept[0], len(order)))
@@ -1074,7 +1073,7 @@ class OffloadScheduler:
         host = list(range(n_gpu, sh.layers))
         for idx in host:
             if m.layers[idx].packed:
-                raise ValueError("policy 1 needs the raw bf16 host copy, but the streamed layers were pinned in the pack12 wire "
+                raise ValueError("policy 1 needs the raw bf16 host copy, but the streamed layers were pinned in the pack10 wire "
                                  "format by an earlier call; reload the model or set LIA_STREAM_FORMAT=raw")
         if host and B * T <= 256:
             # a decode step: every host layer in ONE OpenMP region (lia_host_layers_forward); the pointer tables are rebuilt only

@@ -297,7 +297,7 @@ def test_host_layers_forward_equals_layer_by_layer(native, n_layers):
 
 
 def test_host_kernels_report_scratch_failure_instead_of_crashing(native):
-    """a worker thread that cannot get its scratch block (refused here by lia_host_set_scratch_limit; the same path as a failed
+    """a worker thread that cannot get its scratch block (refused here by lia_host_thread_scratch_limit; the same path as a failed
     aligned_alloc): the call returns LIA_ERR_MEMORY with a message, the team leaves its region in step, and the next call with
     the limit lifted computes as before; F <= 0 is a shape error"""
     from lia_amd import ops
@@ -317,14 +317,14 @@ def test_host_kernels_report_scratch_failure_instead_of_crashing(native):
     x = synth.make_hidden(12, B, T, H)
 
     def layer(limit):
-        L.lia_host_set_scratch_limit(limit)
+        L.lia_host_thread_scratch_limit(limit)
         try:
             k, v, y = k0.copy(), v0.copy(), np.zeros_like(x)
             rc = L.lia_host_layer_forward(ctypes.byref(desc), ctypes.byref(arr), x.ctypes.data, y.ctypes.data, k.ctypes.data, v.ctypes.data,
                                           smax, B, B, T, pos0, 0, 3)
             return rc, y
         finally:
-            L.lia_host_set_scratch_limit(0)
+            L.lia_host_thread_scratch_limit(0)
 
     rc0, y0 = layer(0)
     assert rc0 == 0
@@ -332,7 +332,7 @@ def test_host_kernels_report_scratch_failure_instead_of_crashing(native):
     assert rc1 == native.LIA_ERR_MEMORY and b"scratch" in L.lia_last_error()
     rc2, y2 = layer(0)
     assert rc2 == 0 and (y2 == y0).all()                     # the flag does not leak into the next call
-    L.lia_host_set_scratch_limit(64)
+    L.lia_host_thread_scratch_limit(64)
     try:
         xs = np.zeros((4, 64), np.uint16)
         ws = np.zeros((32, 64), np.uint16)
@@ -343,7 +343,7 @@ def test_host_kernels_report_scratch_failure_instead_of_crashing(native):
         assert L.lia_host_layers_forward(ctypes.byref(desc), 1, wt, x.copy().ctypes.data, np.zeros_like(x).ctypes.data, kt, vt, smax, B, B, T,
                                          pos0, 0, 3) == native.LIA_ERR_MEMORY
     finally:
-        L.lia_host_set_scratch_limit(0)
+        L.lia_host_thread_scratch_limit(0)
     bad = ops.make_desc(H, heads, 0)
     assert L.lia_host_layer_forward(ctypes.byref(bad), ctypes.byref(arr), x.ctypes.data, np.zeros_like(x).ctypes.data, k0.copy().ctypes.data,
                                     v0.copy().ctypes.data, smax, B, B, T, pos0, 0, 3) == native.LIA_ERR_INVALID

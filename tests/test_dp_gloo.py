@@ -209,10 +209,8 @@ class _HostSlotLib:
     def lia_stream_copy_chunk_packed(self, h, slot, off, src, n, pinned):
         return self._copy(self.staging, slot, off, src, n)
 
-    def lia_pack12_bound(self, n):
+    def lia_pack10_bound(self, n):
         return self.cap
-
-    lia_pack11_bound = lia_pack10_bound = lia_pack12_bound
 
     def lia_stream_decode_packed(self, h, slot, n_values, fmt):
         self.decoded = getattr(self, "decoded", []) + [(slot, fmt)]

@@ -398,7 +398,7 @@ def test_dummy_checkpoint_directory_streams_like_the_generator(tmp_path, wire):
     assert [st.tier for st in model.layers] == ["device", "mapped", "mapped", "mapped"]
     assert all(st.packed == {"pack10": 10, "raw": 0}[wire] and st.is_dma_able() for st in model.layers[1:])
     from lia_amd.scheduler import OffloadScheduler
-    model._lia_scheduler = OffloadScheduler(model, pack12=wire)
+    model._lia_scheduler = OffloadScheduler(model, wire=wire)
     out, _, logits = generate(model, ids, max_new_tokens=4, min_new_tokens=4, return_logits=True, prefill_policy=3, decoding_policy=3,
                               gpu_percentage=25, pin_weight=True)
     assert [st.tier for st in model.layers] == ["device", "mapped", "mapped", "mapped"]      # streamed straight from the files

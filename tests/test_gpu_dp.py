@@ -58,7 +58,7 @@ def _worker(rank, world, port, tmpdir, fmt, name, gpu_percentage, mode, backend=
                     st._free()
                     st._np = None
                     st.tier = "remote"          # this rank never sees the host copy
-        model._lia_scheduler = OffloadScheduler(model, device=0, dp_group=g, pack12=fmt)
+        model._lia_scheduler = OffloadScheduler(model, device=0, dp_group=g, wire=fmt)
         mine = g.shard(torch.from_numpy(ids))
         lo, hi = dp.shard_rows(B, rank, world)
         out = generate(model, mine, max_new_tokens=new, min_new_tokens=new, prefill_policy=0, decoding_policy=2,

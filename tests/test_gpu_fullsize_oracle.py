@@ -422,28 +422,24 @@ def test_llama3_8b_decode_layer_fused_routes_are_bit_identical(llama_layer):
     one-slice gate | up GEMM's own epilogue -- r03) against one kernel per op (LIA_FUSE_COMBINE=0 semantics): same bits."""
     import torch
     from lia_amd import _native as N
-    lib = N.lib()
-    lib.lia_gemm_set_fuse_combine.argtypes = [ctypes.c_int]
-    lib.lia_gemm_set_fuse_combine.restype = None
-    lib.lia_gemm_fused_combine_count.argtypes = [ctypes.c_int]
-    lib.lia_gemm_fused_combine_count.restype = ctypes.c_long
     L = llama_layer
+    ctx = L["ctx"]
     H, heads, kvh, B, S0 = L["H"], L["heads"], L["kvh"], 128, 1024
     d = H // heads
     x = _randn(torch, (B, 1, H), 93)
     outs = []
     try:
         for fused in (1, 0):
-            lib.lia_gemm_set_fuse_combine(fused)
+            ctx.set_option(N.LIA_OPT_FUSE_COMBINE, fused)
             kc, vc = _randn(torch, (S0 + 2, B, kvh, d), 91), _randn(torch, (S0 + 2, B, kvh, d), 92)
             kv = N.KV(kc.data_ptr(), vc.data_ptr(), S0 + 2, B, 1)
-            before = lib.lia_gemm_fused_combine_count(3)
+            before = ctx.fused_combines(3)
             y = _llama_run(L, x, kv, B, 1, S0)
             if fused:
-                assert lib.lia_gemm_fused_combine_count(3) == before + 1          # the SiLU.up fusion really ran
+                assert ctx.fused_combines(3) == before + 1          # the SiLU.up fusion really ran
             outs.append((y.clone(), kc[S0].clone(), vc[S0].clone()))
     finally:
-        lib.lia_gemm_set_fuse_combine(1)
+        ctx.set_option(N.LIA_OPT_FUSE_COMBINE, 1)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 

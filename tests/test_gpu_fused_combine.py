@@ -14,28 +14,18 @@ pytestmark = pytest.mark.gpu
 LN, RMS, SILU, ROPE = 1, 2, 3, 4
 
 
-def _knobs():
-    from lia_amd import _native as N
-    lib = N.lib()
-    lib.lia_gemm_set_fuse_combine.argtypes = [ctypes.c_int]
-    lib.lia_gemm_set_fuse_combine.restype = None
-    lib.lia_gemm_fused_combine_count.argtypes = [ctypes.c_int]
-    lib.lia_gemm_fused_combine_count.restype = ctypes.c_long
-    return lib
-
-
 @pytest.mark.parametrize("B,H,heads,F", [(8, 1024, 8, 4096), (64, 2048, 16, 8192), (33, 1536, 12, 6144), (1, 768, 12, 3072), (256, 1024, 8, 4096)])
 def test_opt_decode_layers_fused_equals_unfused(B, H, heads, F):
     """two resident layers, three decode steps: LN2 in the out-proj combine, the next layer's LN1 chained into fc2's."""
     import torch
     from lia_amd import _native as N, ops
-    lib = _knobs()
     ctx = ops.Context(0, 1 << 30)
+    other = ops.Context(0, 0)                    # a second context of the process: its switch stays where it is (per-context options, r05)
     d, T, new = H // heads, 5, 3
     layers = [_layer_setup(torch, ops, synth.make_layer(11 + i, H, F, 0.05), H, heads, F) for i in range(2)]
 
     def run(fused):
-        lib.lia_gemm_set_fuse_combine(1 if fused else 0)
+        ctx.set_option(N.LIA_OPT_FUSE_COMBINE, 1 if fused else 0)
         kvs, keep = [], []
         for _ in layers:
             kc = torch.zeros((T + new, B, heads, d), dtype=torch.bfloat16, device="cuda")
@@ -61,12 +51,15 @@ def test_opt_decode_layers_fused_equals_unfused(B, H, heads, F):
             outs.append(to_bits(a).copy())
         return outs, [to_bits(k).copy() for k, _ in keep]
 
-    n0 = lib.lia_gemm_fused_combine_count(LN)
+    n0 = ctx.fused_combines(LN)
     fused, fk = run(True)
-    n1 = lib.lia_gemm_fused_combine_count(LN)
+    n1 = ctx.fused_combines(LN)
     plain, pk = run(False)
-    assert lib.lia_gemm_fused_combine_count(LN) == n1, "the switch did not turn the fused combines off"
-    lib.lia_gemm_set_fuse_combine(1)
+    assert ctx.fused_combines(LN) == n1, "the switch did not turn the fused combines off"
+    assert other.fused_combines(LN) == 0 and other.fused_combines(99) == -1      # counters are the context's own
+    with pytest.raises(ValueError):
+        ctx.set_option(12345, 1)
+    other.close()
     # (H = 768: the out-proj GEMM has 12 K-chunks and is not split -- its LN2 stays a kernel of its own; fc2's chained LN1 rides)
     want = 3 * new if H >= 1024 else new
     assert n1 - n0 >= want, f"only {n1 - n0} fused LayerNorm combines ran (expected LN2 x2 + one chained LN1 per step)"
@@ -81,7 +74,6 @@ def test_chain_hint_is_ignored_when_the_next_call_takes_another_input():
     """the promise of lia_ctx_chain_next_norm is checked, not trusted: a following call on a different x computes its own LN1"""
     import torch
     from lia_amd import _native as N, ops
-    _knobs().lia_gemm_set_fuse_combine(1)
     B, H, heads, F, T = 16, 1024, 8, 4096, 4
     ctx = ops.Context(0, 1 << 30)
     la = _layer_setup(torch, ops, synth.make_layer(21, H, F, 0.05), H, heads, F)
@@ -120,7 +112,7 @@ def test_llama_layers_fused_equals_unfused(B, H, heads, kvh, F, T):
     import torch
     from lia_amd import _native as N, ops
     from lia_amd.llama import LiaLlamaModel, LlamaShape, rope_tables
-    lib = _knobs()
+    lib = N.lib()
     new, L = 3, 2
     m = synth.make_llama_model(7, 64, H, heads, kvh, F, L, 0.05)
     shape = LlamaShape("t", H, heads, kvh, F, L, 64, max_pos=T + new + 4, rope_theta=10000.0)
@@ -137,7 +129,7 @@ def test_llama_layers_fused_equals_unfused(B, H, heads, kvh, F, T):
                                             ctypes.c_void_p(sin.data_ptr()), B, Tn, pos0, 0, ctypes.c_void_p(ctx.stream)))
 
     def run(fused):
-        lib.lia_gemm_set_fuse_combine(1 if fused else 0)
+        ctx.set_option(N.LIA_OPT_FUSE_COMBINE, 1 if fused else 0)
         keep, kvs = [], []
         for _ in range(L):
             kc = torch.zeros((T + new, B, kvh, d), dtype=torch.bfloat16, device="cuda")
@@ -163,11 +155,10 @@ def test_llama_layers_fused_equals_unfused(B, H, heads, kvh, F, T):
             outs.append(to_bits(a).copy())
         return outs, [(to_bits(k).copy(), to_bits(v).copy()) for k, v in keep]
 
-    before = [lib.lia_gemm_fused_combine_count(k) for k in (RMS, SILU, ROPE)]
+    before = [ctx.fused_combines(k) for k in (RMS, SILU, ROPE)]
     fused, fkv = run(True)
-    after = [lib.lia_gemm_fused_combine_count(k) for k in (RMS, SILU, ROPE)]
+    after = [ctx.fused_combines(k) for k in (RMS, SILU, ROPE)]
     plain, pkv = run(False)
-    lib.lia_gemm_set_fuse_combine(1)
     ran = [a - b for a, b in zip(after, before)]
     assert ran[0] >= 3 * new and ran[1] >= 2 * new and ran[2] >= 2 * new, f"fused combines that ran (rmsnorm, silu, rope): {ran}"
     if B * T > 256:
@@ -180,44 +171,40 @@ def test_llama_layers_fused_equals_unfused(B, H, heads, kvh, F, T):
     model.close()
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 7168, 7168), (128, 4096, 14336), (20, 1024, 4096)])
-def test_inlaunch_splitk_combine_equals_the_combine_kernel(M, N, K):
-    """lia_gemm_set_inlaunch_combine(1): the last-arriving K slice of a tile combines the slabs inside the GEMM launch (ticket per
-    tile) -- slower than the second kernel at these sizes (lia_gemm.hip), kept as the A/B leg: same slabs added in the same
-    order, so the same bits"""
+def test_two_contexts_of_one_process_keep_their_own_switches():
+    """include/lia_hip.h promises that contexts are independent: with the fused combines off in ONE of two live contexts the
+    other still fuses (r04 had process-wide lia_gemm_set_* setters), and both give the same bits"""
     import torch
     from lia_amd import _native as N_, ops
-    lib = N_.lib()
-    lib.lia_gemm_set_inlaunch_combine.argtypes = [ctypes.c_int]
-    lib.lia_gemm_set_inlaunch_combine.restype = None
-    g = torch.Generator(device="cuda").manual_seed(M + K)
+    M, Nn, K = 64, 1024, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
     x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
-    w = (0.02 * torch.randn((N, K), generator=g, device="cuda")).to(torch.bfloat16)
-    bias = (0.1 * torch.randn((N,), generator=g, device="cuda")).to(torch.bfloat16)
-    res = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
-    torch.cuda.synchronize()
-    ctx = ops.Context(0, 8 * M * N * 4 + (1 << 20))
-    try:
-        outs = []
-        for on in (1, 0):
-            lib.lia_gemm_set_inlaunch_combine(on)
-            y = ctx.linear(x, w, bias=bias, residual=res)
-            ctx.synchronize()
-            outs.append(to_bits(y).copy())
-        assert (outs[0] == outs[1]).all(), f"{(outs[0] != outs[1]).sum()} of {outs[0].size} values differ"
-    finally:
-        lib.lia_gemm_set_inlaunch_combine(0)
-        ctx.close()
+    H, heads, F = 1024, 8, 4096
+    la = _layer_setup(torch, ops, synth.make_layer(41, H, F, 0.05), H, heads, F)
+    a, b = ops.Context(0, 1 << 28), ops.Context(0, 1 << 28)
+    b.set_option(N_.LIA_OPT_FUSE_COMBINE, 0)
+    outs = []
+    for ctx in (a, b, a):
+        kc = torch.zeros((4, M, heads, H // heads), dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        kv = N_.KV(kc.data_ptr(), vc.data_ptr(), 4, M, 1)
+        xin = to_dev(torch, synth.make_hidden(8, M, 1, H))
+        y = torch.empty_like(xin)
+        ctx.layer_forward(la[0], 3, la[2], xin, y, kv, M, 1, 0)
+        ctx.synchronize()
+        outs.append(to_bits(y).copy())
+    assert a.fused_combines(LN) >= 2 and b.fused_combines(LN) == 0
+    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+    a.close()
+    b.close()
 
 
-def test_tiled_prefill_gemm_variants_are_bit_identical():
-    """lia_gemm_set_tiled_variant: the phased kernel (262, default), its four-phase / global_load_lds forms (259-261), r01's
-    one-barrier kernel (256) and staggered k-half kernels (257 / 258) all add the same products in the same order"""
+def test_phased_256_tiles_equal_the_128_tiles_bit_for_bit():
+    """the prefill GEMM's two tile shapes add the same products in the same order: M = 1024 rows in one call run the phased 256 x 256
+    kernel (lia_gemm_tiled256p_kernel), the same rows as two calls of 512 run the 128 x 128 kernel -- same bits; and both within
+    bf16 rounding of an fp32 reference"""
     import torch
-    from lia_amd import _native as N_, ops
-    lib = N_.lib()
-    lib.lia_gemm_set_tiled_variant.argtypes = [ctypes.c_int]
-    lib.lia_gemm_set_tiled_variant.restype = None
+    from lia_amd import ops
     M, N, K = 1024, 1536, 1024
     g = torch.Generator(device="cuda").manual_seed(9)
     x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
@@ -226,17 +213,12 @@ def test_tiled_prefill_gemm_variants_are_bit_identical():
     torch.cuda.synchronize()
     ctx = ops.Context(0, 1 << 24)
     try:
-        ref = None
-        for v in (262, 261, 260, 259, 258, 257, 256):
-            lib.lia_gemm_set_tiled_variant(v)
-            y = ctx.linear(x, w, bias=bias, relu=True)
-            ctx.synchronize()
-            bits = to_bits(y).copy()
-            if ref is None:
-                ref = bits
-                want = torch.relu((x.float() @ w.float().T + bias.float()).to(torch.bfloat16).float())
-                assert float((y.float() - want).abs().max()) <= 0.02 * float(want.abs().max())
-            assert (bits == ref).all(), f"variant {v}: {(bits != ref).sum()} of {ref.size} values differ from variant 262"
+        y = ctx.linear(x, w, bias=bias, relu=True)
+        halves = [ctx.linear(x[i * 512:(i + 1) * 512].contiguous(), w, bias=bias, relu=True) for i in range(2)]
+        ctx.synchronize()
+        want = torch.relu((x.float() @ w.float().T + bias.float()).to(torch.bfloat16).float())
+        assert float((y.float() - want).abs().max()) <= 0.02 * float(want.abs().max())
+        got, ref = to_bits(y), np.concatenate([to_bits(h) for h in halves], 0)
+        assert (got == ref).all(), f"{(got != ref).sum()} of {ref.size} values differ between the 256^2 and the 128^2 tiles"
     finally:
-        lib.lia_gemm_set_tiled_variant(262)
         ctx.close()

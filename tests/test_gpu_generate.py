@@ -49,7 +49,7 @@ FLAG_SETS = [
     dict(prefill_policy=0, decoding_policy=1, gpu_percentage=25, pin_weight=True, enable_cxl=True),   # README.md:78 (0/1): host cores read the tier
     dict(prefill_policy=0, decoding_policy=2, gpu_percentage=0, enable_cxl=True),                     # no --pin-weight: the flag is inert (:1214-1217)
 ]
-WIRE = {"raw": 0, "pack12": 12, "pack11": 11, "pack10": 10}
+WIRE = {"raw": 0, "pack10": 10}
 
 
 @pytest.fixture(autouse=True)
@@ -65,7 +65,7 @@ def cxl_nodes_of_this_box():
 
 def _check_tiers(model, c, flags, fmt):
     """every streamed layer sits in the tier and the wire format the flags ask for (`pack10` used to be
-    silently replaced by pack12 here)"""
+    silently replaced by another format here)"""
     n_gpu = int(c["L"] * flags.get("gpu_percentage", 0) / 100)
     pin, cxl = bool(flags.get("pin_weight")), bool(flags.get("enable_cxl"))
     host_compute = flags.get("prefill_policy", 1) == 1 or flags.get("decoding_policy", 1) == 1
@@ -113,22 +113,6 @@ def test_generate_with_immediate_kv_delivery(name, monkeypatch):
                    gpu_percentage=25, pin_weight=True, num_minibatch=2 if c["B"] % 2 == 0 else 1)
     assert model._lia_scheduler.defer_kv is False and model._lia_scheduler._kv_hold is None
     assert (out.numpy() == z["ids_bf16"]).all()
-    model._lia_scheduler.close()
-    model.close()
-
-
-@pytest.mark.parametrize("fmt", ["pack11", "pack12"])
-def test_generate_older_wire_formats(fmt, monkeypatch):
-    """pack11 / pack12 (the first two generations of the wire format, kept selectable): one end-to-end case each"""
-    import torch
-    from lia_amd.generation import generate
-    monkeypatch.setenv("LIA_STREAM_FORMAT", fmt)
-    z, m, ids, c = _load("generate_h256")
-    model = _model(m, c)
-    flags = dict(prefill_policy=0, decoding_policy=2, gpu_percentage=25, pin_weight=True)
-    out = generate(model, torch.from_numpy(ids), max_new_tokens=c["new"], min_new_tokens=c["new"], **flags)
-    assert (out.numpy() == z["ids_bf16"]).all()
-    _check_tiers(model, c, flags, fmt)
     model._lia_scheduler.close()
     model.close()
 

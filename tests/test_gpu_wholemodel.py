@@ -135,7 +135,7 @@ def test_opt30b_width_generate_vs_oracle(opt30_stack, oracle, name, pp, dp, gpu,
     old = getattr(model, "_lia_scheduler", None)
     if old is not None:
         old.close()
-    model._lia_scheduler = OffloadScheduler(model, pack12=fmt)
+    model._lia_scheduler = OffloadScheduler(model, wire=fmt)
     out, _, logits = generate(model, torch.from_numpy(st["ids"]), max_new_tokens=c["new"], min_new_tokens=c["new"], return_logits=True,
                               prefill_policy=pp, decoding_policy=dp, gpu_percentage=gpu, pin_weight=True)
     n_gpu = int(c["L"] * gpu / 100)
@@ -160,7 +160,7 @@ def test_opt30b_width_wire_formats_and_policies_agree_bit_for_bit(opt30_stack):
     model = st["model"]
     runs = {}
     for key, gpu, fmt in (("resident", 100, "raw"), ("streamed raw", 34, "raw"), ("streamed pack10", 34, "pack10")):
-        model._lia_scheduler = OffloadScheduler(model, pack12=fmt)
+        model._lia_scheduler = OffloadScheduler(model, wire=fmt)
         out, _, logits = generate(model, torch.from_numpy(st["ids"]), max_new_tokens=4, min_new_tokens=4, return_logits=True,
                                   prefill_policy=3, decoding_policy=3, gpu_percentage=gpu, pin_weight=True)
         runs[key] = (out.numpy().copy(), [_bits(l) for l in logits])

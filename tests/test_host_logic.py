@@ -356,7 +356,7 @@ def test_coop_store_seeds_the_next_process(tmp_path, monkeypatch):
         link, host = (44 - c) * 14.7, 110 + c * 15.5
         return max(link, host), link
 
-    me = SimpleNamespace(model=SimpleNamespace(shape=SimpleNamespace(name="opt-x", hidden=7168, ffn=28672)), pack12=10, host_threads=16,
+    me = SimpleNamespace(model=SimpleNamespace(shape=SimpleNamespace(name="opt-x", hidden=7168, ffn=28672)), wire=10, host_threads=16,
                          _coop=None, _coop_key=None, cpu_layer_order=OffloadScheduler.cpu_layer_order)
     monkeypatch.setattr("lia_amd.planner.plan_cpu_layers", lambda *a, **k: (12, 0.0))
     ctl = OffloadScheduler._coop_controller(me, 4, 48, 64, 1, 32, 10, 3, None)

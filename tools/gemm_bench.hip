@@ -21,8 +21,6 @@ __global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed) {
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 64;
   int force_split = argc > 2 ? atoi(argv[2]) : 0;
-  if (argc > 3) lia_gemm_set_tiled_variant(atoi(argv[3]));
-  if (getenv("SKV")) lia_gemm_set_skinny_variant(atoi(getenv("SKV")));
 
   struct Shape { const char* name; int N, K; };
   std::vector<Shape> shapes = {{"qkv", 21504, 7168}, {"out", 7168, 7168}, {"fc1", 28672, 7168}, {"fc2", 7168, 28672}, {"lm_head", 50272, 7168}};
@@ -40,8 +38,7 @@ int main(int argc, char** argv) {
   if (M > 256) shapes.pop_back();  // no lm_head in prefill (last position only)
   size_t ws_bytes = (size_t)8 * (M <= 256 ? M : 1) * 128256 * 4; CK(hipMalloc(&ws, ws_bytes));
   if (getenv("ZERO")) { for (int i = 0; i < NBUF; ++i) CK(hipMemset(w[i], 0, maxw * 2)); CK(hipMemset(x, 0, (size_t)M * 28672 * 2)); }
-  unsigned* tickets = nullptr;
-  if (!getenv("NOTICKETS")) { CK(hipMalloc(&tickets, 16384 * 4)); CK(hipMemset(tickets, 0, 16384 * 4)); }
+  LiaGemmOpts* const tickets = nullptr;       // (default options; the r04 in-launch combine and its tickets are gone)
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
@@ -96,81 +93,7 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  if (getenv("T4STAMPS")) {
-    // phased kernel (variant 262): where a workgroup's time goes -- prologue / K loop / epilogue, and the gap to the next
-    // workgroup on the same CU slot (start-to-start minus the three), averaged over the workgroups of one launch
-    for (auto& sh : shapes) {
-      if (!strcmp(sh.name, "dummy")) continue;
-      LiaEpilogue ep{bias, res, sh.N, 0};
-      LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
-      lia_gemm_set_tiled_variant(atoi(getenv("T4STAMPS")));
-      for (int rep = 0; rep < 3; ++rep) lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
-      CK(hipStreamSynchronize(st));
-      const int nwg = std::min(8192, ((M + 255) / 256) * ((sh.N + 255) / 256));
-      std::vector<unsigned long long> h(8192 * 8);
-      CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_t4_stamps), h.size() * 8));
-      double pro = 0, loop = 0, epi = 0, e_issue = 0, e_p0 = 0, e_p1 = 0, e_drain = 0; unsigned long long first = ~0ull, last = 0;
-      for (int g = 0; g < nwg; ++g) {
-        const unsigned long long* q = h.data() + 8 * g;
-        pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]);
-        e_issue += (double)(q[4] - q[2]); e_p0 += (double)(q[5] - q[4]); e_p1 += (double)(q[6] - q[5]); e_drain += (double)(q[3] - q[6]);
-        first = std::min(first, q[0]); last = std::max(last, q[3]);
-      }
-      printf("   epilogue of wave 0: residual loads issued %.2f us, first half (wait + LDS pass + stores issued) %.2f us, second half %.2f us, store drain %.2f us\n",
-             e_issue * 0.01 / nwg, e_p0 * 0.01 / nwg, e_p1 * 0.01 / nwg, e_drain * 0.01 / nwg);
-      const double per_wg_wall = (double)(last - first) * 0.01 / (nwg / 256.0);
-      printf("%-8s N=%d K=%d: %d workgroups; per workgroup: prologue %.2f us, K loop %.2f us (%.3f us per K-tile), epilogue %.2f us; "
-             "kernel span / (workgroups per CU) = %.2f us -> unaccounted %.2f us per workgroup\n", sh.name, sh.N, sh.K, nwg, pro * 0.01 / nwg,
-             loop * 0.01 / nwg, loop * 0.01 / nwg / (sh.K / 64), epi * 0.01 / nwg, per_wg_wall,
-             per_wg_wall - (pro + loop + epi) * 0.01 / nwg);
-    }
-    return 0;
-  }
-  {
-    // one launch of the staggered kernel, then the barrier-to-barrier intervals of waves 0 (group 0) and 4 (group 1)
-    auto& sh = shapes[0];
-    LiaEpilogue ep{bias, res, sh.N, 0};
-    LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
-    lia_gemm_set_tiled_variant(257);
-    for (int rep = 0; rep < 2; ++rep) lia_gemm_launch(x, sh.K, w[0], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
-    CK(hipStreamSynchronize(st));
-    std::vector<unsigned long long> h(2 * 4096);
-    CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_t3_stamps), h.size() * 8));
-    for (int g = 0; g < 2; ++g) {
-      printf("group %d (stamps: before/after each barrier; intervals in cycles of the 100 MHz-or-shader counter):\n", g);
-      const unsigned long long* p = h.data() + g * 4096;
-      // stamp 2i = arrival at barrier i, 2i+1 = release.  work(i) = arrival(i) - release(i-1); wait(i) = release(i) - arrival(i)
-      for (int i = 4; i < 4 + 24; ++i) printf("  barrier %2d: work %6llu  wait %6llu\n", i, p[2 * i] - p[2 * i - 1], p[2 * i + 1] - p[2 * i]);
-      printf("  total over 400 barriers: %llu\n", p[2 * 404] - p[2 * 4]);
-    }
-    return 0;
-  }
 #endif
-  if (getenv("CHECK")) {
-    // variant 257 against variant 256 on the same operands: the two kernels add the same products in the same order
-    // (k ascending inside one accumulator), so the outputs must be bit-identical
-    uint16_t* y2; CK(hipMalloc(&y2, (size_t)M * 50272 * 2));
-    std::vector<uint16_t> h1, h2;
-    for (auto& s : shapes) {
-      LiaEpilogue ep{bias, res, s.N, 0};
-      LiaOutMap om; memset(&om, 0, sizeof(om)); om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
-      for (int rep = 0; rep < 3; ++rep) {
-        om.base[0] = y; lia_gemm_set_tiled_variant(256);
-        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
-        om.base[0] = y2; lia_gemm_set_tiled_variant(getenv("VARIANT") ? atoi(getenv("VARIANT")) : 257);
-        lia_gemm_launch(x, s.K, w[0], s.K, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr);
-        CK(hipStreamSynchronize(st));
-        size_t n = (size_t)M * s.N; h1.resize(n); h2.resize(n);
-        CK(hipMemcpy(h1.data(), y, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), y2, n * 2, hipMemcpyDeviceToHost));
-        size_t bad = 0, first = 0;
-        for (size_t i = 0; i < n; ++i) if (h1[i] != h2[i]) { if (!bad) first = i; ++bad; }
-        printf("%-8s M=%d N=%d K=%d rep %d: %zu mismatches", s.name, M, s.N, s.K, rep, bad);
-        if (bad) printf(" (first at m=%zu n=%zu: %04x vs %04x)", first / s.N, first % s.N, h1[first], h2[first]);
-        printf("\n");
-      }
-    }
-    return 0;
-  }
   for (auto& s : shapes) {
     LiaEpilogue ep{getenv("NOBIAS") ? nullptr : bias, getenv("NORES") ? nullptr : res, s.N, 0};
     LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;

@@ -3,7 +3,7 @@
 // denormals, large outliers and Inf / NaN.  Checks both against the source bit for bit, then times them (HIP events, cold input:
 // 0.83 GB in + 1.23 GB out per launch is larger than L2 + Infinity Cache).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DLIA_PACK10_AB -I isca-2025-lia_amd/csrc -I include tools/pack10_decode_bench.hip -o tools/pack10_decode_bench
-#include "../isca-2025-lia_amd/csrc/lia_pack12.hip"
+#include "../isca-2025-lia_amd/csrc/lia_pack10.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
