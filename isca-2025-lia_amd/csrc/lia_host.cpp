@@ -579,51 +579,25 @@ static void host_linear_skinny(const lia_bf16* x, const lia_bf16* w, const lia_b
   }
 }
 
-// y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual]; 4 x 4 register blocks, K % 32 == 0.
+// y[M,N] = act(x[M,K] . w[N,K]^T + bias) [+ residual], K % 32 == 0.  Any M: more than 256 rows (policy 1's prefill) go through the
+// SAME register-blocked kernel as a decode step, 256 rows at a time inside one parallel region (r05: a separate 4 x 4 kernel for
+// M > 256 ran at 2.6 TFLOP/s on 16 Zen 5 cores where the decode kernel reaches 6.3-7.5; a panel's x slice is the 1 MB the kernel's
+// K-chunking was tuned for, and the weights' re-read per panel -- 64 x 411 MB for OPT-30B's fc1 at B 64 x T 256 -- is 27 GB/s of
+// DRAM traffic beside ~1 s of arithmetic).  Prefill rows and decode rows now see the same arithmetic in the same order.
 static void host_linear(const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, const lia_bf16* residual, lia_bf16* y,
                         long M, int N, int K, int relu) {
   if (M <= 256) { host_linear_skinny(x, w, bias, residual, y, (int)M, N, K, relu); return; }
-  constexpr int RB = 4;
-  const long mblocks = (M + RB - 1) / RB;
-  const int nblocks = (N + RB - 1) / RB;
-  // decode-sized M: parallel over weight rows (each streamed once); prefill-sized M: over both, 256-row x panels
-  const long MP = 256;
-#pragma omp parallel for collapse(2) schedule(dynamic, 4)
-  for (long mp = 0; mp < M; mp += MP)
-    for (int nb = 0; nb < nblocks; ++nb) {
-      const int n0 = nb * RB, nr = N - n0 < RB ? N - n0 : RB;
-      const long mend = mp + MP < M ? mp + MP : M;
-      for (long m0 = mp; m0 < mend; m0 += RB) {
-        const int mr = mend - m0 < RB ? (int)(mend - m0) : RB;
-        __m512 acc[RB][RB];
-        for (int i = 0; i < RB; ++i)
-          for (int j = 0; j < RB; ++j) acc[i][j] = _mm512_setzero_ps();
-        if (mr == RB && nr == RB) {
-          // full block: constant trip counts keep the 16 accumulators in zmm registers
-          const lia_bf16* xr = x + m0 * (long)K;
-          const lia_bf16* wr = w + (long)n0 * K;
-          for (int k = 0; k < K; k += 32) {
-#pragma GCC unroll 4
-            for (int i = 0; i < RB; ++i)
-#pragma GCC unroll 4
-              for (int j = 0; j < RB; ++j) acc[i][j] = dp32(acc[i][j], xr + i * (long)K + k, wr + j * (long)K + k);
-          }
-        } else {
-          for (int k = 0; k < K; k += 32)
-            for (int i = 0; i < mr; ++i)
-              for (int j = 0; j < nr; ++j) acc[i][j] = dp32(acc[i][j], x + (m0 + i) * (long)K + k, w + (long)(n0 + j) * K + k);
-        }
-        for (int i = 0; i < mr; ++i)
-          for (int j = 0; j < nr; ++j) {
-            float t = _mm512_reduce_add_ps(acc[i][j]) + (bias ? bf16_to_f32(bias[n0 + j]) : 0.f);
-            t = round_bf16(t);
-            if (relu && t < 0.f) t = 0.f;
-            if (residual) t = round_bf16(bf16_to_f32(residual[(m0 + i) * (long)N + n0 + j]) + t);
-            y[(m0 + i) * (long)N + n0 + j] = f32_to_bf16(t);
-          }
-      }
+  HostCall* const call = tl_call;
+#pragma omp parallel
+  {
+    HostCall* const prev = team_enter(call);
+    for (long mp = 0; mp < M; mp += 256) {
+      const int rows = (int)(M - mp < 256 ? M - mp : 256);
+      // (the kernel's worksharing loop is `nowait`: a thread that has finished its tiles of this panel starts on the next one)
+      host_linear_skinny_team(x + mp * (long)K, w, bias, residual ? residual + mp * (long)N : nullptr, y + mp * (long)N, rows, N, K, relu);
     }
-  (void)mblocks;
+    team_leave(prev);
+  }
 }
 
 // The linears are compiled for AVX-512-BF16 (vdpbf16ps); on a host without it the first such instruction would be a

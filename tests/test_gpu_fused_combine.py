@@ -176,10 +176,7 @@ def test_two_contexts_of_one_process_keep_their_own_switches():
     other still fuses (r04 had process-wide lia_gemm_set_* setters), and both give the same bits"""
     import torch
     from lia_amd import _native as N_, ops
-    M, Nn, K = 64, 1024, 4096
-    g = torch.Generator(device="cuda").manual_seed(5)
-    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
-    H, heads, F = 1024, 8, 4096
+    M, H, heads, F = 64, 1024, 8, 4096
     la = _layer_setup(torch, ops, synth.make_layer(41, H, F, 0.05), H, heads, F)
     a, b = ops.Context(0, 1 << 28), ops.Context(0, 1 << 28)
     b.set_option(N_.LIA_OPT_FUSE_COMBINE, 0)

@@ -302,8 +302,8 @@ def test_tier_moves_leave_the_layer_usable_when_the_host_allocation_is_refused(m
         raise MemoryError(f"{what}: refused by the test")
 
     monkeypatch.setattr(hostinfo, "guard_host_allocation", refuse)
-    assert st.packed == 10                        # (the default wire format: to_pinned(10) would be a no-op, so ask for another one)
-    for move in (lambda: st.to_pinned(12), lambda: st.to_cxl(0), lambda: st.to_pinned(0, shard=(0, 2))):
+    assert st.packed == 10                        # (the default wire format: to_pinned(10) would be a no-op, so ask for the raw one)
+    for move in (lambda: st.to_pinned(0), lambda: st.to_cxl(0), lambda: st.to_pinned(0, shard=(0, 2))):
         with pytest.raises(MemoryError):
             move()
         assert st.tier == "device" and st._dev is not None and st._ptr is None        # nothing lost, nothing leaked
@@ -394,6 +394,11 @@ def test_bench_line_contract_on_a_small_model():
     assert abs(rf["algorithmic_h2d_gbs"] - rf["algorithmic_h2d_bytes"] / (d["ms_per_step"] * 1e6)) < 1e-6 * rf["algorithmic_h2d_gbs"]
     # ... and the two numbers a reader compares the headline with sit at the top level of the line, not only in roofline.scalars
     assert d["value_raw_format"] > 0 and d["prefill_ms_defer_kv_0"] > 0
+    # what run.py --auto-plan would choose on this box, and the leg of this run that measured it
+    ap = d["auto_plan"]
+    assert "error" not in ap and ap["chosen"]["gpu_percentage"] <= 25 and ap["chosen"]["decoding_policy"] in (2, 3) and ap["predicted_tokens_per_s"] > 0
+    assert ap["measured_by_leg"] in ("value", "value_cooperative", "value_cooperative_kv_in_hbm")
+    assert d["cpu_baseline"]["prefill"]["kind"].startswith("product host path") and d["cpu_baseline"]["prefill"]["prefill_ms"] > 0
     assert rf["scalars"]["value_raw_format"] == d["value_raw_format"] and rf["scalars"]["prefill_ms_defer_kv_0"] == d["prefill_ms_defer_kv_0"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "tokens/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]

@@ -10,7 +10,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
-common="--no-cpu-baseline --no-raw-leg --no-cooperative-leg --no-defer-kv-leg"
+common="--no-cpu-baseline --no-raw-leg --no-cooperative-leg --no-defer-kv-leg --no-auto-plan"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -o kt -- python3 bench.py --steps 8 $common "$@" > "$out/kt.log" 2>&1
 tail -1 "$out/kt.log" | cut -c1-200
 for c in FETCH_SIZE WRITE_SIZE; do
