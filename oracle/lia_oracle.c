@@ -4,9 +4,14 @@
  * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg may load this library; the product path (isca-2025-lia_amd/) never links or calls it.
  *
- * Parity status: the reference has no test that exercises any LIA flag, so this
+ * Parity status: PINNED.  The reference has no test that exercises any LIA flag, so this
  * restatement is pinned against outputs of the reference's own functions executed in the build
- * container (tests/golden/make_golden.py -> the .npz fixtures beside it), not against reference-held vectors.
+ * container (tests/golden/make_golden.py -> the .npz fixtures beside it): OPTDecoderLayer_forward / _OPTAttention_forward with
+ * policy 0, 3, 2 and -- since r05 -- policy 1 (the CPU branch over nn.LayerNorm / nn.Linear / _IPEXlinearAddRef /
+ * _IPEXlinearReluRef / _IPEXScaleDotProductRef), OPTLearnedPositionalEmbedding, and stock-HF greedy ids.  The one piece that can
+ * only be restated, not executed, is the C++ masked-MHA kernel behind policy 1 / 2 attention (Krnl.cpp; IPEX cannot be built
+ * here): it is compared with its executable pure-torch twin at the reference's own kernel-test tolerance, and the pinning mode
+ * lia_oracle_set_attn_twin swaps it for the twin's rounding points so that everything around it is checked bit for bit.
  *
  * Every function cites the reference code it restates.  Paths are relative to /root/reference;
  *   decoder.py    = intel_extension_for_pytorch/transformers/models/reference/modules/decoder.py
