@@ -414,68 +414,6 @@ __global__ __launch_bounds__(256) void lia_pack10_decode_kernel(const char* __re
   }
 }
 
-#ifdef LIA_PACK10_AB
-// the r01-r04 decode, kept for tools/pack10_decode_bench.hip only (bit-identity + timing of the two)
-__global__ __launch_bounds__(256) void lia_pack10_decode_v1_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
-  const LiaPack10Header* hd = (const LiaPack10Header*)src;
-  const size_t nblk = hd->n / 1024;
-  const Lp10Region* rtab = (const Lp10Region*)(src + hd->off_rtab);
-  const int rshift = (int)hd->region_shift;
-  const uint8_t* pa = (const uint8_t*)(src + hd->off_a);
-  const uint16_t *p0 = (const uint16_t*)(src + hd->off_b0), *p1 = (const uint16_t*)(src + hd->off_b1);
-  const uint32_t* tab2 = (const uint32_t*)(src + hd->off_tab2);
-  const uint32_t* tab3 = (const uint32_t*)(src + hd->off_tab3);
-  const uint32_t* l2w = (const uint32_t*)(src + hd->off_l2);
-  const uint32_t* l3w = (const uint32_t*)(src + hd->off_l3);
-  const int lane = threadIdx.x & 63;
-  size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const size_t stride = (size_t)gridDim.x * 4;
-  for (; blk < nblk; blk += stride) {
-    const Lp10Region rt = rtab[blk >> rshift];
-    const uint32_t sym1 = rt.sym1, sym2 = rt.sym2, e3 = rt.e3;
-    const size_t g = blk * 64 + lane;
-    const uint4 av = *(const uint4*)(pa + g * 16);
-    const uint32_t a[4] = {av.x, av.y, av.z, av.w};
-    const uint32_t b0 = p0[g], b1 = p1[g];
-    const uint32_t esc1 = b0 & b1;
-    const int n2 = __popc(esc1);
-    int t2;
-    const int ex2 = wave_excl_scan(n2, lane, t2);
-    uint32_t l2 = 0;
-    if (n2) l2 = (uint32_t)lp10_get_bits(l2w, ((uint64_t)tab2[blk] + ex2) * 2, 2 * n2);
-    if (n2 < 16) l2 &= (1u << (2 * n2)) - 1u;
-    const int n3 = __popc(l2 & (l2 >> 1) & 0x55555555u);
-    int t3;
-    const int ex3 = wave_excl_scan(n3, lane, t3);
-    uint64_t l3 = 0;
-    if (n3) l3 = lp10_get_bits(l3w, ((uint64_t)tab3[blk] + ex3) * 4, 4 * n3);
-    uint32_t o[8];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t sm = (a[k >> 2] >> ((k & 3) * 8)) & 0xff;
-      const uint32_t c1 = ((b0 >> k) & 1) | (((b1 >> k) & 1) << 1);
-      uint32_t ex;
-      if (c1 < 3) ex = (sym1 >> (8 * c1)) & 0xff;
-      else {
-        const uint32_t c2 = l2 & 3;
-        l2 >>= 2;
-        if (c2 < 3) ex = (sym2 >> (8 * c2)) & 0xff;
-        else {
-          const uint32_t nib = (uint32_t)(l3 & 0xf);
-          l3 >>= 4;
-          ex = nib < 14 ? e3 + nib : 0;      // 14: exponent 0; 15: placeholder, patched from the escape records
-        }
-      }
-      const uint32_t x = ((sm & 0x80) << 8) | (ex << 7) | (sm & 0x7f);
-      if (k & 1) o[k >> 1] |= x << 16; else o[k >> 1] = x;
-    }
-    *(uint4*)(dst + g * 16) = uint4{o[0], o[1], o[2], o[3]};
-    *(uint4*)(dst + g * 16 + 8) = uint4{o[4], o[5], o[6], o[7]};
-  }
-}
-
-#endif
-
 __global__ __launch_bounds__(256) void lia_pack10_patch_kernel(const char* __restrict__ src, bf16_t* __restrict__ dst) {
   const LiaPack10Header* hd = (const LiaPack10Header*)src;
   const uint2* esc = (const uint2*)(src + hd->off_esc);
