@@ -1263,13 +1263,20 @@ extern "C" int lia_stream_decode_packed(lia_streamer* s, int slot, size_t n_valu
   HIP_TRY(hipEventRecord(s->t1[slot], s->copy));                       // copy-engine busy time ends here
   HIP_TRY(hipEventRecord(s->landed[slot], s->copy));
   HIP_TRY(hipStreamWaitEvent(s->decode, s->landed[slot], 0));
-  streamer_collect_decode(s, slot, true);                              // (the slot's previous decode finished long ago: its consumer released the slot)
+  // the timing bracket re-uses the slot's event pair: collect the previous launch first -- WITHOUT waiting (this runs inside the
+  // token loop).  The slot's previous decode finished long ago (its consumer released the slot); should it not have -- a dropped
+  // prefetch whose decode is still in flight -- this launch simply goes untimed.
+  streamer_collect_decode(s, slot, false);
+  (void)hipGetLastError();                                             // hipErrorNotReady from the query is an answer, not an error
+  const bool timed = !s->decode_pending[slot];
   lia_packed_decode_launch(s->staging + (size_t)slot * s->staging_bytes, (bf16_t*)(s->slots + (size_t)slot * s->slot_bytes), n_values, s->decode,
-                           s->d0[slot], s->d1[slot]);
+                           timed ? s->d0[slot] : nullptr, timed ? s->d1[slot] : nullptr);
   HIP_TRY(hipGetLastError());
-  s->decode_in[slot] = (double)s->pending_bytes[slot];
-  s->decode_out[slot] = 2.0 * (double)n_values;
-  s->decode_pending[slot] = 1;
+  if (timed) {
+    s->decode_in[slot] = (double)s->pending_bytes[slot];
+    s->decode_out[slot] = 2.0 * (double)n_values;
+    s->decode_pending[slot] = 1;
+  }
   s->decoded_on_side[slot] = 1;
   return LIA_OK;
 }
