@@ -472,19 +472,12 @@ extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, 
 // Decode either format (the header's magic says which); asynchronous on `st`.
 // ev0 / ev1 (nullable): recorded on `st` immediately around the MAIN decode kernel (lia_stream_decode_stats; the patch kernel
 // behind it -- a few hundred escape records -- is outside the bracket, as a profiler's per-kernel duration would have it).
-// The decode stream sits idle behind an event wait until the layer's copy lands, and the first dispatch after such a wait pays the
-// queue's wake-up (~20 us on an otherwise idle GPU: the first r05 profile read 392 us per kernel where the bracket read 416): a
-// one-wave no-op kernel in front of ev0 takes that latency, so the bracket times the decode kernel the way rocprofv3 does.
-__global__ void lia_pack_nop_kernel() {}
 extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const size_t nblk = n_values / 1024;
   unsigned blocks = (unsigned)((nblk + 3) / 4);
   if (blocks > LP10_DECODE_GRID) blocks = LP10_DECODE_GRID;
   if (blocks == 0) return;
-  if (ev0) {
-    hipLaunchKernelGGL(lia_pack_nop_kernel, dim3(1), dim3(64), 0, st);
-    (void)hipEventRecord(ev0, st);
-  }
+  if (ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(lia_pack10_decode_kernel, dim3(blocks), dim3(256), 0, st, src, dst);
   if (ev1) (void)hipEventRecord(ev1, st);
   hipLaunchKernelGGL(lia_pack10_patch_kernel, dim3(64), dim3(256), 0, st, src, dst);
