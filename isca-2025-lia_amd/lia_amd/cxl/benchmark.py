@@ -25,11 +25,14 @@ from ..ops import Context
 from .numa_alloc import numa_alloc_tensor, numa_free_tensor, set_cxl_nodes
 
 NUMBER, REPEAT, WARMUP = 3, 3, 2          # benchmark.py:10-12
-CHUNK = 1 << 30                           # the 4 GiB buffer crosses the link in four 1 GiB slot-sized copies
+CHUNK = 4 << 30                           # slot size: the reference's 4 GiB buffer is ONE copy per transfer (larger buffers go in 4 GiB pieces)
 
 
 class _Transfer:
-    """the host buffer of one tier + a two-slot streamer; run() = REPEAT timed groups of NUMBER whole-buffer transfers"""
+    """the host buffer of one tier + a two-slot streamer; run() = REPEAT timed groups of NUMBER whole-buffer transfers.  A transfer
+    is enqueued asynchronously; the only host-side wait is lia_stream_begin's collection of the SAME slot's previous copy, i.e. the
+    copy engine always has the next transfer queued while the host thread sleeps -- which matters beside the CPU GEMM, when that
+    thread may not get a CPU for tens of milliseconds (r05's first version moved 1 GiB pieces and read 22 GB/s there instead of 47)"""
 
     def __init__(self, from_cxl, register, nbytes):
         self.lib, self.nbytes, self.numa = N.lib(), nbytes, None
@@ -85,6 +88,11 @@ class _Transfer:
 
 class _Compute:
     def __init__(self, mm):
+        from .. import hostinfo
+        # torch sizes its pool by the CPUs it SEES (256 on the GPU box), not by the container's quota (16): an unbounded 8192^3 GEMM
+        # is throttled by CFS and takes every other thread of the process down with it.  The reference runs on a box it owns
+        # (run.sh:1-14); the bound from this box's own numbers is the equivalent.
+        hostinfo.cap_torch_threads()
         self.a, self.b = torch.ones(mm, mm), torch.ones(mm, mm)
         self.costs, self.total = [], 0.0
 

@@ -48,11 +48,14 @@ int main(int argc, char** argv) {
     void* sp; CK(hipGetSymbolAddress(&sp, HIP_SYMBOL(g_s2_stamps)));
     for (auto& sh : shapes) {
       if (!strcmp(sh.name, "dummy")) continue;
-      LiaEpilogue ep{bias, res, sh.N, 0};
+      const bool glu = getenv("GLU") && !strcmp(sh.name, "gate_up");   // the Llama layer's own call: no bias / residual, SiLU*up paired by the epilogue
+      LiaEpilogue ep{glu ? nullptr : bias, glu ? nullptr : res, sh.N, 0};
       LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = sh.N; om.seg_n = sh.N; om.T = 1;
+      LiaPost post{}; post.kind = LIA_POST_SILU_MUL; post.out = res; post.ldo = sh.N / 2; post.gu_block = LIA_GU_BLOCK;
+      int post_done = 0;
       for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemsetAsync(sp, 0, 8192 * 8 * 8, st));
-        lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, e0, e1, nullptr, nullptr, nullptr);
+        lia_gemm_launch(x, sh.K, w[rep % NBUF], sh.K, M, sh.N, sh.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, e0, e1, nullptr, glu ? &post : nullptr, glu ? &post_done : nullptr);
       }
       CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -95,14 +98,19 @@ int main(int argc, char** argv) {
   }
 #endif
   for (auto& s : shapes) {
-    LiaEpilogue ep{getenv("NOBIAS") ? nullptr : bias, getenv("NORES") ? nullptr : res, s.N, 0};
+    const bool glu = getenv("GLU") && !strcmp(s.name, "gate_up");
+    LiaEpilogue ep{(getenv("NOBIAS") || glu) ? nullptr : bias, (getenv("NORES") || glu) ? nullptr : res, s.N, 0};
     LiaOutMap om; memset(&om, 0, sizeof(om)); om.base[0] = y; om.ld[0] = s.N; om.seg_n = s.N; om.T = 1;
+    LiaPost post_{}; post_.kind = LIA_POST_SILU_MUL; post_.out = res; post_.ldo = s.N / 2; post_.gu_block = LIA_GU_BLOCK;
+    int post_done_ = 0;
+    const LiaPost* post = glu ? &post_ : nullptr;
+    int* post_done = glu ? &post_done_ : nullptr;
     const int iters = M > 256 ? 4 : 12;
     const long ldp = getenv("LDPAD") ? atol(getenv("LDPAD")) : 0;   // row stride = K + LDPAD elements (aliasing experiment)
-    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, nullptr, nullptr);
+    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, post, post_done);
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
-    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, nullptr, nullptr);
+    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, post, post_done);
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     double bytes = 2.0 * ((double)s.N * s.K + (double)M * s.K + (double)M * s.N);
