@@ -266,7 +266,8 @@ int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, lia_streamer
 void lia_stream_destroy(lia_streamer* s);
 void* lia_stream_slot_ptr(lia_streamer* s, int slot);
 /* enqueue host -> slot; first waits (on the copy stream) until the slot's last consumer released it.
- * pinned = 0 stages through the streamer's pinned bounce buffer (the reference's cpu_buff path,
+ * pinned = 0 stages through the streamer's two pinned 64 MiB bounce buffers -- a team memcpy fills one while the copy engine drains
+ * the other -- (the reference's cpu_buff path,
  * modeling_opt.py:1219-1220, 1289-1292). */
 int lia_stream_prefetch(lia_streamer* s, int slot, const void* host_ptr, size_t bytes, int pinned);
 /* the same in three steps, for callers that put work of their own (an RCCL broadcast of each chunk to the

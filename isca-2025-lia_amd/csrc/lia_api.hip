@@ -1094,7 +1094,11 @@ struct lia_streamer {
   std::vector<hipEvent_t> copied, released, t0, t1;
   std::vector<char> has_release, timing_pending, was_marked;
   std::vector<size_t> pending_bytes;
-  char* bounce;
+  // pageable sources (the reference's un-pinned numa_alloc tensors, a layer kept without --pin-weight) are staged through two pinned
+  // bounce buffers of LIA_BOUNCE_BYTES: a team memcpy fills one while the copy engine drains the other (staged_copy)
+  char* bounce[2];
+  hipEvent_t bounce_done[2];
+  int bounce_next;
   double bytes, busy_ms;
 };
 
@@ -1127,7 +1131,8 @@ extern "C" int lia_stream_create(lia_ctx* ctx, int n_slots, size_t slot_bytes, l
   *out = nullptr;
   lia_streamer* s = new lia_streamer();
   s->ctx = ctx; s->n_slots = n_slots; s->slot_bytes = align_up(slot_bytes, 256);
-  s->bounce = nullptr; s->bytes = 0; s->busy_ms = 0; s->slots = nullptr; s->staging = nullptr; s->staging_bytes = 0;
+  s->bounce[0] = s->bounce[1] = nullptr; s->bounce_done[0] = s->bounce_done[1] = nullptr; s->bounce_next = 0;
+  s->bytes = 0; s->busy_ms = 0; s->slots = nullptr; s->staging = nullptr; s->staging_bytes = 0;
   s->dec_ms = s->dec_in = s->dec_out = 0; s->dec_launches = 0;
   HIP_TRY(hipMalloc((void**)&s->slots, s->slot_bytes * n_slots));
   if (ctx->serialized) s->copy = ctx->compute;
@@ -1152,7 +1157,10 @@ extern "C" void lia_stream_destroy(lia_streamer* s) {
     (void)hipEventDestroy(s->copied[i]); (void)hipEventDestroy(s->released[i]);
     (void)hipEventDestroy(s->t0[i]); (void)hipEventDestroy(s->t1[i]);
   }
-  if (s->bounce) (void)hipHostFree(s->bounce);
+  for (int i = 0; i < 2; ++i) {
+    if (s->bounce[i]) (void)hipHostFree(s->bounce[i]);
+    if (s->bounce_done[i]) (void)hipEventDestroy(s->bounce_done[i]);
+  }
   if (s->slots) (void)hipFree(s->slots);
   if (s->staging) {
     (void)hipStreamSynchronize(s->decode);
@@ -1188,20 +1196,40 @@ extern "C" int lia_stream_begin(lia_streamer* s, int slot) {
   return LIA_OK;
 }
 
+// Pageable source -> device through the two pinned bounce buffers (the reference's cpu_buff, modeling_opt.py:1219-1220, and what
+// `copy_(non_blocking=True)` from its un-pinned numa_alloc tensors does inside torch).  r01-r04: one slot-sized bounce buffer, a
+// single-threaded memcpy behind a stream synchronize -- 16.6 GB/s in the H2D microbenchmark twin where torch's own staging reaches
+// 51.  Now 64 MiB pieces, a team memcpy (lia_host_parallel_memcpy, the context's host threads) into one buffer while the copy engine
+// drains the other; the host thread waits only for the buffer it is about to overwrite.
+constexpr size_t LIA_BOUNCE_BYTES = (size_t)64 << 20;
+extern "C" void lia_host_parallel_memcpy(void* dst, const void* src, size_t bytes, int n_threads);
+static int staged_copy(lia_streamer* s, char* dst_device, const void* host_ptr, size_t bytes) {
+  for (int i = 0; i < 2; ++i)
+    if (!s->bounce[i]) {
+      HIP_TRY(hipHostMalloc((void**)&s->bounce[i], LIA_BOUNCE_BYTES, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&s->bounce_done[i], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(s->bounce_done[i], s->copy));
+    }
+  for (size_t off = 0; off < bytes; off += LIA_BOUNCE_BYTES) {
+    const size_t n = std::min(LIA_BOUNCE_BYTES, bytes - off);
+    const int b = s->bounce_next;
+    s->bounce_next ^= 1;
+    HIP_TRY(hipEventSynchronize(s->bounce_done[b]));                 // the DMA that last read this buffer has finished
+    lia_host_parallel_memcpy(s->bounce[b], (const char*)host_ptr + off, n, s->ctx->host_threads);
+    HIP_TRY(hipMemcpyAsync(dst_device + off, s->bounce[b], n, hipMemcpyHostToDevice, s->copy));
+    HIP_TRY(hipEventRecord(s->bounce_done[b], s->copy));
+  }
+  return LIA_OK;
+}
+
 extern "C" int lia_stream_copy_chunk(lia_streamer* s, int slot, size_t offset, const void* host_ptr, size_t bytes, int pinned) {
   if (!s || slot < 0 || slot >= s->n_slots || !host_ptr || offset + bytes > s->slot_bytes) {
     lia_set_error("lia_stream_copy_chunk: slot=%d offset=%zu bytes=%zu (slot holds %zu)", slot, offset, bytes, s ? s->slot_bytes : 0);
     return LIA_ERR_INVALID;
   }
-  const void* src = host_ptr;
-  if (!pinned) {
-    // pageable source: stage through a pinned bounce buffer (the reference's cpu_buff, modeling_opt.py:1219-1220)
-    if (!s->bounce) HIP_TRY(hipHostMalloc((void**)&s->bounce, s->slot_bytes, hipHostMallocDefault));
-    HIP_TRY(hipStreamSynchronize(s->copy));  // previous use of the bounce buffer has left the host
-    memcpy(s->bounce, host_ptr, bytes);
-    src = s->bounce;
-  }
-  HIP_TRY(hipMemcpyAsync(s->slots + (size_t)slot * s->slot_bytes + offset, src, bytes, hipMemcpyHostToDevice, s->copy));
+  char* const dst = s->slots + (size_t)slot * s->slot_bytes + offset;
+  if (pinned) HIP_TRY(hipMemcpyAsync(dst, host_ptr, bytes, hipMemcpyHostToDevice, s->copy));
+  else if (int rc = staged_copy(s, dst, host_ptr, bytes)) return rc;
   s->pending_bytes[slot] += bytes;
   return LIA_OK;
 }
@@ -1240,14 +1268,9 @@ extern "C" int lia_stream_copy_chunk_packed(lia_streamer* s, int slot, size_t of
   int rc = ensure_staging(s);
   if (rc) return rc;
   if (offset + bytes > s->staging_bytes) { lia_set_error("lia_stream_copy_chunk_packed: %zu + %zu > staging %zu", offset, bytes, s->staging_bytes); return LIA_ERR_INVALID; }
-  const void* src = host_ptr;
-  if (!pinned) {
-    if (!s->bounce) HIP_TRY(hipHostMalloc((void**)&s->bounce, s->slot_bytes, hipHostMallocDefault));
-    HIP_TRY(hipStreamSynchronize(s->copy));
-    memcpy(s->bounce, host_ptr, bytes);
-    src = s->bounce;
-  }
-  HIP_TRY(hipMemcpyAsync(s->staging + (size_t)slot * s->staging_bytes + offset, src, bytes, hipMemcpyHostToDevice, s->copy));
+  char* const dst = s->staging + (size_t)slot * s->staging_bytes + offset;
+  if (pinned) HIP_TRY(hipMemcpyAsync(dst, host_ptr, bytes, hipMemcpyHostToDevice, s->copy));
+  else if (int rc = staged_copy(s, dst, host_ptr, bytes)) return rc;
   s->pending_bytes[slot] += bytes;
   return LIA_OK;
 }

@@ -770,6 +770,22 @@ extern "C" int lia_host_layers_forward(const lia_layer_desc* d, int n_layers, co
   return n_layers & 1;
 }
 
+// memcpy by a team (the streamer's staging of pageable sources, lia_api.hip::staged_copy): 1 MiB pieces dealt out statically;
+// n_threads <= 0 = at most 8 (a caller that never said how many CPUs it owns: the box may show 256 and grant 16).  One thread moves
+// ~10 GB/s, the link takes 53.
+extern "C" void lia_host_parallel_memcpy(void* dst, const void* src, size_t bytes, int n_threads) {
+  constexpr size_t PIECE = (size_t)1 << 20;
+  const long pieces = (long)((bytes + PIECE - 1) / PIECE);
+  if (pieces <= 1) { memcpy(dst, src, bytes); return; }
+  int nt = n_threads > 0 ? n_threads : (omp_get_max_threads() < 8 ? omp_get_max_threads() : 8);
+  if (nt > pieces) nt = (int)pieces;
+#pragma omp parallel for schedule(static) num_threads(nt)
+  for (long i = 0; i < pieces; ++i) {
+    const size_t off = (size_t)i * PIECE;
+    memcpy((char*)dst + off, (const char*)src + off, bytes - off < PIECE ? bytes - off : PIECE);
+  }
+}
+
 // 1 when the vdpbf16ps inner loops are compiled in AND this CPU executes them
 extern "C" int lia_host_has_avx512_bf16(void) {
 #if LIA_HAVE_DPBF16

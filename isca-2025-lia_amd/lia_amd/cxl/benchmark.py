@@ -48,6 +48,8 @@ class _Transfer:
                 raise MemoryError(N.lib().lia_last_error().decode(errors="replace"))
             ctypes.memset(self.ptr, 1, nbytes)
         self.ctx = Context(0, 0)
+        from .. import hostinfo
+        self.ctx.set_host_threads(hostinfo.default_host_threads(1))      # the team that stages an unregistered source (lia_api.hip::staged_copy)
         self.chunk = min(CHUNK, nbytes)
         self.h = ctypes.c_void_p()
         N.check(self.lib.lia_stream_create(self.ctx.handle, 2, self.chunk, ctypes.byref(self.h)), "lia_stream_create")
