@@ -301,6 +301,47 @@ def test_layer_forward_error_codes(gpu):
         ctx.layer_forward(ops.make_desc(250, 5, 1024), 3, wptrs, x, y, kv, 2, 4, 0)  # head_dim 50
 
 
+def test_streamer_stages_a_pageable_source_in_pieces(gpu):
+    """lia_stream_prefetch(pinned = 0): a source that is neither pinned nor registered (the reference's un-pinned numa_alloc tensors,
+    a layer kept without --pin-weight) crosses the link through two 64 MiB bounce buffers filled by a team memcpy -- 150 MiB + 37
+    bytes is three pieces, the last one ragged -- and must arrive byte for byte; the pinned path of the same streamer afterwards
+    still works, and two slots in flight do not mix their pieces."""
+    import ctypes
+    ctx, ops, torch = gpu
+    from lia_amd import _native as N
+    L = N.lib()
+    n = (150 << 20) + 37
+    rs = np.random.RandomState(9)
+    bufs = [rs.randint(0, 256, size=n, dtype=np.uint8) for _ in range(2)]
+    slot_bytes = (n + 255) // 256 * 256
+    h = ctypes.c_void_p()
+    N.check(L.lia_stream_create(ctx.handle, 2, slot_bytes, ctypes.byref(h)))
+    ctx.set_host_threads(4)
+    try:
+        for slot, b in enumerate(bufs):                                   # both slots queued back to back: the bounce buffers alternate
+            N.check(L.lia_stream_prefetch(h, slot, ctypes.c_void_p(b.ctypes.data), n, 0))
+        for slot, b in enumerate(bufs):
+            N.check(L.lia_stream_wait(h, slot, ctypes.c_void_p(ctx.stream)))
+            ctx.synchronize()
+            back = np.empty(n, np.uint8)
+            N.check(L.lia_memcpy_d2h(back.ctypes.data, ctypes.c_void_p(L.lia_stream_slot_ptr(h, slot)), n))
+            assert (back == b).all(), f"slot {slot}: {int((back != b).sum())} of {n} bytes differ"
+            N.check(L.lia_stream_release(h, slot, ctypes.c_void_p(ctx.stream)))
+        pinned = torch.from_numpy(bufs[1][:1 << 20].copy()).pin_memory()
+        N.check(L.lia_stream_prefetch(h, 0, ctypes.c_void_p(pinned.data_ptr()), 1 << 20, 1))
+        N.check(L.lia_stream_wait(h, 0, ctypes.c_void_p(ctx.stream)))
+        ctx.synchronize()
+        back = np.empty(1 << 20, np.uint8)
+        N.check(L.lia_memcpy_d2h(back.ctypes.data, ctypes.c_void_p(L.lia_stream_slot_ptr(h, 0)), 1 << 20))
+        assert (back == bufs[1][:1 << 20]).all()
+        by, ms = ctypes.c_double(), ctypes.c_double()
+        N.check(L.lia_stream_stats(h, ctypes.byref(by), ctypes.byref(ms), 1))
+        assert by.value == 2 * n + (1 << 20) and ms.value > 0
+    finally:
+        L.lia_stream_destroy(h)
+        ctx.set_host_threads(0)
+
+
 @pytest.mark.parametrize("fmt", [10])
 @pytest.mark.parametrize("kind", ["normal", "wide", "zeros", "denormals", "specials"])
 def test_pack10_roundtrip_is_bit_exact(gpu, kind, fmt):
