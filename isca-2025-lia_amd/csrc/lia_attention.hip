@@ -195,38 +195,88 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// prefill, d = 128, second generation.  The arithmetic -- every product, rounding, max / sum update and its order -- is
-// that of lia_attn_prefill_kernel<128>, so the two kernels agree bit for bit; what changes is how the bytes move:
-//   * 64-key tiles (two 32-key blocks per barrier pair instead of one);
-//   * register-staged prefetch: the global loads of tile t+1 are issued before tile t is computed and written to LDS
-//     after the next barrier (cdna_hip_programming.md T14), so HBM / L2 latency hides behind the MFMAs;
-//   * V is staged row-major like K (two ds_write_b128 per thread instead of sixteen ds_write_b16) in the dual-use image
-//     off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) of T10, and the V^T operand is read with
-//     ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4-key x 16-dim block and
-//     receives one dim of the four keys.
+// prefill, d = 128, third generation (r05).  The arithmetic -- every product, rounding, max / sum update and its order -- is that
+// of lia_attn_prefill_kernel<128> and of the second generation (tools/attn_prefill_gen2.inc keeps that one;
+// tools/attn_prefill_bench compares the two bit for bit on OPT-30B's, Llama-3-8B's and ragged shapes).  What changed is how the work
+// is laid out, from per-wave cycle stamps and SQ counters of the second generation (LABNOTES.md r05: VALU 50 % busy, waves 40 % of
+// their life in waits, SIMD 3 / XCD 7 holding every heavy piece of the causal triangle):
+//   * K and V tiles (64 keys) go from global memory straight to LDS (global_load_lds, 16 B per lane, the images' chunk permutations
+//     applied on the source address), double-buffered, ONE barrier per tile; the stage after sweep 1's last tile is sweep 2's first;
+//   * a two-block tile runs as A: q.k chain of block 0 (fragments of block 1 fetched under it), B: chain of block 1 under the
+//     softmax arithmetic of block 0, C: P.V of block 0 under the arithmetic of block 1, D: P.V of block 1 -- interleaved by hand
+//     (sched_barrier between the pieces): hipcc otherwise serialises chain, arithmetic, chain, arithmetic;
+//   * the arithmetic works on pairs (v_pk_add / v_pk_mul / v_pk_fma_f32, one v_cvt_pk_bf16_f32 per pair), masks are selects
+//     (the second generation's `a || (b && c)` became a branch per element), POST_SCALE is a template parameter;
+//   * every other (batch row, head) takes its query blocks and the four row blocks of a workgroup in reverse order.
+// OPT-30B's B 64 x T 256 x 56 heads: 433 -> 333 us; Llama-3-8B's B 128 x T 1024 x 32 / 8 heads: 5.51 -> 3.23 ms.
+// V^T operand: ds_read_b64_tr_b16 from the row-major image off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+// (lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4-key x 16-dim block and receives one dim of the four keys).
 // ---------------------------------------------------------------------------------------------
 typedef short lia_v4s __attribute__((ext_vector_type(4)));
+#define GL_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
 
-__global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* __restrict__ q, long ldq,
-                                                                   const bf16_t* __restrict__ kc,
-                                                                   const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
-                                                                   long ldo, int T, int heads, int kv_heads, long kv_row,
-                                                                   long kv_batch, int b0, float scaling, int post_scale) {
+#define P3_KOFF(i) (((i) & 3) + 8 * ((i) >> 2))
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one v_cvt_pk_bf16_f32 for the pair (compiler-visible: inline asm would hide the MFMA -> VALU read hazard from the hazard recognizer)
+typedef __bf16 p3_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t p3_cvt_pk(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, p3_bf16x2));
+}
+// two scores at the reference's rounding points: bf16 of q.k; with POST_SCALE the product by d^-0.5 and its rounding (values of rbf())
+template <int POST_SCALE> __device__ __forceinline__ f32x2 p3_round2(float a, float b, float scaling) {
+  uint32_t p = p3_cvt_pk(a, b);
+  f32x2 r = {__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)};
+  if (POST_SCALE) {
+    const f32x2 t = r * scaling;
+    p = p3_cvt_pk(t.x, t.y);
+    r = f32x2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)};
+  }
+  return r;
+}
+// causal / length mask of elements 2 c, 2 c + 1 of the lane: key 32 kt + 4 h + P3_KOFF(i) is visible iff P3_KOFF(i) <= lim
+__device__ __forceinline__ f32x2 p3_mask2(f32x2 r, int lim, int c) {
+  return f32x2{(lim >= P3_KOFF(2 * c)) ? r.x : -INFINITY, (lim >= P3_KOFF(2 * c + 1)) ? r.y : -INFINITY};
+}
+// __expf(r - m) of a pair: the subtraction, the product by log2(e) and v_exp_f32, as __expf lowers it
+__device__ __forceinline__ f32x2 p3_exp2(f32x2 r, float m) {
+  const f32x2 t = (r - m) * 0x1.715476p+0f;
+  return f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+}
+// bf16(e / l) of a pair, packed: hoisted reciprocal + two residual corrections = the correctly rounded quotient (second generation)
+__device__ __forceinline__ uint32_t p3_prob2(f32x2 r, float m, float l, float rl) {
+  const f32x2 e = p3_exp2(r, m);
+  const f32x2 nl = (f32x2)(-l), rr = (f32x2)rl;
+  f32x2 q = e * rl;
+  q = __builtin_elementwise_fma(__builtin_elementwise_fma(nl, q, e), rr, q);
+  q = __builtin_elementwise_fma(__builtin_elementwise_fma(nl, q, e), rr, q);
+  return p3_cvt_pk(q.x, q.y);
+}
+
+template <int POST_SCALE>
+__global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
+                                                                  const bf16_t* __restrict__ vc, bf16_t* __restrict__ out, long ldo, int T,
+                                                                  int heads, int kv_heads, long kv_row, long kv_batch, int b0, float scaling) {
   constexpr int D = 128;
-  __shared__ __attribute__((aligned(16))) char k_lds[64 * 256];
-  __shared__ __attribute__((aligned(16))) char v_lds[64 * 256];
+  __shared__ __attribute__((aligned(16))) char lds[2][2][64 * 256];   // [buffer][0 = K, 1 = V][key row of 256 bytes]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int hh = blockIdx.y, b = blockIdx.z;
-  const int q_wg = blockIdx.x * 128;
-  const int q_wave = q_wg + wave * 32;
+  int bx = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+  // every other (batch row, head) takes its query blocks -- and, below, the four row blocks of a workgroup -- in reverse order:
+  // consecutive workgroup ids go to consecutive XCDs and wave w of a workgroup to SIMD w, and late rows have more keys to visit, so
+  // without it XCD 7 / SIMD 3 would get every heavy piece and XCD 0 / SIMD 0 every light one
+  const int rev = (hh + b) & 1;
+  if (rev) bx = gridDim.x - 1 - bx;
+  const int q_wg = bx * 128;
+  const int wsub = rev ? 3 - wave : wave;
+  const int q_wave = q_wg + wsub * 32;
   const int kh = hh / (heads / kv_heads);
-  // kv_row / kv_batch: elements between consecutive positions / batch rows of K and V.  Seq-major cache [S][Bc][h][d]:
-  // (Bc h d, h d); token-major projection output [B][T][h][d]: (h d, T h d)
   const bf16_t* kbase = kc + (long)(b0 + b) * kv_batch + (long)kh * D;
   const bf16_t* vbase = vc + (long)(b0 + b) * kv_batch + (long)kh * D;
-  const float qscale = post_scale ? 1.0f : scaling;
+  const float qscale = POST_SCALE ? 1.0f : scaling;
 
   bf16x8 qf[8];
   {
@@ -246,17 +296,32 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
   const int n32 = min((q_wg + 128 + 31) / 32, (T + 31) / 32);   // 32-key blocks the workgroup needs (causal)
   const int n64 = (n32 + 1) / 2;
   const int my_q = q_wave + r;
+  const int nblk = min(q_wave + 31, T - 1) / 32 + 1;            // 32-key blocks THIS wave needs: 0 .. nblk - 1
+  const int vis = min(my_q, T - 1) - 4 * h;                     // key 32 kt + 4 h + koff is visible iff koff <= vis - 32 kt
 
-  // staging: thread -> key rr*16 + tid/16 of the tile, chunk tid%16 (a key row = 256 contiguous bytes over 16 lanes)
-  const int skey = tid >> 4, sc = tid & 15;
-  const int k_wr = skey * 256 + ((sc ^ skey) << 4);                                   // + rr * 4096 (key & 15 == skey)
-  const int v_wr = skey * 256 + ((sc ^ (((skey & 3) << 2) | ((skey >> 2) & 3))) << 4);  // + rr * 4096 (16 rr keeps both fields)
-  // K^T fragment read: key row 32 sb + r, chunk 2 s + h
-  const int k_rd = r * 256;
-  // V^T transposed read: group g1 = (lane >> 4) & 1 takes dims 16 g1 .. +15 of the 32-dim block; lane i = lane & 15 of the
-  // group addresses key q = i >> 2, columns 4 p .. 4 p + 3 (p = i & 3)
+  // ---- staging by LDS-DMA: instruction j of wave w moves key rows 16 j + 4 w + (lane >> 4) of the tile, one 16-byte chunk per lane,
+  // to consecutive LDS bytes (1 KB per instruction); the images' chunk permutations are applied on the SOURCE side:
+  //   K: chunk c of row R sits in slot c ^ (R & 15);  V: in slot c ^ (((R & 3) << 2) | ((R >> 2) & 3))   (R & 15 = 4 w + (lane >> 4))
+  const int srow = 4 * wave + (lane >> 4), sslot = lane & 15;
+  const bf16_t* ksrc = kbase + 8 * (sslot ^ srow);
+  const bf16_t* vsrc = vbase + 8 * (sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
+#define P3_ISSUE(t, buf, WITH_V)                                                                                                   \
+  do {                                                                                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                             \
+      const long key_ = min((t) * 64 + 16 * j_ + srow, T - 1);                                                                     \
+      __builtin_amdgcn_global_load_lds(GL_AS1(ksrc + key_ * kv_row), LDS_AS3(&lds[buf][0][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
+      if (WITH_V)                                                                                                                  \
+        __builtin_amdgcn_global_load_lds(GL_AS1(vsrc + key_ * kv_row), LDS_AS3(&lds[buf][1][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
+    }                                                                                                                              \
+  } while (0)
+
+  // K^T fragment of 16-dim slice ss: key row 32 sb + r, chunk (2 ss + h) ^ (r & 15)
+  int k_rd[8];
+#pragma unroll
+  for (int ss = 0; ss < 8; ++ss) k_rd[ss] = r * 256 + (((2 * ss + h) ^ (r & 15)) << 4);
+  // V^T transposed read (ds_read_b64_tr_b16), as in the second generation
   const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
-  int v_rd[2][4];     // [u][d]: byte offset of (key 4 h + 8 u + q, dims 32 d + 16 g1 + 4 p) in the swizzled image
+  int v_rd[2][4];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -266,182 +331,186 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
       v_rd[u][d] = 256 * key + 16 * (ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) + 8 * (tp & 1);
     }
 
-  // q.k of one 32-key block: eight dependent MFMAs
-#define P2_QK(sb, sacc)                                                                                               \
-  do {                                                                                                                \
-    sacc = f32x16{0};                                                                                                 \
-    _Pragma("unroll") for (int ss_ = 0; ss_ < 8; ++ss_) {                                                             \
-      uint4 kv_ = *(const uint4*)(k_lds + (sb) * 8192 + k_rd + (((2 * ss_ + h) ^ (r & 15)) << 4));                    \
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv_), qf[ss_], sacc, 0, 0, 0);        \
-    }                                                                                                                 \
+#define P3_KFRAGS(kf, kb, sb)                                                                                              \
+  do { _Pragma("unroll") for (int ss_ = 0; ss_ < 8; ++ss_) kf[ss_] = *(const uint4*)((kb) + (sb) * 8192 + k_rd[ss_]); } while (0)
+#define P3_QK(kf, sacc)                                                                                                    \
+  do {                                                                                                                     \
+    sacc = f32x16{0};                                                                                                      \
+    _Pragma("unroll") for (int ss_ = 0; ss_ < 8; ++ss_)                                                                    \
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ss_]), qf[ss_], sacc, 0, 0, 0);         \
   } while (0)
-  // the reference's rounding points on the scores, then the causal mask (inside_: wave-uniform, nothing to mask)
-#define P2_ROUND_MASK(kt32, sacc, inside_)                                                                            \
-  do {                                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                  \
-      int key_ = (kt32) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;                                                        \
-      float sv_ = rbf(sacc[i]);                                                                                       \
-      if (post_scale) sv_ = rbf(sv_ * scaling);                                                                       \
-      sacc[i] = ((inside_) || (key_ <= my_q && key_ < T)) ? sv_ : -INFINITY;                                          \
-    }                                                                                                                 \
-  } while (0)
-#define P2_SCORES(kt32, sb, sacc)                                                                                     \
-  do {                                                                                                                \
-    P2_QK(sb, sacc);                                                                                                  \
-    const bool in_ = (kt32) * 32 + 31 <= q_wave && (kt32) * 32 + 31 < T;                                              \
-    P2_ROUND_MASK(kt32, sacc, in_);                                                                                   \
-  } while (0)
-  // running row max / sum of exp with the block's scores (sweep 1)
-#define P2_STATS(s)                                                                                                   \
-  do {                                                                                                                \
-    float tm = s[0];                                                                                                  \
-    _Pragma("unroll") for (int i = 1; i < 16; ++i) tm = fmaxf(tm, s[i]);                                              \
-    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                                                                           \
-    float mn = fmaxf(m, tm);                                                                                          \
-    if (mn > -INFINITY) {                                                                                             \
-      float ts = 0.f;                                                                                                 \
-      _Pragma("unroll") for (int i = 0; i < 16; ++i) ts += __expf(s[i] - mn);                                         \
-      ts += __shfl_xor(ts, 32, 64);                                                                                   \
-      l = l * __expf(m - mn) + ts;                                                                                    \
-      m = mn;                                                                                                         \
-    }                                                                                                                 \
-  } while (0)
-  // A 64-key tile that lies entirely at or below the wave's diagonal (all but the last one or two tiles of a wave) runs both
-  // blocks' q.k chains FIRST and only then the VALU work on block 0, which overlaps the matrix pipe still busy with block 1
-  // (then P.V of block 0 under the VALU work of block 1): same operations, same order within a block and between the
-  // blocks' updates of (m, l) and of the output accumulators -- the bits do not change.  PMC before: matrix pipe 10 % busy,
-  // VALU 30 %, two waves per SIMD (222 of 512 registers each) stalled on one another's latencies; B 128 x T 1024 x 32 heads
-  // 7.25 -> 5.65 ms, OPT-30B's B 64 x T 256 x 56 heads 0.478 -> 0.409 ms.  (The same interleave for the partly masked tiles,
-  // with the mask flags as run-time values, needs 294 registers -- one wave per SIMD, 12.7 ms -- or spills at 256: 7.9 ms.)
-#define P2_TILE_INSIDE(t) ((2 * (t) + 1) * 32 + 31 <= q_wave && (2 * (t) + 1) * 32 + 31 < T)
-  // (A second such path for the diagonal tile -- block 0 visible, block 1 masked, flags still compile-time -- takes the kernel to
-  // 314 registers: one wave per SIMD, 8.6 ms; capped at 256 it spills 20 bytes: 6.2 ms.  The diagonal tiles keep the plain path.)
 
-  // (named registers and unconditional loads: an array filled under `if (t + 1 < n64)` is kept in scratch by hipcc)
-  uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
-#define P2_LD(base, t, rr) (*(const uint4*)((base) + (long)min((t) * 64 + (rr) * 16 + skey, T - 1) * kv_row + 8 * sc))
-#define P2_LOAD_K(t) do { const int t_ = min((t), n64 - 1); kreg0 = P2_LD(kbase, t_, 0); kreg1 = P2_LD(kbase, t_, 1); kreg2 = P2_LD(kbase, t_, 2); kreg3 = P2_LD(kbase, t_, 3); } while (0);
-#define P2_LOAD_V(t) do { const int t_ = min((t), n64 - 1); vreg0 = P2_LD(vbase, t_, 0); vreg1 = P2_LD(vbase, t_, 1); vreg2 = P2_LD(vbase, t_, 2); vreg3 = P2_LD(vbase, t_, 3); } while (0);
-#define P2_STORE_K() do { *(uint4*)(k_lds + k_wr) = kreg0; *(uint4*)(k_lds + 4096 + k_wr) = kreg1; *(uint4*)(k_lds + 8192 + k_wr) = kreg2; *(uint4*)(k_lds + 12288 + k_wr) = kreg3; } while (0);
-#define P2_STORE_V() do { *(uint4*)(v_lds + v_wr) = vreg0; *(uint4*)(v_lds + 4096 + v_wr) = vreg1; *(uint4*)(v_lds + 8192 + v_wr) = vreg2; *(uint4*)(v_lds + 12288 + v_wr) = vreg3; } while (0);
+  // ---- sweep 1: row max and sum of exp over the visible keys ----
+  // statistics of a block held as eight rounded pairs: the first generation's operations in its order (its `if (mn > -inf)` is
+  // always taken: key 0 is visible to every query, so the running maximum is finite from block 0 on)
+#define P3_STATS(rp)                                                                                                       \
+  do {                                                                                                                     \
+    float tm_ = fmaxf(rp[0].x, rp[0].y);                                                                                   \
+    _Pragma("unroll") for (int c_ = 1; c_ < 8; ++c_) tm_ = fmaxf(tm_, fmaxf(rp[c_].x, rp[c_].y));                          \
+    tm_ = fmaxf(tm_, __shfl_xor(tm_, 32, 64));                                                                             \
+    const float mn_ = fmaxf(m, tm_);                                                                                       \
+    float ts_ = 0.f;                                                                                                       \
+    _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) {                                                                     \
+      const f32x2 e_ = p3_exp2(rp[c_], mn_);                                                                               \
+      ts_ += e_.x;                                                                                                         \
+      ts_ += e_.y;                                                                                                         \
+    }                                                                                                                      \
+    ts_ += __shfl_xor(ts_, 32, 64);                                                                                        \
+    l = l * __expf(m - mn_) + ts_;                                                                                         \
+    m = mn_;                                                                                                               \
+  } while (0)
+#define P3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+  // chain 0 of a two-block tile with the K^T fragments of block 1 fetched under it
+#define P3_CHAIN0()                                                                                                        \
+  P3_KFRAGS(kf0, kb, 0);                                                                                                   \
+  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                          \
+    s0 = P3_MFMA(__builtin_bit_cast(bf16x8, kf0[c]), qf[c], s0);                                                           \
+    kf1[c] = *(const uint4*)(kb + 8192 + k_rd[c]);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+  }                                                                                                                        \
+  __builtin_amdgcn_sched_barrier(0)
+  // two visible blocks: chain 1 runs under the statistics of block 0 (never masked here) -- MFMAs 0..3 beside the rounding and the
+  // maximum, 4..7 beside the sum of exp; then block 1, always through the mask (it may hold the diagonal or the end of the sequence)
+#define P3_S1_TILE2()                                                                                                      \
+  do {                                                                                                                     \
+    uint4 kf0[8], kf1[8];                                                                                                  \
+    f32x16 s0 = f32x16{0}, s1 = f32x16{0};                                                                                 \
+    f32x2 rp[8];                                                                                                           \
+    float tm = -INFINITY, mn = 0.f, ts = 0.f;                                                                              \
+    P3_CHAIN0();                                                                                                           \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                        \
+      s1 = P3_MFMA(__builtin_bit_cast(bf16x8, kf1[c]), qf[c], s1);                                                         \
+      if (c < 4) {                                                                                                         \
+        rp[2 * c] = p3_round2<POST_SCALE>(s0[4 * c], s0[4 * c + 1], scaling);                                              \
+        rp[2 * c + 1] = p3_round2<POST_SCALE>(s0[4 * c + 2], s0[4 * c + 3], scaling);                                      \
+        tm = fmaxf(fmaxf(tm, fmaxf(rp[2 * c].x, rp[2 * c].y)), fmaxf(rp[2 * c + 1].x, rp[2 * c + 1].y));                   \
+        if (c == 3) {                                                                                                      \
+          tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                                                                          \
+          mn = fmaxf(m, tm);                                                                                               \
+        }                                                                                                                  \
+      } else {                                                                                                             \
+        const f32x2 e0 = p3_exp2(rp[2 * (c - 4)], mn), e1 = p3_exp2(rp[2 * (c - 4) + 1], mn);                              \
+        ts += e0.x; ts += e0.y; ts += e1.x; ts += e1.y;                                                                    \
+      }                                                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    }                                                                                                                      \
+    ts += __shfl_xor(ts, 32, 64);                                                                                          \
+    l = l * __expf(m - mn) + ts;                                                                                           \
+    m = mn;                                                                                                                \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                        \
+      rp[c] = p3_round2<POST_SCALE>(s1[2 * c], s1[2 * c + 1], scaling);                                                    \
+      rp[c] = p3_mask2(rp[c], lim1, c);                                                                                    \
+    }                                                                                                                      \
+    P3_STATS(rp);                                                                                                          \
+  } while (0)
 
-  // ---- sweep 1: row max and sum of exp over all keys <= query ----
   float m = -INFINITY, l = 0.f;
-  P2_LOAD_K(0)
+  P3_ISSUE(0, 0, false);
   for (int t = 0; t < n64; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    P2_STORE_K()
-    __syncthreads();
-    P2_LOAD_K(t + 1)      // (clamped: the last iteration re-reads its own tile)
-    if (P2_TILE_INSIDE(t)) {
-      f32x16 s0, s1;
-      P2_QK(0, s0);
-      P2_QK(1, s1);
-      P2_ROUND_MASK(2 * t, s0, true);
-      P2_STATS(s0);
-      P2_ROUND_MASK(2 * t + 1, s1, true);
-      P2_STATS(s1);
-      continue;
-    }
+    // (the stage after sweep 1's last tile is sweep 2's first: its K and V ride under this tile's arithmetic)
+    if (t + 1 < n64) P3_ISSUE(t + 1, (t + 1) & 1, false);
+    else P3_ISSUE(0, n64 & 1, true);
+    const char* kb = &lds[t & 1][0][0];
+    const int nb = nblk - 2 * t;
+    const int lim1 = vis - 32 * (2 * t + 1);
+    if (nb >= 2) {
+      P3_S1_TILE2();
+    } else if (nb == 1) {
+      uint4 kf0[8];
+      f32x16 s0;
+      f32x2 rp[8];
+      P3_KFRAGS(kf0, kb, 0);
+      P3_QK(kf0, s0);
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      const int kt = 2 * t + sb;
-      if (kt < n32 && kt * 32 <= q_wave + 31) {  // wave-uniform: block exists and is not entirely above the diagonal
-        f32x16 s;
-        P2_SCORES(kt, sb, s);
-        P2_STATS(s);
-      }
+      for (int c = 0; c < 8; ++c) rp[c] = p3_mask2(p3_round2<POST_SCALE>(s0[2 * c], s0[2 * c + 1], scaling), lim1 + 32, c);
+      P3_STATS(rp);
     }
   }
 
   // ---- sweep 2: P = bf16(exp(s - m) / l), O^T += V^T . P^T ----
-  // e / l for the 16 e of a block share l: the reciprocal and its Newton step are hoisted, the per-element part is
-  // the quotient + two residual corrections of the IEEE sequence hipcc emits for `/` (v_div_scale is the identity here:
-  // 1 <= l <= T, 0 <= e <= 1), i.e. the same correctly rounded quotient in 5 FMAs instead of ~11 instructions.
-  // (lia_attn_prefill_kernel keeps the plain `/`; tools/attn_ab.py compares the two kernels bit for bit.)
   const float rl0 = __builtin_amdgcn_rcpf(l);
   const float rl = __builtin_fmaf(__builtin_fmaf(-l, rl0, 1.0f), rl0, rl0);
-#define P2_DIV(e_, out_)                                                                                              \
-  do {                                                                                                                \
-    const float n_ = (e_);                                                                                            \
-    float q_ = n_ * rl;                                                                                               \
-    q_ = __builtin_fmaf(__builtin_fmaf(-l, q_, n_), rl, q_);                                                          \
-    out_ = __builtin_fmaf(__builtin_fmaf(-l, q_, n_), rl, q_);                                                        \
-  } while (0)
   f32x16 oacc[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) oacc[d] = f32x16{0};
-  P2_LOAD_K(0)
-  P2_LOAD_V(0)
+  // V^T piece c = (ks = c >> 2, d = c & 3) of block sb: keys 32 sb + 16 ks + 4 h + (0..3) -> elements 0..3, the same + 8 -> elements
+  // 4..7 (the k order of an accumulator tile used as an operand); dims 32 d ..
+#define P3_VFRAG(dst, vb, sb, c)                                                                                            \
+  do {                                                                                                                     \
+    const char* vt_ = (vb) + (32 * (sb) + 16 * ((c) >> 2)) * 256;                                                          \
+    lia_v4s lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vt_ + v_rd[0][(c) & 3])); \
+    lia_v4s hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vt_ + v_rd[1][(c) & 3])); \
+    dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));                           \
+  } while (0)
+#define P3_PF(pk, c) __builtin_bit_cast(bf16x8, uint4{pk[4 * ((c) >> 2)], pk[4 * ((c) >> 2) + 1], pk[4 * ((c) >> 2) + 2], pk[4 * ((c) >> 2) + 3]})
+  // two visible blocks: chain 1 under the softmax of block 0, P.V of block 0 under the softmax of block 1, then P.V of block 1; the
+  // V^T pieces are fetched one phase ahead.  Every oacc[d] takes its four products in the order (block 0, ks 0), (0, 1), (1, 0), (1, 1).
+#define P3_S2_TILE2()                                                                                                      \
+  do {                                                                                                                     \
+    uint4 kf0[8], kf1[8];                                                                                                  \
+    f32x16 s0 = f32x16{0}, s1 = f32x16{0};                                                                                 \
+    uint32_t pk0[8], pk1[8];                                                                                               \
+    bf16x8 vfa[8], vfb[8];                                                                                                 \
+    P3_CHAIN0();                                                                                                           \
+    _Pragma("unroll") for (int c2 = 0; c2 < 4; ++c2) {                                                                     \
+      _Pragma("unroll") for (int c = 2 * c2; c < 2 * c2 + 2; ++c) {                                                        \
+        s1 = P3_MFMA(__builtin_bit_cast(bf16x8, kf1[c]), qf[c], s1);                                                       \
+        P3_VFRAG(vfa[c], vb, 0, c);                                                                                        \
+        pk0[c] = p3_prob2(p3_round2<POST_SCALE>(s0[2 * c], s0[2 * c + 1], scaling), m, l, rl);                             \
+      }                                                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int c2 = 0; c2 < 4; ++c2) {                                                                     \
+      _Pragma("unroll") for (int c = 2 * c2; c < 2 * c2 + 2; ++c) {                                                        \
+        oacc[c & 3] = P3_MFMA(vfa[c], P3_PF(pk0, c), oacc[c & 3]);                                                         \
+        P3_VFRAG(vfb[c], vb, 1, c);                                                                                        \
+        f32x2 r_ = p3_round2<POST_SCALE>(s1[2 * c], s1[2 * c + 1], scaling);                                               \
+        r_ = p3_mask2(r_, lim1, c);                                                                                        \
+        pk1[c] = p3_prob2(r_, m, l, rl);                                                                                   \
+      }                                                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) oacc[c & 3] = P3_MFMA(vfb[c], P3_PF(pk1, c), oacc[c & 3]);               \
+  } while (0)
+
   for (int t = 0; t < n64; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    P2_STORE_K()
-    P2_STORE_V()
-    __syncthreads();
-    P2_LOAD_K(t + 1)
-    P2_LOAD_V(t + 1)
-#define P2_PROBS(s, pk)                                                                                               \
-  do {                                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
-      float p0, p1;                                                                                                   \
-      P2_DIV(__expf(s[2 * i] - m), p0);                                                                               \
-      P2_DIV(__expf(s[2 * i + 1] - m), p1);                                                                           \
-      pk[i] = pack_bf16x2(p0, p1);                                                                                    \
-    }                                                                                                                 \
-  } while (0)
-    // keys 32 sb + 16 ks + 4 h + (0..3) -> elements 0..3, the same + 8 -> elements 4..7 (the k order of an
-    // accumulator tile used as an operand)
-#define P2_PV(sb, pk)                                                                                                 \
-  do {                                                                                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
-      bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[4 * ks], pk[4 * ks + 1], pk[4 * ks + 2], pk[4 * ks + 3]});      \
-      _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                                 \
-        const char* vb = v_lds + (32 * (sb) + 16 * ks) * 256;                                                         \
-        lia_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[0][d])); \
-        lia_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lia_v4s*)(vb + v_rd[1][d])); \
-        bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));              \
-        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);                                  \
-      }                                                                                                               \
-    }                                                                                                                 \
-  } while (0)
-    if (P2_TILE_INSIDE(t)) {
-      f32x16 s0, s1;
-      uint32_t pk0[8], pk1[8];
-      P2_QK(0, s0);
-      P2_QK(1, s1);
-      P2_ROUND_MASK(2 * t, s0, true);
-      P2_PROBS(s0, pk0);
-      P2_PV(0, pk0);
-      P2_ROUND_MASK(2 * t + 1, s1, true);
-      P2_PROBS(s1, pk1);
-      P2_PV(1, pk1);
-      continue;
-    }
+    if (t + 1 < n64) P3_ISSUE(t + 1, (n64 + t + 1) & 1, true);
+    const char* kb = &lds[(n64 + t) & 1][0][0];
+    const char* vb = &lds[(n64 + t) & 1][1][0];
+    const int nb = nblk - 2 * t;
+    const int lim1 = vis - 32 * (2 * t + 1);
+    if (nb >= 2) {
+      P3_S2_TILE2();
+    } else if (nb == 1) {
+      uint4 kf0[8];
+      f32x16 s0;
+      uint32_t pk0[8];
+      bf16x8 vfa[8];
+      P3_KFRAGS(kf0, kb, 0);
+      P3_QK(kf0, s0);
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      const int kt = 2 * t + sb;
-      if (kt < n32 && kt * 32 <= q_wave + 31) {
-        f32x16 s;
-        uint32_t pk[8];
-        P2_SCORES(kt, sb, s);
-        P2_PROBS(s, pk);
-        P2_PV(sb, pk);
+      for (int c = 0; c < 8; ++c) {
+        P3_VFRAG(vfa[c], vb, 0, c);
+        pk0[c] = p3_prob2(p3_mask2(p3_round2<POST_SCALE>(s0[2 * c], s0[2 * c + 1], scaling), lim1 + 32, c), m, l, rl);
       }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) oacc[c & 3] = P3_MFMA(vfa[c], P3_PF(pk0, c), oacc[c & 3]);
     }
   }
-#undef P2_PROBS
-#undef P2_PV
-#undef P2_QK
-#undef P2_ROUND_MASK
-#undef P2_STATS
-#undef P2_TILE_INSIDE
-#undef P2_SCORES
-#undef P2_DIV
-#undef P2_LOAD_K
-#undef P2_LOAD_V
-#undef P2_LD
-#undef P2_STORE_K
-#undef P2_STORE_V
+#undef P3_S2_TILE2
+#undef P3_S1_TILE2
+#undef P3_CHAIN0
+#undef P3_STATS
+#undef P3_PF
+#undef P3_MFMA
+#undef P3_VFRAG
+#undef P3_QK
+#undef P3_KFRAGS
+#undef P3_ISSUE
 
   if (my_q < T) {
     bf16_t* op = out + ((long)b * T + my_q) * ldo + (long)hh * D;
@@ -456,6 +525,7 @@ __global__ __launch_bounds__(256) void lia_attn_prefill128_kernel(const bf16_t* 
       }
   }
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // decode (T == 1): one workgroup per (batch row, KV head); KV-bandwidth bound.  The G = heads / kv_heads query
@@ -664,7 +734,8 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
     case 128: {
       const long hd = (long)kv_heads * 128;
       // (a token-major [B][T][h][d] K/V -- strides (hd, T hd) -- was measured: same time, so the cache layout stays)
-      hipLaunchKernelGGL(lia_attn_prefill128_kernel, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, post_scale);
+      if (post_scale) hipLaunchKernelGGL(lia_attn_prefill128_kernel<1>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling);
+      else hipLaunchKernelGGL(lia_attn_prefill128_kernel<0>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling);
       break;
     }
     case 64: hipLaunchKernelGGL(lia_attn_prefill_kernel<64>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;
