@@ -40,19 +40,22 @@ for case in range(n_cases):
     g = torch.Generator(device="cuda").manual_seed(1000 + case)
     q = torch.randn((B, T, heads * d), generator=g, device="cuda").to(bf)
     smax = S + rng.choice([0, 1, 5])
-    k = torch.randn((smax, B, heads, d), generator=g, device="cuda").to(bf)
-    v = torch.randn((smax, B, heads, d), generator=g, device="cuda").to(bf)
+    # the cache may be wider than the batch (a minibatch of a larger cache: rows b0 .. b0 + B - 1 of Bc)
+    b0 = rng.choice([0, 0, 1, 3])
+    Bc = B + b0 + rng.choice([0, 2])
+    k = torch.randn((smax, Bc, heads, d), generator=g, device="cuda").to(bf)
+    v = torch.randn((smax, Bc, heads, d), generator=g, device="cuda").to(bf)
     torch.cuda.synchronize()
-    y = ctx.attention(q, k, v, S, heads)
+    y = ctx.attention(q, k, v, S, heads, b0=b0)
     ctx.synchronize()
-    t = ref(q.view(B, T, heads, d), k[:S], v[:S], prefill).reshape(B, T, heads * d)
+    t = ref(q.view(B, T, heads, d), k[:S, b0:b0 + B], v[:S, b0:b0 + B], prefill).reshape(B, T, heads * d)
     err = (y.float() - t.float()).abs()
     tol = 0.03 + 0.02 * t.float().abs()          # a few bf16 ulps of the output: p carries 8 bits, the sums differ in order
     bad = int((err > tol).sum())
     close = float((err <= 0.008 + 0.008 * t.float().abs()).float().mean())
     flag = "" if (bad == 0 and close > 0.97) else "   <-- FAIL"
     if flag or case % 10 == 0:
-        print(f"case {case}: {'prefill' if prefill else 'decode'} B={B} T={T} S={S} h={heads} d={d}: max err {float(err.max()):.4f}, "
+        print(f"case {case}: {'prefill' if prefill else 'decode'} B={B} (rows {b0}.. of {Bc}) T={T} S={S} h={heads} d={d}: max err {float(err.max()):.4f}, "
               f"within 1 ulp {close:.4f}, outside tol {bad}{flag}", flush=True)
     if flag:
         sys.exit(1)
