@@ -43,8 +43,11 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int hh = blockIdx.y, b = blockIdx.z;
-  const int q_wg = blockIdx.x * 128;
-  const int q_wave = q_wg + wave * 32;
+  // every other (batch row, head) takes its query blocks and its waves' row blocks in reverse order (r05, see the d = 128 kernel:
+  // otherwise XCD gridDim.x - 1 and SIMD 3 collect all the long rows of the causal triangle); the results do not depend on it
+  const int rev = (hh + b) & 1;
+  const int q_wg = (rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
+  const int q_wave = q_wg + (rev ? 3 - wave : wave) * 32;
   // grouped-query attention (Llama family): query head hh reads K/V head hh / (heads / kv_heads); OPT: kv_heads == heads
   const int kh = hh / (heads / kv_heads);
   const long kv_row = (long)Bc * kv_heads * D;  // elements between consecutive sequence positions
