@@ -211,3 +211,40 @@ def test_generate_argument_errors():
     with pytest.raises(ValueError):
         generate(model, t, max_new_tokens=2, prefill_policy=5, decoding_policy=2)
     model.close()
+
+
+@pytest.mark.parametrize("flags", [dict(prefill_policy=3, decoding_policy=3, gpu_percentage=100, pin_weight=True),
+                                   dict(prefill_policy=0, decoding_policy=2, gpu_percentage=50, pin_weight=True, num_minibatch=2)],
+                         ids=["resident", "streamed-0-2-mb2"])
+def test_generate_at_the_position_limit_matches_oracle(oracle, flags):
+    """Maximum size of the domain: a prompt that ends 8 positions before OPT's max_position_embeddings (2048), head_dim 128 -- the
+    prefill attention walks 32 key tiles per query block and both ends of the causal triangle, the decode steps run over a cache
+    of 2040+ positions, the learned positions are read at their last rows.  Logits against the CPU oracle on the same weights."""
+    import torch
+    from lia_amd.generation import generate
+    vocab, max_pos, H, heads, F, L, B, T, new, seed = 256, 2048, 256, 2, 512, 2, 2, 2040, 6, 31
+    m = synth.make_model(seed, vocab, max_pos, H, F, L, 0.05)
+    ids = synth.make_prompt_ids(seed + 1, B, T, vocab)
+    c = dict(vocab=vocab, max_pos=max_pos, H=H, heads=heads, F=F, L=L, B=B, T=T, new=new)
+    model = _model(m, c)
+    out, lat, logits = generate(model, torch.from_numpy(ids), max_new_tokens=new, min_new_tokens=new, return_logits=True, **flags)
+    ref_ids, _, ref_logits = oracle.generate(m, ids, new, heads, flags["prefill_policy"], flags["decoding_policy"],
+                                             flags["gpu_percentage"], return_logits=True)
+    assert out.shape == (B, T + new)
+    for s, (g, r) in enumerate(zip(logits, ref_logits)):
+        gb = g.cpu().view(torch.int16).numpy().view(np.uint16)
+        gf, rf = synth.bf16_bits_to_f32(gb), synth.bf16_bits_to_f32(r)
+        scale = max(float(np.abs(rf).max()), 1.0)
+        err = np.abs(gf - rf)
+        quantum = 2.0 ** (np.floor(np.log2(scale)) - 7)
+        assert np.quantile(err, 0.999) <= 1e-2 * scale and err.max() <= 1e-2 * scale + quantum, (s, float(err.max()), scale)
+        # greedy ids: equal wherever the oracle's own top-2 gap exceeds two quanta (parity_util's rule for random-init logits)
+        top2 = np.sort(rf, axis=-1)[:, -2:]
+        decided = (top2[:, 1] - top2[:, 0]) > 2 * quantum
+        assert (out.numpy()[decided, T + s] == ref_ids[decided, T + s]).all()
+        if not decided.all() or (out.numpy()[:, T + s] != ref_ids[:, T + s]).any():
+            break                                   # rows that parted on a near-tie see different caches from here on
+    with pytest.raises(Exception):                  # one token more than the learned positions hold
+        generate(model, torch.from_numpy(ids), max_new_tokens=new + 4, min_new_tokens=new + 4, **flags)
+    model._lia_scheduler.close()
+    model.close()
