@@ -248,3 +248,37 @@ def test_generate_at_the_position_limit_matches_oracle(oracle, flags):
         generate(model, torch.from_numpy(ids), max_new_tokens=new + 4, min_new_tokens=new + 4, **flags)
     model._lia_scheduler.close()
     model.close()
+
+
+@pytest.mark.parametrize("flags", [dict(prefill_policy=3, decoding_policy=3, gpu_percentage=100, pin_weight=True),
+                                   dict(prefill_policy=0, decoding_policy=2, gpu_percentage=50, pin_weight=True),
+                                   dict(prefill_policy=0, decoding_policy=0, gpu_percentage=0, pin_weight=True),
+                                   dict()],
+                         ids=["resident", "streamed-0-2", "streamed-0-0", "host-1-1"])
+@pytest.mark.parametrize("B,T,new", [(1, 1, 3), (3, 1, 2), (2, 2, 1)])
+def test_generate_smallest_prompts_match_oracle(oracle, flags, B, T, new):
+    """The small end of the domain: a one-token prompt (the prefill IS a decode-shaped step: no causal mask, no last-position
+    tail), three rows of one token, and a single new token (prefill only, no decode step at all)."""
+    import torch
+    from lia_amd.generation import generate
+    z, m, _, c = _load("generate_h256")
+    ids = synth.make_prompt_ids(77 + B + T, B, T, c["vocab"])
+    model = _model(m, c)
+    out, lat, logits = generate(model, torch.from_numpy(ids), max_new_tokens=new, min_new_tokens=new, return_logits=True,
+                                token_latency=True, **flags)
+    ref_ids, _, ref_logits = oracle.generate(m, ids, new, c["heads"], flags.get("prefill_policy", 1), flags.get("decoding_policy", 1),
+                                             flags.get("gpu_percentage", 0), return_logits=True)
+    assert out.shape == (B, T + new) and len(lat) == new and len(logits) == new
+    for s, (g, r) in enumerate(zip(logits, ref_logits)):
+        gb = g.cpu().view(torch.int16).numpy().view(np.uint16)
+        gf, rf = synth.bf16_bits_to_f32(gb), synth.bf16_bits_to_f32(r)
+        scale = max(float(np.abs(rf).max()), 1.0)
+        quantum = 2.0 ** (np.floor(np.log2(scale)) - 7)
+        assert np.abs(gf - rf).max() <= 1e-2 * scale + quantum, (s, float(np.abs(gf - rf).max()), scale)
+        top2 = np.sort(rf, axis=-1)[:, -2:]
+        decided = (top2[:, 1] - top2[:, 0]) > 2 * quantum
+        assert (out.numpy()[decided, T + s] == ref_ids[decided, T + s]).all()
+        if (out.numpy()[:, T + s] != ref_ids[:, T + s]).any():
+            break
+    model._lia_scheduler.close()
+    model.close()
