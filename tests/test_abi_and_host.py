@@ -427,3 +427,49 @@ def test_host_allocation_guard(monkeypatch):
     hostinfo.check_host_allocation(50 << 30, "fits")
     with pytest.raises(MemoryError):
         hostinfo.check_host_allocation(90 << 30, "opt-175b streamed layers")
+
+
+def test_host_linear_restates_the_references_tpp_linear_tests(native):
+    """tests/cpu/test_tpp_linear.py:104-305 on this path's policy-1 linear: x = rand(1, 4, 4096), nn.Linear(4096, 4096) in bf16,
+    with bias (:124-150 `tpp_linear_bias`), without, + ReLU (:229-250 `tpp_linear_relu`, the fc1 form), + the input as residual
+    (:269-290 `tpp_linear_add`, the out_proj / fc2 form); the reference asserts equality with eager bf16 at its TestCase's bf16
+    precision.  Here: against torch's eager bf16 module, at most one bf16 ulp apart (1e-4 absolute around zero, where the fp32
+    summation order shows), >= 99 % bit-identical.  (A child process: torch's
+    OpenMP runtime next to the library's team.)"""
+    import subprocess
+    import sys
+    if not native.lib().lia_host_has_avx512_bf16():
+        pytest.skip("host without AVX-512-BF16")
+    code = f"""
+import sys
+sys.path[:0] = {[os.path.join(ROOT, "isca-2025-lia_amd")]!r}
+import numpy as np, torch
+from lia_amd import _native as N
+L = N.lib()
+torch.manual_seed(128)
+torch.set_num_threads(2)
+bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)
+for name, bias, relu, add in [("linear", True, 0, False), ("linear_nobias", False, 0, False), ("linear_relu", False, 1, False),
+                              ("linear_relu_bias", True, 1, False), ("linear_add", False, 0, True), ("linear_add_bias", True, 0, True)]:
+    x = torch.rand(1, 4, 4096).to(torch.bfloat16)
+    mlp = torch.nn.Linear(4096, 4096, bias=bias).eval().to(torch.bfloat16)
+    with torch.no_grad():
+        ref = mlp(x)
+        if relu: ref = torch.nn.functional.relu(ref)
+        if add: ref = ref + x
+    xb, wb = bits(x[0]), bits(mlp.weight.detach())
+    bb = bits(mlp.bias.detach()) if bias else None
+    y = np.zeros((4, 4096), np.uint16)
+    rc = L.lia_host_linear(xb.ctypes.data, wb.ctypes.data, bb.ctypes.data if bias else None, xb.ctypes.data if add else None, y.ctypes.data, 4, 4096, 4096, relu, 4)
+    assert rc == 0, L.lia_last_error()
+    r = bits(ref[0])
+    rf, yf = ref[0].float().numpy(), torch.from_numpy(y.view(np.int16)).view(torch.bfloat16).float().numpy()
+    quantum = np.exp2(np.floor(np.log2(np.maximum(np.abs(rf), 1e-30))) - 7)       # one bf16 ulp at the reference value
+    err = np.abs(rf - yf)
+    same = float((r == y).mean())
+    assert (err <= np.maximum(quantum, 1e-4)).all() and same >= 0.99, (name, float(err.max()), same)
+    print(name, "identical", same)
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-800:], r.stderr[-2000:])
