@@ -282,3 +282,22 @@ def test_generate_smallest_prompts_match_oracle(oracle, flags, B, T, new):
             break
     model._lia_scheduler.close()
     model.close()
+
+
+def test_batch_that_num_minibatch_does_not_divide_is_refused():
+    """lia/modeling_opt.py:1178-1180 computes mini_bsz = int(bsz / num_minibatch) and loops num_minibatch times: with 3 rows and
+    num_minibatch 2 the reference would silently leave the last row's hidden state unwritten.  This path refuses the combination
+    (documented deviation in error behaviour: a ValueError instead of a wrong row)."""
+    import torch
+    from lia_amd.generation import generate
+    z, m, _, c = _load("generate_h256")
+    model = _model(m, c)
+    ids = torch.from_numpy(synth.make_prompt_ids(5, 3, 6, c["vocab"]))
+    with pytest.raises(ValueError, match="not divisible"):
+        generate(model, ids, max_new_tokens=2, min_new_tokens=2, prefill_policy=0, decoding_policy=2, gpu_percentage=50,
+                 pin_weight=True, num_minibatch=2)
+    out = generate(model, ids, max_new_tokens=2, min_new_tokens=2, prefill_policy=0, decoding_policy=2, gpu_percentage=50,
+                   pin_weight=True, num_minibatch=3)                  # the model object is usable afterwards, with a divisor
+    assert out.shape == (3, 8)
+    model._lia_scheduler.close()
+    model.close()
