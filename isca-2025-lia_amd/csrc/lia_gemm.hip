@@ -169,13 +169,14 @@ __device__ __forceinline__ int tl_swz(int row) { return (row >> 1) & 7; }
 // 16 bytes per lane, whole 128-byte lines per row, the residual read the same way.  Rounding points are
 // unchanged: bf16(acc) -> bf16(+bias) -> relu -> bf16(residual + .).
 // ---------------------------------------------------------------------------------------------
+enum { LIA_EF_BIAS = 1, LIA_EF_RELU = 2, LIA_EF_RESIDUAL = 4, LIA_EF_GLU = 8 };   // compile-time epilogue masks (EF below)
 // (MBT, J0, MB: the m-blocks J0 .. J0+MB-1 of an accumulator array with MBT of them; m_base = first row of block J0)
 // the residual rows of a wave tile of 16 MB rows x 64 columns, all requested at once (clamped addresses, no branch
 // around a load: a load inside a per-row `if` is waited for on the spot -- 16 dependent round trips, ~13 us per tile)
-template <int MB>
+template <int MB, int EF = -1>
 __device__ __forceinline__ void epilogue_load_residual(uint4 (&rres)[2 * MB], int m_base, int n_base, int M, int N, const LiaEpilogue& ep,
                                                        int lane) {
-  if (ep.residual == nullptr) return;
+  if (EF < 0 ? ep.residual == nullptr : !(EF & LIA_EF_RESIDUAL)) return;
   const int c = lane & 7;
 #pragma unroll
   for (int r = 0; r < 2 * MB; ++r) {
@@ -188,20 +189,28 @@ __device__ __forceinline__ void epilogue_load_residual(uint4 (&rres)[2 * MB], in
 // idle -- VALU time, not memory (the second half, whose residual rows had long arrived, alone took 5 us).  So: no integer
 // division per store (the output segment of a lane's 8 columns and the cache row of its first tile row are worked out
 // once, rows then advance by 8), and the two roundings of a pair of values share one v_cvt_pk.
-template <int MBT, int J0, int MB>
+// EF: -1 = the epilogue's switches are read from `ep` at run time; otherwise a compile-time mask (LIA_EF_*) of what this launch's
+// epilogue does -- the phased kernel is instantiated per mask: with run-time switches hipcc computes every variant of a value and
+// selects (14 VALU instructions per output: 8.8 us per 256 x 256 tile without a residual, 12-13 us with one; tools/gemm_tile_stamps)
+template <int MBT, int J0, int MB, int EF = -1>
 __device__ __forceinline__ void epilogue_via_lds_part(const f32x4 (&acc)[4][MBT], const uint4 (&rres)[2 * MB], char* region, int m_base,
                                                       int n_base, int M, int N, const LiaEpilogue& ep, const LiaOutMap& om, int lane) {
   const int l15 = lane & 15, lq = lane >> 4;
-  const bool hb = ep.bias != nullptr, hr = ep.residual != nullptr;
+  const bool hb = EF < 0 ? ep.bias != nullptr : (EF & LIA_EF_BIAS) != 0, hr = EF < 0 ? ep.residual != nullptr : (EF & LIA_EF_RESIDUAL) != 0;
+  const bool relu = EF < 0 ? ep.relu != 0 : (EF & LIA_EF_RELU) != 0, glu = EF < 0 ? ep.glu != 0 : (EF & LIA_EF_GLU) != 0;
   const int c = lane & 7;
+  // the four bias pieces of the lane are requested at once from clamped addresses: a load under `if (n < N)` is waited for on the
+  // spot, and eight such round trips (two parts) were most of the 8-13 us this epilogue took per tile (tools/gemm_tile_stamps)
+  uint2 bq[4] = {};
+  if (hb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = *(const uint2*)(ep.bias + min(n_base + i * 16 + 4 * lq, N - 4));
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     const int n = n_base + i * 16 + 4 * lq;
-    if (hb && n < N) {
-      uint2 bb = *(const uint2*)(ep.bias + n);
-      b[0] = bf2f(bb.x & 0xffff); b[1] = bf2f(bb.x >> 16); b[2] = bf2f(bb.y & 0xffff); b[3] = bf2f(bb.y >> 16);
-    }
+    if (hb && n < N) { b[0] = bf2f(bq[i].x & 0xffff); b[1] = bf2f(bq[i].x >> 16); b[2] = bf2f(bq[i].y & 0xffff); b[3] = bf2f(bq[i].y >> 16); }
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
       const int m = j * 16 + l15;
@@ -212,14 +221,14 @@ __device__ __forceinline__ void epilogue_via_lds_part(const f32x4 (&acc)[4][MBT]
         uint32_t p = pack_bf16x2(acc[i][J0 + j][2 * h], acc[i][J0 + j][2 * h + 1]);
         float t0 = __uint_as_float(p << 16), t1 = __uint_as_float(p & 0xffff0000u);
         if (hb) { t0 += b[2 * h]; t1 += b[2 * h + 1]; }
-        if (ep.relu) { t0 = fmaxf(t0, 0.f); t1 = fmaxf(t1, 0.f); }
-        o2[h] = (hb || ep.relu) ? pack_bf16x2(t0, t1) : p;
+        if (relu) { t0 = fmaxf(t0, 0.f); t1 = fmaxf(t1, 0.f); }
+        o2[h] = (hb || relu) ? pack_bf16x2(t0, t1) : p;
       }
       const int chunk = (2 * i + (lq >> 1)) ^ (m & 7);
       *(uint2*)(region + m * 128 + chunk * 16 + (lq & 1) * 8) = uint2{o2[0], o2[1]};
     }
   }
-  if (ep.glu) {
+  if (glu) {
     // gated-linear-unit output: the wave's 64 columns are 32 gate | 32 up columns of the same 32 outputs (the weight rows are
     // interleaved in blocks of LIA_GU_BLOCK).  Lanes c < 4 read their gate chunk c and the up chunk c + 4 of a row and store
     // silu(gate) * up -- the arithmetic of lia_silu_mul_kernel on the same bf16-rounded values -- as 8 of the N / 2 outputs.
@@ -238,34 +247,59 @@ __device__ __forceinline__ void epilogue_via_lds_part(const f32x4 (&acc)[4][MBT]
     }
     return;
   }
-  // where my 8 columns go: segment and column inside it (constant over the rows), cache row of my first tile row
+  // where my 8 columns go: segment and column inside it (constant over the rows); the rows' offsets are worked out first (in cache
+  // mode a division per part, then additions), then every LDS read is issued, then every store: interleaved per row the scalar
+  // loads of the map's fields and the LDS round trip sat in front of each store
   const int gn = n_base + c * 8;
   const int seg = gn / om.seg_n;
   bf16_t* const obase = om.base[seg] + (gn - seg * om.seg_n);
   const long old = om.ld[seg];
   const bool cmode = om.cache_mode[seg] != 0;
-  int gm = m_base + (lane >> 3);
-  int cb = 0, ct = 0;
-  if (cmode) { cb = gm / om.T; ct = gm - cb * om.T; }
+  const int gm0 = m_base + (lane >> 3);
+  long roff[2 * MB];
+  if (cmode) {
+    const int T_ = om.T, Bc_ = om.Bc;
+    int cb = gm0 / T_, ct = gm0 - cb * T_;
+    const long base_ = (long)om.pos0 * Bc_ + om.b0;
+#pragma unroll
+    for (int r = 0; r < 2 * MB; ++r) {
+      roff[r] = (base_ + (long)ct * Bc_ + cb) * old;
+      ct += 8;
+      while (ct >= T_) { ct -= T_; ++cb; }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 2 * MB; ++r) roff[r] = (long)(gm0 + 8 * r) * old;
+  }
   // same-wave LDS write -> read: program order + the compiler's lgkmcnt wait suffice (the region is private)
+  uint4 v[2 * MB];
 #pragma unroll
   for (int r = 0; r < 2 * MB; ++r) {
     const int m = r * 8 + (lane >> 3);
-    uint4 v = *(const uint4*)(region + m * 128 + ((c ^ (m & 7)) << 4));
-    if (hr) {
+    v[r] = *(const uint4*)(region + m * 128 + ((c ^ (m & 7)) << 4));
+  }
+  if (hr) {
+#pragma unroll
+    for (int r = 0; r < 2 * MB; ++r) {
       const uint4 rr = rres[r];
-      const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+      const uint32_t vw[4] = {v[r].x, v[r].y, v[r].z, v[r].w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
       uint32_t ow[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         ow[e] = pack_bf16x2(__uint_as_float(rw[e] << 16) + __uint_as_float(vw[e] << 16),
                             __uint_as_float(rw[e] & 0xffff0000u) + __uint_as_float(vw[e] & 0xffff0000u));
-      v = uint4{ow[0], ow[1], ow[2], ow[3]};
+      v[r] = uint4{ow[0], ow[1], ow[2], ow[3]};
     }
-    const long row = cmode ? (long)(om.pos0 + ct) * om.Bc + om.b0 + cb : (long)gm;
-    if (gm < M && gn < N) *(uint4*)(obase + row * old) = v;
-    gm += 8;
-    if (cmode) { ct += 8; while (ct >= om.T) { ct -= om.T; ++cb; } }
+  }
+  if (m_base + 16 * MB <= M) {               // (wave-uniform) every row of the part exists: no per-row test
+    if (gn < N) {
+#pragma unroll
+      for (int r = 0; r < 2 * MB; ++r) *(uint4*)(obase + roff[r]) = v[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 2 * MB; ++r)
+      if (gm0 + 8 * r < M && gn < N) *(uint4*)(obase + roff[r]) = v[r];
   }
 }
 
@@ -697,7 +731,14 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256_kernel(const bf16_t* __
 // lgkmcnt(0) BEFORE its first barrier (group 1 lags half a phase).
 // ---------------------------------------------------------------------------------------------
 constexpr int T4_BUF_BYTES = 65536;   // one K-tile: W rows 0-255 at row * 128, x rows at 32768 + row * 128
+#ifdef LIA_GEMM_STAMPS
+__device__ unsigned long long g_t4_stamps[65536 * 8];   // per workgroup: start, first K-tile landed, after the K loop, epilogue issued, drained, hw id
+#define T4_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_t4_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define T4_STAMP(i) do { } while (0)
+#endif
 
+template <int EF>
 __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
@@ -706,6 +747,7 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
   const int l15 = lane & 15, lq = lane >> 4;
   const int wn = wave & 3, wm = wave >> 2;   // wave tile: W rows [64 wn, +64) x (x rows [64 wm, +64) and [128 + 64 wm, +64))
 
+  T4_STAMP(0);
   int tm, tn;
   t2_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * T2_BM, n0 = tn * T2_BN;
@@ -785,6 +827,7 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
   T4_STAGE_X0(1, 1); T4_STAGE_W0(1, 1); T4_STAGE_W1(1, 1);
   wait_vmcnt<8>();             // X0, W0, W1 of tile 0 have landed (X1(0) is waited for in PA)
   T4_BARRIER();
+  T4_STAMP(1);
   if (wm == 1) T4_BARRIER();     // the stagger
   int t = 0;
   for (; t + 2 < nk; t += 2) {
@@ -810,11 +853,19 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
   // is its own.  The residual rows of BOTH halves of the wave tile are requested before the first store: vmcnt retires in
   // order, so a residual load issued behind the first half's stores would wait for them as well (the fragment registers are
   // free now)
+  T4_STAMP(2);
   uint4 rres0[8], rres1[8];
-  epilogue_load_residual<4>(rres0, m0 + wm * 64, n0 + wn * 64, M, N, ep, lane);
-  epilogue_load_residual<4>(rres1, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, lane);
-  epilogue_via_lds_part<4, 0, 4>(acc0, rres0, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
-  epilogue_via_lds_part<4, 0, 4>(acc1, rres1, smem + wave * 16384 + 8192, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
+  epilogue_load_residual<4, EF>(rres0, m0 + wm * 64, n0 + wn * 64, M, N, ep, lane);
+  epilogue_load_residual<4, EF>(rres1, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, lane);
+  epilogue_via_lds_part<4, 0, 4, EF>(acc0, rres0, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
+  epilogue_via_lds_part<4, 0, 4, EF>(acc1, rres1, smem + wave * 16384 + 8192, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, om, lane);
+#ifdef LIA_GEMM_STAMPS
+  T4_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  T4_STAMP(4);
+  if (threadIdx.x == 0 && blockIdx.x < 65536)
+    g_t4_stamps[blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // XCC_ID, HW_ID
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1008,14 +1059,28 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
     const bool phased = (K / T2_BK) >= 4 && ((K / T2_BK) & 1) == 0;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF_BYTES);
+#define LIA_T4_EACH(X) X(0) X(LIA_EF_BIAS) X(LIA_EF_BIAS | LIA_EF_RELU) X(LIA_EF_BIAS | LIA_EF_RESIDUAL) X(LIA_EF_RESIDUAL) X(LIA_EF_GLU) X(-1)
+#define LIA_T4_ATTR(EF) (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256p_kernel<EF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF_BYTES);
+      LIA_T4_EACH(LIA_T4_ATTR)
+#undef LIA_T4_ATTR
       (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_TILE_BYTES);
       attr_set = true;
     }
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (phased)
-      hipLaunchKernelGGL(lia_gemm_tiled256p_kernel, dim3(tiles_m * tiles_n), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om);
-    else
+    if (phased) {
+      // the epilogue's switches as a compile-time mask: the layers' own combinations have an instantiation each, anything else runs
+      // the run-time form (same arithmetic)
+      const int mask = (ep->bias ? LIA_EF_BIAS : 0) | (ep->relu ? LIA_EF_RELU : 0) | (ep->residual ? LIA_EF_RESIDUAL : 0) | (ep->glu ? LIA_EF_GLU : 0);
+      bool done = false;
+#define LIA_T4_LAUNCH(EF)                                                                                                             \
+      if (!done && ((EF) == -1 || mask == (EF))) {                                                                                        \
+        hipLaunchKernelGGL(lia_gemm_tiled256p_kernel<EF>, dim3(tiles_m * tiles_n), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); \
+        done = true;                                                                                                                    \
+      }
+      LIA_T4_EACH(LIA_T4_LAUNCH)
+#undef LIA_T4_LAUNCH
+#undef LIA_T4_EACH
+    } else
       hipLaunchKernelGGL(lia_gemm_tiled256_kernel, dim3(tiles_m * tiles_n), dim3(512), 4 * T2_TILE_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om);
     if (ev1) (void)hipEventRecord(ev1, st);
     return 0;
