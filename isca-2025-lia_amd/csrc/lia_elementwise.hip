@@ -92,12 +92,19 @@ __global__ __launch_bounds__(256) void lia_layernorm_reg_kernel(const bf16_t* __
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
   bf16_t* yr = y + row * ldy;
+  // gain and bias of piece k + 1 are requested (clamped index, no branch around the loads) before piece k is computed and stored:
+  // loaded under `if (i < nv)` each pair was waited for on the spot -- NV dependent round trips per wave
+  uint4 gv = *(const uint4*)(g + 8 * min(lane, nv - 1)), bv = *(const uint4*)(b + 8 * min(lane, nv - 1));
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int i = lane + 64 * k;
+    const uint4 gc = gv, bc = bv;
+    if (k + 1 < NV) {
+      gv = *(const uint4*)(g + 8 * min(i + 64, nv - 1));
+      bv = *(const uint4*)(b + 8 * min(i + 64, nv - 1));
+    }
     if (i < nv) {
-      const uint4 gv = *(const uint4*)(g + 8 * i), bv = *(const uint4*)(b + 8 * i);
-      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gv.x, gv.y, gv.z, gv.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {gc.x, gc.y, gc.z, gc.w}, bw[4] = {bc.x, bc.y, bc.z, bc.w};
       uint32_t o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
