@@ -58,11 +58,14 @@ __global__ __launch_bounds__(256) void lia_rmsnorm_reg_kernel(const bf16_t* __re
   }
   const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)H + eps);
   bf16_t* yr = y + row * ldy;
+  // the gain of piece k + 1 is requested (clamped index) before piece k is computed: see lia_layernorm_reg_kernel
+  uint4 gn = *(const uint4*)(w + 8 * min(lane, nv - 1));
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int i = lane + 64 * k;
+    const uint4 g = gn;
+    if (k + 1 < NV) gn = *(const uint4*)(w + 8 * min(i + 64, nv - 1));
     if (i < nv) {
-      const uint4 g = *(const uint4*)(w + 8 * i);
       const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, gw[4] = {g.x, g.y, g.z, g.w};
       uint32_t o[4];
 #pragma unroll
