@@ -69,6 +69,10 @@ def build_parser():
     ap.add_argument("--no-cooperative-kv-leg", action="store_true", help="skip the cooperative split's KV-in-HBM variant (value_cooperative_kv_in_hbm)")
     ap.add_argument("--coop-steps", type=int, default=28, help="decode steps of the cooperative leg (the controller's search takes 12-20; value_cooperative = the last 8)")
     ap.add_argument("--no-dp-extra-legs", action="store_true", help="N > 1: skip the KV-in-HBM and all-gather legs")
+    ap.add_argument("--dp-allgather-legs", action="store_true",
+                    help="N > 1: also run the all-gather legs (every rank re-draws the model and pins 1/N of each streamed layer; value_allgather*). "
+                         "Off by default: this streaming mode has run over gloo and over RCCL at world size 1 only, and an optional leg must "
+                         "not be able to take the measured headline line down with it on first contact with an 8-GPU node")
     ap.add_argument("--dp-extra-steps", type=int, default=6)
     ap.add_argument("--dp-backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL; gloo for dry runs with --dp-same-gpu)")
     ap.add_argument("--dp-same-gpu", action="store_true", help="dry run: the ranks share GPU 0 (one-GPU box, --dp-backend gloo)")
@@ -443,7 +447,7 @@ def dp_extra_legs(a, dist, backend, group, model, sched, shape, ids, gen_kwargs,
     headline_kv_in_hbm = (gen_kwargs.get("prefill_policy"), gen_kwargs.get("decoding_policy")) == (3, 3)
     alt_name, alt = ("policy_0_2", dict(prefill_policy=0, decoding_policy=2)) if headline_kv_in_hbm else ("kv_in_hbm", dict(prefill_policy=3, decoding_policy=3))
     leg(alt_name, model, dict(gen_kwargs, **alt))
-    if group.mode != "allgather" and world > 1:
+    if group.mode != "allgather" and world > 1 and a.dp_allgather_legs:
         # every rank needs its own slice of every streamed layer: the root gives its copies up, all ranks draw the (seeded) layers
         # again and pin slice r of G.  The resident layers and the head stay as they are.
         sched.close()
@@ -967,7 +971,7 @@ def main(argv=None):
         # the name of the leg that hung, so the measured headline is still the last JSON line of the output.
         import threading
         if rank == 0:
-            out["dp_extra_legs"] = "pending (this line is re-printed with value_policy_0_2 (or value_kv_in_hbm) / value_allgather when they finish)"
+            out["dp_extra_legs"] = "pending (this line is re-printed with value_policy_0_2 (or value_kv_in_hbm) -- and value_allgather* under --dp-allgather-legs -- when they finish)"
             print(json.dumps(promote_scalars(out)), flush=True)
         progress = {}
         timer = threading.Timer(a.dp_extra_timeout, watchdog_fire, args=(out, progress, rank, a.dp_extra_timeout))

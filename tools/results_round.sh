@@ -24,7 +24,7 @@ for c in 21 23 25; do run opt30b_gpu10_p3p3_pack10_cpu$c --prefill-policy 3 --de
 run llama3_8b_gpu100_b128_t1024_n128 --model llama-3-8b --gpu-percentage 100 --batch 128 --prompt 1024 --steps 127
 run opt66b_gpu5_cxl_pack10 --model opt-66b --gpu-percentage 5 --enable-cxl --cxl-nodes 0,1 --batch 32 --no-raw-leg --no-cpu-baseline
 # data-parallel dry runs on the one GPU of the box: the line's schema for N > 1 (two ranks share the GPU over gloo), and real RCCL at world size 1
-[ -n "${SKIP_DP2:-}" ] || run dp2_same_gpu_gloo_opt30b_gb64 --dp-same-gpu --dp-backend gloo --gpus 2 --global-batch 64 --steps 8 --warmup 1
+[ -n "${SKIP_DP2:-}" ] || run dp2_same_gpu_gloo_opt30b_gb64 --dp-same-gpu --dp-backend gloo --gpus 2 --global-batch 64 --steps 8 --warmup 1 --dp-allgather-legs --dp-extra-timeout 900
 # four ranks on the one GPU, a global batch that the ranks do not divide (17 + 17 + 16 + 16 rows), 4 host threads each
 run dp4_same_gpu_gloo_opt30b_gb66 --dp-same-gpu --dp-backend gloo --gpus 4 --global-batch 66 --steps 4 --warmup 1 --no-dp-extra-legs
 [ -n "${SKIP_DP2:-}" ] || run dp1_rccl_world1_opt30b --force-dp --steps 8 --warmup 1 --no-raw-leg --no-cpu-baseline --no-cooperative-leg
