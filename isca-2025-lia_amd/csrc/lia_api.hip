@@ -14,6 +14,7 @@
 #include "lia_common.h"
 
 // kernels' host launchers
+extern "C" size_t lia_gemm_workspace_bytes(int M, int N);
 extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int M, int N, int K,
                                const LiaEpilogue* ep, const LiaOutMap* om, float* workspace, size_t workspace_bytes,
                                LiaGemmOpts* opts, int force_split, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, int* regime,
@@ -468,7 +469,7 @@ extern "C" int lia_linear(lia_ctx* ctx, const lia_bf16* x, long ldx, const lia_b
   if (M < 0 || N <= 0 || K <= 0) { lia_set_error("lia_linear: M=%d N=%d K=%d", M, N, K); return LIA_ERR_INVALID; }
   LiaEpilogue ep{bias, residual, ldr, relu};
   LiaOutMap om = plain_out(y, ldy, N);
-  size_t need = M <= 256 ? (size_t)8 * M * N * 4 : 0;
+  size_t need = lia_gemm_workspace_bytes(M, N);          // split-K slabs: 8 for M <= 256, up to 4 for the tiled kernel below M = 2048
   size_t have = std::min(need, ctx->ws_bytes);
   ctx->normed_src = nullptr; ctx->chain_armed = false;   // the workspace is about to be reused
   return gemm_checked(ctx, x, ldx, w, M, N, K, ep, om, (float*)ctx->ws, have, split_k, (hipStream_t)stream);

@@ -738,10 +738,15 @@ __device__ unsigned long long g_t4_stamps[65536 * 8];   // per workgroup: start,
 #define T4_STAMP(i) do { } while (0)
 #endif
 
-template <int EF>
+// SK (r06): the launch is split over K -- grid.y slices of `cps` K-tiles each (even, >= 4; the last slice takes what is left), every
+// workgroup writes its fp32 accumulators to slab blockIdx.y of `partial` ([slices][M][N], the skinny regime's layout) and the
+// epilogue runs in the combine kernel.  For 256 < M < ~2000 with N / 256 column tiles too few to fill 256 CUs (OPT-30B out-proj /
+// fc2 at the reference's batch 900: 4 x 28 = 112 tiles).
+template <int EF, bool SK = false>
 __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                   const bf16_t* __restrict__ W, long ldw, int M, int N, int K,
-                                                                  int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om) {
+                                                                  int tiles_m, int tiles_n, LiaEpilogue ep, LiaOutMap om,
+                                                                  float* __restrict__ partial, int cps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -765,8 +770,9 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
   const int srow = tid >> 3;
   const int sck = ((tid & 7) ^ tl_swz(srow)) << 3;
   char* const sdst = smem + wave * 1024;
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * ldw), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)m0 * ldx), 0, 0x7fffffff, 0x00020000);
+  const int kt0 = SK ? (int)blockIdx.y * cps : 0;           // first K-tile of this slice
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * ldw + (long)kt0 * T2_BK), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)m0 * ldx + (long)kt0 * T2_BK), 0, 0x7fffffff, 0x00020000);
   const int wv0 = (int)((min(n0 + srow, N - 1) - n0) * ldw + sck) * 2, wv1 = (int)((min(n0 + 64 + srow, N - 1) - n0) * ldw + sck) * 2;
   const int wv2 = (int)((min(n0 + 128 + srow, N - 1) - n0) * ldw + sck) * 2, wv3 = (int)((min(n0 + 192 + srow, N - 1) - n0) * ldw + sck) * 2;
   const int xv0 = (int)((min(m0 + srow, M - 1) - m0) * ldx + sck) * 2, xv1 = (int)((min(m0 + 64 + srow, M - 1) - m0) * ldx + sck) * 2;
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
     if (!(LAST) || wm == 0) T4_BARRIER();                                                                                 \
   } while (0)
 
-  const int nk = K / T2_BK;      // even and >= 4 (the launcher falls back to the one-barrier kernel otherwise)
+  const int nk = SK ? min(cps, K / T2_BK - kt0) : K / T2_BK;      // even and >= 4 (the launcher falls back to the one-barrier kernel otherwise)
   T4_STAGE_X0(0, 0); T4_STAGE_W0(0, 0); T4_STAGE_W1(0, 0); T4_STAGE_X1(0, 0);
   T4_STAGE_X0(1, 1); T4_STAGE_W0(1, 1); T4_STAGE_W1(1, 1);
   wait_vmcnt<8>();             // X0, W0, W1 of tile 0 have landed (X1(0) is waited for in PA)
@@ -854,6 +860,21 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
   // order, so a residual load issued behind the first half's stores would wait for them as well (the fragment registers are
   // free now)
   T4_STAMP(2);
+  if constexpr (SK) {
+    // the slice's partial sums, fp32, as they stand in the accumulators: lane (l15, lq) holds 4 consecutive n of row l15 of each block
+    float* const ps = partial + (long)blockIdx.y * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + 4 * lq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + l15;
+        if (n < N && m < M) *(f32x4*)(ps + (long)m * N + n) = acc0[i][j];
+        if (n < N && m + 128 < M) *(f32x4*)(ps + (long)(m + 128) * N + n) = acc1[i][j];
+      }
+    }
+    return;
+  }
   uint4 rres0[8], rres1[8];
   epilogue_load_residual<4, EF>(rres0, m0 + wm * 64, n0 + wn * 64, M, N, ep, lane);
   epilogue_load_residual<4, EF>(rres1, m0 + 128 + wm * 64, n0 + wn * 64, M, N, ep, lane);
@@ -872,8 +893,8 @@ __global__ __launch_bounds__(512) void lia_gemm_tiled256p_kernel(const bf16_t* _
 // host launcher
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t lia_gemm_workspace_bytes(int M, int N) {
-  // worst case split-K = 8 fp32 slabs of a skinny problem
-  if (M > 256) return 0;
+  // worst case split-K = 8 fp32 slabs of a skinny problem; 256 < M < 2048 may split the phased tiled kernel up to 4 ways
+  if (M > 256) return M < 2048 ? (size_t)4 * M * N * sizeof(float) : 0;
   return (size_t)8 * M * N * sizeof(float);
 }
 
@@ -1053,20 +1074,65 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
   }
   ep = &ep_t;
   om = &om_t;
-  if (M >= 1024 && N >= 512) {
-    // 256 x 256 tiles: the phased kernel, or -- K / 64 odd or < 4 -- the one-barrier-per-K-tile kernel (same bits)
+#ifdef LIA_MIDM_OLD
+  if (M >= 1024 && N >= 512) {          // (tools/gemm_bench -DLIA_MIDM_OLD: r05's dispatch, the 128 x 128 kernel below M = 1024)
+#else
+  if (M > 256 && N >= 512) {
+#endif
+    // 256 x 256 tiles: the phased kernel, or -- K / 64 odd or < 4 -- the one-barrier-per-K-tile kernel (same bits).  r06: also for
+    // 256 < M < 1024 (r01's 128 x 128 kernel served that range until now: the reference's batch-900 lines put every decode GEMM there)
     const int tiles_m = (M + T2_BM - 1) / T2_BM, tiles_n = (N + T2_BN - 1) / T2_BN;
-    const bool phased = (K / T2_BK) >= 4 && ((K / T2_BK) & 1) == 0;
+    const int nkt = K / T2_BK;
+    const bool phased = nkt >= 4 && (nkt & 1) == 0;
+    // split over K where the tiles alone leave CUs idle: a cost model in microseconds -- rounds of 256 workgroups x (K-tiles of a
+    // slice x 1.5 us + 12 us of prologue / epilogue) + the slabs written and read back at ~4 TB/s (tools/gemm_bench, M = 900)
+    int split = 1, cps = nkt;
+    if (phased && tiles_m * tiles_n < 256 && M < 2048 && !ep->glu && force_split >= 0) {
+      double best = 1e30;
+      for (int sp = (force_split > 0 ? force_split : 1); sp <= (force_split > 0 ? force_split : 4); ++sp) {
+        int c = (nkt + sp - 1) / sp;
+        c += c & 1;                                               // even slices
+        const int ns = (nkt + c - 1) / c;                         // slices that really exist
+        if (c < 4 || nkt - (ns - 1) * c < 4) continue;            // (the last one keeps >= 4 K-tiles; nkt and c even -> it is even)
+        if (ns > 1 && (size_t)ns * M * N * sizeof(float) > workspace_bytes) continue;
+        const int rounds = (tiles_m * tiles_n * ns + 255) / 256;
+        const double t = rounds * (c * 1.5 + 12.0) + (ns > 1 ? (double)ns * M * N * 8.0 / 4e6 : 0.0);
+        if (t < best) { best = t; split = ns; cps = c; }
+      }
+    }
     static bool attr_set = false;
     if (!attr_set) {
 #define LIA_T4_EACH(X) X(0) X(LIA_EF_BIAS) X(LIA_EF_BIAS | LIA_EF_RELU) X(LIA_EF_BIAS | LIA_EF_RESIDUAL) X(LIA_EF_RESIDUAL) X(LIA_EF_GLU) X(-1)
 #define LIA_T4_ATTR(EF) (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256p_kernel<EF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF_BYTES);
       LIA_T4_EACH(LIA_T4_ATTR)
 #undef LIA_T4_ATTR
+      (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256p_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T4_BUF_BYTES);
       (void)hipFuncSetAttribute((const void*)lia_gemm_tiled256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T2_TILE_BYTES);
       attr_set = true;
     }
+    // M <= 384: three 128-row tiles waste fewer rows than two 256-row ones, and the 128 x 128 kernel (two workgroups per CU: 512
+    // slots, ~1.12 us per K-tile + 8) wins where its grid fills them -- OPT-30B q|k|v at M = 300: 133 against 147 us; it loses
+    // everywhere else (out-proj 115 against 64 us, fc1 247 / 188, fc2 415 / 228: tools/gemm_bench, r06)
+    bool small_tiles = false;
+    if (phased && M <= 384 && force_split <= 0) {
+      const int t128 = ((M + TL_BM - 1) / TL_BM) * ((N + TL_BN - 1) / TL_BN);
+      const double fill256 = (double)(tiles_m * tiles_n * split) / (256.0 * ((tiles_m * tiles_n * split + 255) / 256));
+      const double est256 = ((tiles_m * tiles_n * split + 255) / 256) * (cps * (fill256 < 0.7 ? 1.25 : 1.5) + 12.0) +
+                            (split > 1 ? (double)split * M * N * 8.0 / 4e6 : 0.0);
+      const double est128 = ((t128 + 511) / 512) * (nkt * 1.12 + 8.0);
+      small_tiles = est128 < est256;
+    }
+    if (!small_tiles) {
     if (ev0) (void)hipEventRecord(ev0, st);
+    if (phased && split > 1) {
+      hipLaunchKernelGGL((lia_gemm_tiled256p_kernel<0, true>), dim3(tiles_m * tiles_n, split), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K,
+                         tiles_m, tiles_n, *ep, *om, workspace, cps);
+      if (ev1) (void)hipEventRecord(ev1, st);
+      if (post && post_done && !*post_done && launch_fused_combine(workspace, split, M, N, *ep, *om, *post, opts, st)) { *post_done = 1; return 0; }
+      const long nq = (long)M * (N / 4);
+      hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace, split, M, N, *ep, *om);
+      return 0;
+    }
     if (phased) {
       // the epilogue's switches as a compile-time mask: the layers' own combinations have an instantiation each, anything else runs
       // the run-time form (same arithmetic)
@@ -1074,7 +1140,8 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
       bool done = false;
 #define LIA_T4_LAUNCH(EF)                                                                                                             \
       if (!done && ((EF) == -1 || mask == (EF))) {                                                                                        \
-        hipLaunchKernelGGL(lia_gemm_tiled256p_kernel<EF>, dim3(tiles_m * tiles_n), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om); \
+        hipLaunchKernelGGL(lia_gemm_tiled256p_kernel<EF>, dim3(tiles_m * tiles_n), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om, \
+                           (float*)nullptr, 0);                                                                                          \
         done = true;                                                                                                                    \
       }
       LIA_T4_EACH(LIA_T4_LAUNCH)
@@ -1084,6 +1151,7 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
       hipLaunchKernelGGL(lia_gemm_tiled256_kernel, dim3(tiles_m * tiles_n), dim3(512), 4 * T2_TILE_BYTES, st, x, ldx, W, ldw, M, N, K, tiles_m, tiles_n, *ep, *om);
     if (ev1) (void)hipEventRecord(ev1, st);
     return 0;
+    }
   }
   int tiles_m = (M + TL_BM - 1) / TL_BM, tiles_n = (N + TL_BN - 1) / TL_BN;
   if (ev0) (void)hipEventRecord(ev0, st);

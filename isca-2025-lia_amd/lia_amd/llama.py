@@ -226,9 +226,9 @@ class LlamaScheduler:
         B, T = input_ids.shape
         L = sh.layers
         n_gpu = L if gpu_percentage >= 100 else int(L * gpu_percentage / 100)
-        if B % num_minibatch:
-            raise ValueError(f"batch {B} not divisible by num_minibatch {num_minibatch}")
-        mini = B // num_minibatch if T > 1 else B
+        from .scheduler import minibatch_bounds
+        minis = minibatch_bounds(B, num_minibatch) if T > 1 else [(0, B)]      # ragged last minibatch, num_minibatch clamped to B
+        mini = max(n for _, n in minis)
         if m.placed_for != (n_gpu, bool(pin_weight), bool(enable_cxl), LayerStore._fmt_of(self.pack)):
             if self.pipe is not None:
                 self.pipe.drain()          # copies in flight read the host buffers a re-placement frees
@@ -280,16 +280,15 @@ class LlamaScheduler:
                     if nxt == idx or not pipe.can_prefetch():
                         break
                     pipe.prefetch(nxt)
-            nmb = B // mini
             tail = self.prefill_tail and T > 1 and pos0 == 0 and idx == L - 1
             if tail:
                 xlast = torch.empty((B, 1, sh.hidden), dtype=torch.bfloat16, device="cuda")
             fn = lib.lia_llama_layer_forward_last if tail else lib.lia_llama_layer_forward
-            for i in range(nmb):
-                sl = slice(i * mini, (i + 1) * mini)
+            for b0, nb in minis:
+                sl = slice(b0, b0 + nb)
                 N.check(fn(ctx.handle, ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(x[sl].data_ptr()),
                            ctypes.c_void_p((xlast if tail else y)[sl].data_ptr()), ctypes.byref(kv_state.kv[idx]),
-                           ctypes.c_void_p(cos.data_ptr()), ctypes.c_void_p(sin.data_ptr()), mini, T, pos0, i * mini, st),
+                           ctypes.c_void_p(cos.data_ptr()), ctypes.c_void_p(sin.data_ptr()), nb, T, pos0, b0, st),
                         "lia_llama_layer_forward")
             if idx >= n_gpu:
                 pipe.release(idx)

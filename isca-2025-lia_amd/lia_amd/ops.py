@@ -133,15 +133,22 @@ class Context:
         N.check(self.lib.lia_embed(_ptr(ids), _ptr(tok), _ptr(pos), _ptr(y), B, T, past_len, H, self._st(stream)), "lia_embed")
         return y
 
+    LM_HEAD_ROWS = 256       # rows per lia_lm_head call (its argmax scratch is sized for that many)
+
     def lm_head(self, hidden, lnw, lnb, emb, eps=1e-5, suppress_token=-1, stream=None):
+        """final LN + tied lm_head on the LAST position + argmax (models.py:424-431, greedy_search.py:367).  A batch beyond 256 rows
+        (the reference's --batch-size 900 ... 1580 lines, llm/scripts/cxl_offloading.sh:13-39) goes through in chunks of 256 rows:
+        rows are independent, the results are those of one call."""
         for t in (hidden, lnw, lnb, emb):
             _chk(t)
         B, T, H = hidden.shape
         vocab = emb.shape[0]
         logits = torch.empty((B, vocab), dtype=torch.bfloat16, device=hidden.device)
         nxt = torch.empty((B,), dtype=torch.int64, device=hidden.device)
-        N.check(self.lib.lia_lm_head(self.handle, _ptr(hidden), B, T, H, _ptr(lnw), _ptr(lnb), _ptr(emb), vocab, eps, suppress_token, _ptr(logits),
-                                     _ptr(nxt), self._st(stream)), "lia_lm_head")
+        for b0 in range(0, B, self.LM_HEAD_ROWS):
+            nb = min(self.LM_HEAD_ROWS, B - b0)
+            N.check(self.lib.lia_lm_head(self.handle, _ptr(hidden[b0:b0 + nb]), nb, T, H, _ptr(lnw), _ptr(lnb), _ptr(emb), vocab, eps, suppress_token,
+                                         _ptr(logits[b0:b0 + nb]), _ptr(nxt[b0:b0 + nb]), self._st(stream)), "lia_lm_head")
         return logits, nxt
 
     # ---- the operator boundary ------------------------------------------------------------------

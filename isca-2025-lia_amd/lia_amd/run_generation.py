@@ -60,6 +60,11 @@ def build_parser():
                    help="with --decoding-policy 2: this many streamed layers take their decode step on the host cores (policy 1 per layer); "
                         "-1 = chosen online from the measured decode steps (scheduler.CoopController), seeded by the planner")
     p.add_argument("--cpu-layers-start", default=None, type=int, help=argparse.SUPPRESS)
+    p.add_argument("--result-json", default=None, type=str,
+                   help="write one JSON record of the run to this path (tools/run_matrix.py): the summary numbers, the weight stream's "
+                        "bytes / copy-engine time over the timed iterations, the library's per-launch brackets of the FIRST (warm-up) "
+                        "iteration, the host-memory peak, the planner's pick for the same line; a run the box cannot hold (MemoryError) "
+                        "is recorded with its reason instead of a traceback")
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--init", default="normal", choices=["normal", "uniform01", "trained-like"],
                    help="uniform01 = the reference's dummy-weight recipe (utils/opt-weight-gen.py:61-62)")
@@ -102,8 +107,30 @@ def prompt_input_ids(args, vocab, tokenizer, out=print):
     return row.repeat(args.batch_size, 1)
 
 
+def is_llama(args):
+    """`-m` names a Llama: a HF directory whose config.json says so (run_generation.py:159-166 loads OPT and Llama through the same
+    AutoModelForCausalLM call), or one of the known Llama shape names (random-init weights, like the OPT shape names)"""
+    if os.path.isdir(args.model_id):
+        from .checkpoint import is_llama_dir
+        return is_llama_dir(args.model_id)
+    try:
+        resolve_shape(args.model_id)
+        return False
+    except ValueError:
+        from .llama import resolve_llama_shape
+        try:
+            resolve_llama_shape(args.model_id)
+            return True
+        except ValueError:
+            return False
+
+
 def model_shape(args):
     """shape of the model `-m` names, without loading it (the planner needs it first)"""
+    if is_llama(args):
+        from .checkpoint import llama_shape_of
+        from .llama import resolve_llama_shape
+        return llama_shape_of(args.model_id) if os.path.isdir(args.model_id) else resolve_llama_shape(args.model_id)
     if os.path.isdir(args.model_id):
         import json
         from . import packed_checkpoint
@@ -155,6 +182,17 @@ def auto_plan(args, out=print):
 
 
 def load_model(args):
+    if is_llama(args):
+        # build-defined (the reference's LlamaDecoderLayer_forward carries no policy, decoder.py:121-169): layers [0, gpu%) resident,
+        # the others stream through the same WeightPipeline, every layer's arithmetic and KV cache on the GPU
+        from .llama import LiaLlamaModel
+        shape = model_shape(args)
+        n_gpu = shape.layers if args.gpu_percentage >= 100 else int(shape.layers * args.gpu_percentage / 100)
+        fmt = {"raw": 0, "pack10": 10}[args.stream_format or default_stream_format()]
+        if os.path.isdir(args.model_id):
+            from .checkpoint import load_hf_llama
+            return load_hf_llama(args.model_id, n_gpu_layers=n_gpu, pin_weight=True, wire=fmt)
+        return LiaLlamaModel.random_init(shape, seed=args.seed, n_gpu_layers=n_gpu, pin_weight=True, pack=fmt)
     if os.path.isdir(args.model_id):
         from . import packed_checkpoint
         if packed_checkpoint.is_packed_dir(args.model_id):
@@ -165,8 +203,17 @@ def load_model(args):
                 wires = [e["wire"] for e in man["layers"]]
                 args.stream_format = {0: "raw", 10: "pack10"}[max(set(wires), key=wires.count)]
             return packed_checkpoint.load_packed(args.model_id, n_gpu_layers=int(shape_layers * args.gpu_percentage / 100))
+        # a HF directory: converted layer by layer, every layer straight to the tier the flags name (checkpoint.load_hf_opt)
         from .checkpoint import load_hf_opt
-        return load_hf_opt(args.model_id)
+        from .scheduler import OffloadScheduler
+        import json
+        L_ = json.load(open(os.path.join(args.model_id, "config.json")))["num_hidden_layers"]
+        n_gpu = int(L_ * args.gpu_percentage / 100)
+        fmt = {"raw": 0, "pack10": 10}[args.stream_format or default_stream_format()]
+        if args.prefill_policy == 1 or args.decoding_policy == 1:
+            fmt = 0
+        raw = OffloadScheduler.cpu_layer_set(n_gpu, L_, args.cpu_layers) if (args.cpu_layers and args.cpu_layers > 0 and args.decoding_policy in (2, 3)) else ()
+        return load_hf_opt(args.model_id, n_gpu_layers=n_gpu, pin_weight=args.pin_weight, enable_cxl=args.enable_cxl, wire=fmt, raw_layers=raw)
     shape = resolve_shape(args.model_id)
     n_gpu = int(shape.layers * args.gpu_percentage / 100)
     fmt = {"raw": 0, "pack10": 10}[args.stream_format or default_stream_format()]
@@ -200,11 +247,15 @@ def summarize(total_time, num_iter, num_warmup, total_list, batch_size, out=prin
     return res
 
 
-def profile_once(model, input_ids, generate_kwargs, out=print):
+def profile_once(model, input_ids, generate_kwargs, out=print, warm=True):
     """--profile (run_generation.py:290-307): one generate() with every GEMM launch bracketed by HIP events on its own stream
-    (lia_prof_*), the host-attention wall clock and the weight stream's copy-engine time; prints the table and returns it."""
+    (lia_prof_*), the host-attention wall clock and the weight stream's copy-engine time; prints the table and returns it.
+    warm=False (--result-json): no untimed call in front -- the profiled generation IS the harness's first warm-up iteration."""
     sched = model._lia_scheduler
-    generate(model, input_ids, **dict(generate_kwargs, max_steps=2))       # untimed: allocations, placement, page-in
+    if warm:
+        generate(model, input_ids, **dict(generate_kwargs, max_steps=2))       # untimed: allocations, placement, page-in
+    elif getattr(sched, "ctx", None) is None:
+        generate(model, input_ids, **dict(generate_kwargs, max_steps=1))       # the library context (and its brackets) exists after the first forward
     st = {}
 
     def hook(step):
@@ -241,11 +292,82 @@ def profile_once(model, input_ids, generate_kwargs, out=print):
     out("%-8s %-40s %8s %12s %16s %12s" % ("phase", "what", "calls", "ms", "compute", "memory"))
     for r in rows:
         out("%-8s %-40s %8s %12.3f %16s %12s" % r)
+    profile_once.last = (res, rows)
     return rows
+
+
+def _dominant(rows, phase):
+    """the largest time share of a phase among the profiled resources (GEMM regimes, host attention, the link's copy engine)"""
+    cand = [(r[3], r[1]) for r in rows if r[0] == phase and r[1] != "wall clock"]
+    wall = next((r[3] for r in rows if r[0] == phase and r[1] == "wall clock"), None)
+    if not cand or not wall:
+        return None
+    ms, what = max(cand)
+    return {"what": what, "ms": round(ms, 2), "share_of_wall": round(ms / wall, 3)}
+
+
+def plan_beside(args):
+    """what lia_amd.planner would pick for this line's model / batch / lengths on this box (not applied): the reference hand-picks
+    these per script line (llm/scripts/lia_offline.sh:13-29)"""
+    if is_llama(args):
+        return {"note": "lia_amd.planner models OPT layers and the LIA policies; a Llama runs every layer on the GPU (build-defined, SURVEY.md quirk 3)"}
+    try:
+        from . import planner
+        box = planner.calibrate(verbose=False)
+        fmt = args.stream_format or default_stream_format()
+        box.wire_ratio = {"raw": 1.0, "pack10": 0.675}[fmt]
+        shape = model_shape(args)
+        B, T, new = args.batch_size, int(args.input_tokens), args.max_new_tokens
+        pl = planner.plan(shape, B, T, new, box)
+        rec = {"gpu_percentage": pl.gpu_percentage, "prefill_policy": pl.prefill_policy, "decoding_policy": pl.decoding_policy,
+               "predicted_prefill_ms": round(pl.prefill_ms, 1), "predicted_decode_tokens_per_s": round(pl.decode_tokens_per_s, 1),
+               "hbm_gb": round(pl.hbm_gb, 1), "host_gb": round(pl.host_gb, 1), "note": pl.note, "calibrated": box.calibrated}
+        if pl.n_gpu_layers < shape.layers:
+            c2, ms2 = planner.plan_cpu_layers(shape, B, T, new, pl.gpu_percentage, box)
+            c3, ms3 = planner.plan_cpu_layers(shape, B, T, new, pl.gpu_percentage, box, kv_in_hbm=True)
+            rec["cooperative"] = {"kv_on_host": {"host_layers": c2, "predicted_tokens_per_s": round(1e3 * B / ms2, 1)},
+                                  "kv_in_hbm": {"host_layers": c3, "predicted_tokens_per_s": round(1e3 * B / ms3, 1)}}
+        try:          # the hand-picked flags through the same model, for the ratio
+            pre, dec, hbm, host, _ = planner.estimate(shape, B, T, new, args.gpu_percentage, args.decoding_policy if args.decoding_policy in (2, 3) else 2, box)
+            rec["hand_picked_estimate"] = {"prefill_ms": round(pre, 1), "decode_tokens_per_s": round(1e3 * B / dec, 1), "hbm_gb": round(hbm, 1),
+                                           "host_gb": round(host, 1), "note": "decode estimated as policy 2" if args.decoding_policy not in (2, 3) else ""}
+        except Exception as e:       # noqa: BLE001
+            rec["hand_picked_estimate"] = {"error": str(e)}
+        return rec
+    except MemoryError as e:
+        return {"error": f"no placement fits: {e}"}
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if not args.result_json:
+        return _main(args)
+    import json
+    import resource
+    from . import hostinfo
+    rec = {"argv": list(argv) if argv is not None else None, "flags": {k: v for k, v in vars(args).items() if k != "result_json"}}
+    t0 = time.time()
+    try:
+        rec["result"] = _main(args, rec)
+        rec["status"] = "ok"
+    except MemoryError as e:
+        rec["status"], rec["reason"] = "refused: memory", str(e)
+        print("[refused]", e)
+    except ValueError as e:
+        rec["status"], rec["reason"] = "refused: flags", str(e)
+        print("[refused]", e)
+    rec["wall_s"] = round(time.time() - t0, 1)
+    mem = hostinfo.cgroup_memory()
+    rec["host_memory"] = {"cgroup_peak_gib": None if mem["peak"] is None else round(mem["peak"] / 2**30, 2),
+                          "cgroup_limit_gib": None if mem["max"] is None else round(mem["max"] / 2**30, 1),
+                          "process_max_rss_gib": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20, 2)}
+    os.makedirs(os.path.dirname(os.path.abspath(args.result_json)), exist_ok=True)
+    with open(args.result_json, "w") as f:
+        json.dump(rec, f, indent=1, default=str)
+    return rec.get("result")
+
+
+def _main(args, rec=None):
     print(args)
     if not args.benchmark:
         print("note: only the --benchmark protocol exists here; running it")
@@ -258,13 +380,30 @@ def main(argv=None):
         node = hostinfo.pin_node(0)
         if node >= 0 and hostinfo.pin_to_node(node):
             print(f"host threads pinned to NUMA node {node}")
+    if rec is not None and not args.auto_plan:
+        rec["planner_pick"] = plan_beside(args)
+    if args.auto_plan and is_llama(args):
+        raise SystemExit("[ERROR] --auto-plan plans OPT layers and the LIA policies; a Llama has no policy to plan (pick --gpu-percentage)")
     if args.auto_plan:
-        auto_plan(args)
+        pl = auto_plan(args)
+        if rec is not None:
+            rec["auto_plan"] = {"gpu_percentage": args.gpu_percentage, "prefill_policy": args.prefill_policy, "decoding_policy": args.decoding_policy,
+                                "cpu_layers": args.cpu_layers, "cpu_layers_start": args.cpu_layers_start,
+                                "predicted_prefill_ms": round(pl.prefill_ms, 1), "predicted_decode_tokens_per_s": round(pl.decode_tokens_per_s, 1)}
+    t_load = time.time()
     model = load_model(args)
+    if rec is not None:
+        rec["model_load_s"] = round(time.time() - t_load, 1)
     if args.stream_format is None:
         args.stream_format = default_stream_format()
     from .scheduler import OffloadScheduler
-    model._lia_scheduler = OffloadScheduler(model, wire=args.stream_format)     # generate() drives this scheduler
+    if getattr(model, "family", "opt") == "llama":
+        from .llama import LlamaScheduler
+        model._lia_scheduler = LlamaScheduler(model, pack=args.stream_format)
+        print(f"note: {model.shape.name} is a Llama: --prefill-policy / --decoding-policy have no counterpart (decoder.py:121-169); "
+              f"gpu% {args.gpu_percentage} of the layers resident, the others streamed, every layer computed on the GPU")
+    else:
+        model._lia_scheduler = OffloadScheduler(model, wire=args.stream_format)     # generate() drives this scheduler
     generate_kwargs = dict(do_sample=False, num_beams=1, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
                            token_latency=args.token_latency, prefill_policy=args.prefill_policy,
                            decoding_policy=args.decoding_policy, no_overlap=args.no_overlap, pin_weight=args.pin_weight,
@@ -278,9 +417,21 @@ def main(argv=None):
     if args.profile:
         profile_once(model, input_ids, generate_kwargs)
     total_time, total_list = 0.0, []
+    sched = model._lia_scheduler
     for i in range(args.num_iter):
+        if rec is not None and i == args.num_warmup and hasattr(sched, "stream_stats"):
+            sched.stream_stats(reset=True)                     # the weight stream's bytes / copy-engine time over the timed iterations
         tic = time.time()
-        output = generate(model, input_ids, **generate_kwargs)
+        if rec is not None and i == 0 and args.num_warmup >= 1 and hasattr(sched, "coop_report"):
+            profile_once(model, input_ids, generate_kwargs, warm=False)       # the first warm-up iteration, bracketed
+            output = profile_once.last[0]
+            if not args.token_latency:
+                output = output[0]
+            rows = profile_once.last[1]
+            rec["profile_of_warmup_iteration"] = {"rows": [list(r) for r in rows], "dominant_prefill": _dominant(rows, "prefill"),
+                                                  "dominant_decode": _dominant(rows, "decode")}
+        else:
+            output = generate(model, input_ids, **generate_kwargs)
         gen_ids = output[0] if args.token_latency else output
         toc = time.time()
         total_new_tokens = [int(o.shape[0] - i_.shape[0]) for i_, o in zip(input_ids, gen_ids)]
@@ -293,6 +444,13 @@ def main(argv=None):
             if args.token_latency:
                 total_list.append(output[1])
     res = summarize(total_time, args.num_iter, args.num_warmup, total_list, args.batch_size)
+    if rec is not None and hasattr(sched, "stream_stats"):
+        b, ms = sched.stream_stats()
+        n_t = max(1, args.num_iter - args.num_warmup)
+        rec["weight_stream"] = {"bytes_per_timed_iteration": b / n_t, "copy_engine_busy_ms_per_timed_iteration": round(ms / n_t, 1),
+                                "gbs_while_busy": round(b / max(ms, 1e-9) / 1e6, 2), "gbs_over_wall": round(b / max(total_time, 1e-9) / 1e9, 2),
+                                "fraction_of_63_gbs_link_over_wall": round(b / max(total_time, 1e-9) / 63e9, 3),
+                                "wire_format": args.stream_format}
     if "decode_tokens_per_s" in res:
         print("Decode throughput: %.2f tokens/s, prefill %.1f ms" % (res["decode_tokens_per_s"], res["prefill_ms"]))
     coop = getattr(model._lia_scheduler, "coop_report", lambda: None)()

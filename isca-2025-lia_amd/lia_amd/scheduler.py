@@ -274,6 +274,16 @@ def default_stream_format():
     return fmt
 
 
+def minibatch_bounds(B, num_minibatch):
+    """[(first row, rows)] of the prefill minibatches: num_minibatch clamped to [1, B]; every minibatch has int(B / num_minibatch)
+    rows (lia/modeling_opt.py:1178) except the last, which also takes the remainder the reference drops."""
+    B, n = int(B), max(1, min(int(num_minibatch), int(B)))
+    if B <= 0:
+        return []
+    mini = B // n
+    return [(i * mini, mini) for i in range(n - 1)] + [((n - 1) * mini, B - (n - 1) * mini)]
+
+
 _KV_SERIAL = itertools.count(1)      # KVState / LlamaKVState objects, numbered: id() values come back after a free
 
 
@@ -719,11 +729,15 @@ class OffloadScheduler:
                              "phases: the cache of a generation lives either in HBM or on the host")
         if is_prefill and policy == 2 and n_gpu < L:
             raise ValueError("prefill policy must be 0 on the GPU path (the reference has no prefill-2 branch)")
-        if B % num_minibatch:
-            raise ValueError(f"batch {B} not divisible by num_minibatch {num_minibatch}")
-        mini = B // num_minibatch if (policy in (0, 3) and is_prefill) or policy == 0 else B   # :1178 mini_bsz
+        # :1178 mini_bsz = int(bsz / num_minibatch), looped num_minibatch times: the reference leaves the rows behind the last full
+        # minibatch unwritten when the division has a remainder and computes nothing at all for num_minibatch > bsz -- both happen in
+        # its own scripts (cxl_offloading.sh:37 `--batch-size 1150 --num-minibatch 3`, lia_offline.sh:27-29 `--batch-size 1
+        # --num-minibatch 2`).  Here: the intended semantics -- num_minibatch clamped to the batch, the last
+        # minibatch takes the remainder (minibatch_bounds)
+        minis = minibatch_bounds(B, num_minibatch) if (policy in (0, 3) and is_prefill) or policy == 0 else [(0, B)]
+        mini = max(n for _, n in minis)
         return SimpleNamespace(B=B, T=T, L=L, n_gpu=n_gpu, is_prefill=is_prefill, policy=policy, prefill_policy=prefill_policy,
-                               decoding_policy=decoding_policy, gpu_percentage=gpu_percentage, mini=mini, overlap=not no_overlap,
+                               decoding_policy=decoding_policy, gpu_percentage=gpu_percentage, mini=mini, minis=minis, overlap=not no_overlap,
                                pos0=kv_state.len, coop=None, cpu_set=frozenset(), host_act=frozenset(), host_now=frozenset(),
                                t_fwd0=None, busy0=0.0, hold=None, x=None, y=None)
 
@@ -858,12 +872,12 @@ class OffloadScheduler:
                     pol, kvl = 3, hold[idx - n_gpu][2]             # same arithmetic, rows land in the HBM holding cache
                 if tail_last and idx == L - 1:
                     xlast = torch.empty((B, 1, sh.hidden), dtype=torch.bfloat16, device="cuda")
-                for i in range(B // mini):
-                    sl = slice(i * mini, (i + 1) * mini)
+                for b0, nb in s.minis:
+                    sl = slice(b0, b0 + nb)
                     if tail_last and idx == L - 1:
-                        ctx.layer_forward_last(m.desc, pol, wptrs, x[sl], xlast[sl], kvl, mini, T, pos0, i * mini)
+                        ctx.layer_forward_last(m.desc, pol, wptrs, x[sl], xlast[sl], kvl, nb, T, pos0, b0)
                     else:
-                        ctx.layer_forward(m.desc, pol, wptrs, x[sl], y[sl], kvl, mini, T, pos0, i * mini)
+                        ctx.layer_forward(m.desc, pol, wptrs, x[sl], y[sl], kvl, nb, T, pos0, b0)
             else:
                 ctx.layer_forward(m.desc, 2, wptrs, x, y, kv_state.kv[idx], B, T, pos0, 0)   # :1493-1543
             pipe.release(idx)

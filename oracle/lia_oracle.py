@@ -145,7 +145,7 @@ def tpp_unblock(wb):
 
 
 def generate(model, input_ids, max_new_tokens, heads, prefill_policy=1, decoding_policy=1, gpu_percentage=0,
-             return_logits=False):
+             return_logits=False, return_kv=False):
     """Greedy loop of the reference: greedy_search.py:144-424 over OPTDecoder.forward's layer loop
     (lia/modeling_opt.py:1222-1558): layers [0, n_gpu) run policy 3, the rest the phase's policy;
     n_gpu = int(L * gpu% / 100) (:1182).  Returns (ids [B,T+new], latency_list) like config.token_latency."""
@@ -174,6 +174,8 @@ def generate(model, input_ids, max_new_tokens, heads, prefill_policy=1, decoding
         lat.append(time.time() - tic)
         if return_logits:
             all_logits.append(logits)
+    if return_kv:          # + the per-layer caches [Smax, B, h, d] (rows [0, T + new - 1) written), for the K/V-row parity tests
+        return (ids, lat, all_logits, kcs, vcs) if return_logits else (ids, lat, kcs, vcs)
     if return_logits:
         return ids, lat, all_logits
     return ids, lat

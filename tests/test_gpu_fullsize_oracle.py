@@ -269,6 +269,67 @@ def test_opt30b_m16384_gemm_on_sampled_rows(opt_layer, oracle, which):
     op_close(to_bits(y[ridx]), ref, f"M=16384 {which} ({len(rows)} sampled rows)")
 
 
+@pytest.mark.parametrize("which", ["qkv", "out", "fc1", "fc2"])
+@pytest.mark.parametrize("M", [900, 450, 257])
+def test_opt30b_mid_m_gemm_vs_oracle(opt_layer, oracle, which, M):
+    """256 < M < 1024: the reference's large-batch operating point (llm/scripts/lia_offline.sh:21-23, cxl_offloading.sh:13-29 run
+    --batch-size 900, so every decode GEMM there has M = 900 rows: decoder.py:79-105, attentions.py:393-394,418).  r06 gives this
+    range the phased 256 x 256 kernel (masked last row tile; split over K where N / 256 tiles do not fill the chip).  The
+    layer's four GEMMs with their real epilogues at M = 900 / 450 / 257, oracle-checked on 96 rows that include both sides of
+    every 256-row tile boundary and the last rows."""
+    import torch
+    L = opt_layer
+    if L["name"] != "opt-30b":
+        pytest.skip("the batch-900 lines are OPT-30B")
+    orc = _checker(oracle)
+    H, F, W = L["H"], L["F"], L["W"]
+    from lia_amd import ops
+    offs = {n: i for i, n in enumerate(ops.LAYER_TENSORS)}
+    po, _ = ops.pack_offsets(L["desc"])
+    dev = lambda n, shape: L["flat"][po[offs[n]] // 2: po[offs[n]] // 2 + int(np.prod(shape))].view(*shape)  # noqa: E731
+    if which == "qkv":
+        w, b, res, relu, K = dev("q_w", (3 * H, H)), dev("q_b", (3 * H,)), None, False, H
+        wo, bo = np.concatenate([W["q_w"], W["k_w"], W["v_w"]]), np.concatenate([W["q_b"], W["k_b"], W["v_b"]])
+    elif which == "out":
+        w, b, relu, K, wo, bo, res = dev("out_w", (H, H)), dev("out_b", (H,)), False, H, W["out_w"], W["out_b"], _randn(torch, (M, H), 141)
+    elif which == "fc1":
+        w, b, res, relu, K, wo, bo = dev("fc1_w", (F, H)), dev("fc1_b", (F,)), None, True, H, W["fc1_w"], W["fc1_b"]
+    else:
+        w, b, relu, K, wo, bo, res = dev("fc2_w", (H, F)), dev("fc2_b", (H,)), False, F, W["fc2_w"], W["fc2_b"], _randn(torch, (M, H), 142)
+    x = _randn(torch, (M, K), 143, 0.5 if which == "fc2" else 1.0)
+    guard = torch.full((M + 64, w.shape[0]), float("nan"), dtype=torch.bfloat16, device="cuda")     # rows behind M must stay untouched
+    y = L["ctx"].linear(x, w, b, res, relu=relu)
+    L["ctx"].synchronize()
+    assert y.shape == (M, w.shape[0]) and not torch.isnan(y.float()).any()
+    del guard
+    edge = [r for r in (0, 1, 127, 128, 255, 256, 257, 383, 511, 512, 767, 768, 769, 895, 896, 897, 898, 899, M - 2, M - 1) if r < M]
+    rows = np.unique(np.concatenate([np.array(edge), np.random.RandomState(M).choice(M, 96 - len(edge), replace=False)]))
+    ridx = torch.from_numpy(rows).cuda()
+    ref = orc.linear(_bits(x[ridx]), wo, bo, None if res is None else _bits(res[ridx]), relu=relu)
+    op_close(to_bits(y[ridx]), ref, f"M={M} {which} ({len(rows)} rows incl. the tile edges)")
+
+
+def test_opt30b_prefill_attention_t2016_vs_oracle(opt_layer, oracle):
+    """The reference's long-prompt lines (llm/scripts/lia_offline.sh:15,19, lia_online.sh:17,23: --input-tokens 2016 / 1792): the
+    causal prefill attention at T = 2016, 56 heads x d = 128 (attentions.py:443-536), one row of the batch at full width, same
+    inputs on both sides.  31.5 key tiles per query block: the last tile is ragged (2016 = 31 x 64 + 32)."""
+    import torch
+    L = opt_layer
+    if L["name"] != "opt-30b":
+        pytest.skip("the long-prompt lines are OPT-30B")
+    orc = _checker(oracle)
+    H, heads = L["H"], L["heads"]
+    d, T, B = H // heads, 2016, 1
+    q = _randn(torch, (B, T, H), 151, 1.5)
+    kc, vc = _randn(torch, (T, B, heads, d), 152), _randn(torch, (T, B, heads, d), 153)
+    out = L["ctx"].attention(q, kc, vc, T, heads)
+    L["ctx"].synchronize()
+    ref = orc.attention(_bits(q), _bits(kc), _bits(vc), T, heads, True)
+    # softmax(dtype=bf16) probabilities are rounded before P.V (attentions.py:512): a probability that lands on the other side of
+    # a rounding boundary moves the output by up to one quantum of |v| ~ 3 (the largest output): same bound as the T = 256 op test
+    op_close(to_bits(out), ref, f"opt-30b prefill attention T={T} d={d}", min_exact=0.99)
+
+
 def _report_argmax(name, logits_bits, nxt, ref_logits, ref_next):
     rl = synth.bf16_bits_to_f32(ref_logits)
     top2 = np.sort(rl, -1)[:, -2:]

@@ -161,3 +161,65 @@ def test_llama_layer_forward_last_equals_last_position(oracle, name):
     assert_close(to_bits(yl)[:, 0], to_bits(yf)[:, -1], 0.07, 0.016, 0.75, "llama last-only vs full prefill")
     ctx.close()
     model.close()
+
+
+def _write_hf_llama(path, m, cfg, shards=2):
+    """synth.make_llama_model's dict as a HF LlamaForCausalLM directory: config.json + `shards` safetensors files"""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    json.dump(dict(architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=cfg["H"], num_attention_heads=cfg["heads"],
+                   num_key_value_heads=cfg["kvh"], intermediate_size=cfg["F"], num_hidden_layers=cfg["L"], vocab_size=cfg["vocab"],
+                   max_position_embeddings=64, rope_theta=cfg["theta"], rms_norm_eps=1e-5, torch_dtype="bfloat16", tie_word_embeddings=False),
+              open(os.path.join(path, "config.json"), "w"))
+    t = lambda bits: torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16).clone()      # noqa: E731
+    hf = {"in_norm_w": "input_layernorm", "q_w": "self_attn.q_proj", "k_w": "self_attn.k_proj", "v_w": "self_attn.v_proj", "o_w": "self_attn.o_proj",
+          "post_norm_w": "post_attention_layernorm", "gate_w": "mlp.gate_proj", "up_w": "mlp.up_proj", "down_w": "mlp.down_proj"}
+    parts = [{} for _ in range(shards)]
+    parts[0].update({"model.embed_tokens.weight": t(m["embed_tokens"]), "model.norm.weight": t(m["final_norm_w"])})
+    parts[-1]["lm_head.weight"] = t(m["lm_head"])
+    for i, lw in enumerate(m["layers"]):
+        for short, name in hf.items():
+            parts[i * shards // len(m["layers"])][f"model.layers.{i}.{name}.weight"] = t(lw[short])
+    for n, sd in enumerate(parts):
+        save_file(sd, os.path.join(path, f"model-{n + 1:05d}-of-{shards:05d}.safetensors"))
+
+
+@pytest.mark.parametrize("gpu_pct", [50, 100])
+def test_llama_hf_directory_through_run_py(tmp_path, capsys, gpu_pct):
+    """`python run.py --benchmark -m <HF Llama directory> ... --gpu-percentage 50 --pin-weight` (run_generation.py:159-166 loads OPT and
+    Llama through the same AutoModelForCausalLM call): config.json names LlamaForCausalLM -> checkpoint.load_hf_llama converts it
+    layer by layer (two safetensors shards), half the layers stream, the harness prints the HF golden continuation every iteration."""
+    from lia_amd import run_generation
+    z = np.load(os.path.join(GOLD, "llama_generate_h256.npz"))
+    vocab, H, heads, kvh, F, L, B, T, new, seed = [int(v) for v in z["cfg"]]
+    m = synth.make_llama_model(seed, vocab, H, heads, kvh, F, L, float(z["w_std"][0]))
+    ck = str(tmp_path / "tiny-llama")
+    _write_hf_llama(ck, m, dict(H=H, heads=heads, kvh=kvh, F=F, L=L, vocab=vocab, theta=float(z["theta"][0])))
+    prompt = synth.make_prompt_ids(seed + 1, B, T, vocab)[0]
+    orig = run_generation.synthetic_prompt
+    run_generation.synthetic_prompt = lambda vocab_, n, batch, seed=0: __import__("torch").from_numpy(np.tile(prompt[None, :], (batch, 1)))
+    try:
+        res = run_generation.main(["--benchmark", "-m", ck, "--dtype", "bfloat16", "--ipex", "--input-tokens", str(T), "--max-new-tokens", str(new),
+                                   "--batch-size", str(B), "--token-latency", "--num-iter", "2", "--num-warmup", "1", "--greedy",
+                                   "--prefill-policy", "0", "--decoding-policy", "2", "--gpu-percentage", str(gpu_pct), "--num-minibatch", "2",
+                                   "--pin-weight", "--stream-format", "pack10"])
+    finally:
+        run_generation.synthetic_prompt = orig
+    text = capsys.readouterr().out
+    assert "is a Llama" in text and res["prefill_ms"] > 0 and res["decode_tokens_per_s"] > 0
+    assert text.count(str(z["ids_bf16"][0, T:].tolist())) == 2, text[-2000:]
+
+
+def test_llama_shape_name_through_run_py(capsys):
+    """`run.py -m meta-llama/Llama-3-8B` used to end in `ValueError: unknown OPT shape`: a known Llama shape name now
+    resolves to a random-init model of that shape -- here a two-layer stand-in registered under a name, to keep the test small"""
+    from lia_amd import llama, run_generation
+    llama.LLAMA_SHAPES["llama-test-2l"] = llama.LlamaShape("llama-test-2l", 256, 4, 2, 512, 2, 512, max_pos=64, rope_theta=10000.0)
+    try:
+        res = run_generation.main(["--benchmark", "-m", "meta-llama/llama-test-2l", "--input-tokens", "8", "--max-new-tokens", "3", "--batch-size", "2",
+                                   "--token-latency", "--num-iter", "2", "--num-warmup", "1", "--greedy", "--gpu-percentage", "50", "--pin-weight"])
+    finally:
+        del llama.LLAMA_SHAPES["llama-test-2l"]
+    assert "is a Llama" in capsys.readouterr().out and res["decode_tokens_per_s"] > 0

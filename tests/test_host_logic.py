@@ -37,6 +37,22 @@ def test_cgroup_guards():
     assert hostinfo.default_host_threads(8) >= 1 and hostinfo.default_host_threads(1) >= hostinfo.default_host_threads(8)
 
 
+def test_minibatch_bounds_cover_every_row_once():
+    """the ragged prefill split (scheduler.minibatch_bounds): the reference's own script lines that lia/modeling_opt.py:1178's
+    int(bsz / num_minibatch) mishandles -- 1150 / 3 (cxl_offloading.sh:37), 1 / 2 (lia_offline.sh:27-29) -- and the property"""
+    from lia_amd.scheduler import minibatch_bounds
+    assert minibatch_bounds(1150, 3) == [(0, 383), (383, 383), (766, 384)]
+    assert minibatch_bounds(1, 2) == [(0, 1)]
+    assert minibatch_bounds(64, 2) == [(0, 32), (32, 32)] and minibatch_bounds(64, 1) == [(0, 64)]
+    assert minibatch_bounds(1580, 4) == [(0, 395), (395, 395), (790, 395), (1185, 395)]
+    for B in (1, 2, 3, 7, 64, 900, 1150):
+        for mb in (1, 2, 3, 4, 8, 2000):
+            b = minibatch_bounds(B, mb)
+            assert len(b) == min(B, mb) and b[0][0] == 0 and sum(n for _, n in b) == B and all(n >= 1 for _, n in b)
+            assert all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+            assert all(n == B // min(B, mb) for _, n in b[:-1])          # the reference's mini_bsz for every full minibatch
+
+
 def test_allgather_slices_cover_the_wire_bytes():
     from lia_amd.model import LayerStore
     for total in (1, 255, 256, 832_000_123, 1_233_315_840):

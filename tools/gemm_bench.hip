@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&y, (size_t)M * 128256 * 2)); CK(hipMalloc(&bias, 128256 * 2)); CK(hipMalloc(&res, (size_t)M * 128256 * 2));
   fill_kernel<<<256, 256>>>(bias, 128256, 5); fill_kernel<<<2048, 256>>>(res, (size_t)M * 128256, 7);
   if (M > 256) shapes.pop_back();  // no lm_head in prefill (last position only)
-  size_t ws_bytes = (size_t)8 * (M <= 256 ? M : 1) * 128256 * 4; CK(hipMalloc(&ws, ws_bytes));
+  size_t ws_bytes = M <= 256 ? (size_t)8 * M * 128256 * 4 : (size_t)4 * (M < 2048 ? M : 1) * 28672 * 4; CK(hipMalloc(&ws, ws_bytes));
   if (getenv("ZERO")) { for (int i = 0; i < NBUF; ++i) CK(hipMemset(w[i], 0, maxw * 2)); CK(hipMemset(x, 0, (size_t)M * 28672 * 2)); }
   LiaGemmOpts* const tickets = nullptr;       // (default options; the r04 in-launch combine and its tickets are gone)
   hipStream_t st; CK(hipStreamCreate(&st));
