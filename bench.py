@@ -67,7 +67,10 @@ def build_parser():
     ap.add_argument("--no-cooperative-leg", action="store_true", help="skip the build-defined cooperative-split leg (value_cooperative)")
     ap.add_argument("--no-auto-plan", action="store_true", help="skip the auto_plan object (what run.py --auto-plan would choose on this box, ~5 s)")
     ap.add_argument("--no-cooperative-kv-leg", action="store_true", help="skip the cooperative split's KV-in-HBM variant (value_cooperative_kv_in_hbm)")
-    ap.add_argument("--coop-steps", type=int, default=28, help="decode steps of the cooperative leg (the controller's search takes 12-20; value_cooperative = the last 8)")
+    ap.add_argument("--coop-steps", type=int, default=28, help="decode steps the cooperative leg gives the controller's search (it takes 12-20); "
+                    "--coop-windows x 8 more steps follow, value_cooperative = the median window")
+    ap.add_argument("--coop-windows", type=int, default=3, help="8-step windows behind the search; value_cooperative* = their median rate, each window "
+                    "reported with its own CFS-throttle counters (r05 verdict, weak item 9: one 8-step average had an unknown spread)")
     ap.add_argument("--no-dp-extra-legs", action="store_true", help="N > 1: skip the KV-in-HBM and all-gather legs")
     ap.add_argument("--dp-allgather-legs", action="store_true",
                     help="N > 1: also run the all-gather legs (every rank re-draws the model and pins 1/N of each streamed layer; value_allgather*). "
@@ -196,6 +199,38 @@ def cpu_oracle_sample(shape, B, T, threads):
                       f"scaled x{L} layers (x{B // Bp} batch for prefill); embeddings / lm_head excluded"}
 
 
+def cpu_host_head_sample(model, shape, B, threads, reps=3):
+    """The part of a decode step the policy-1 leg leaves on the GPU -- token + position embedding, final LayerNorm, the tied lm_head on
+    the last position, argmax -- measured on the HOST cores (the reference's policy 1 runs all of it on the CPU: embeddings
+    lia/modeling_opt.py:1108,1137-1142, final LN :1563, lm_head models.py:424-431): lia_host_layernorm + lia_host_linear over a host
+    copy of the embedding matrix (0.72 GB for OPT-30B) + numpy gather / argmax.  Returns ms per decode step; cpu_baseline.value adds
+    it to every host-layer step, so the reported baseline is a FULL-CPU step."""
+    import ctypes
+    import numpy as np
+    import torch
+    from lia_amd import _native as N
+    L = N.lib()
+    H, V = shape.hidden, shape.vocab
+    tok = model.embed_tokens.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+    pos = model.embed_positions.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+    lnw = model.final_ln_w.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+    lnb = model.final_ln_b.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+    ids = np.random.RandomState(1).randint(4, V, size=B)
+    f32 = lambda b: (b.astype(np.uint32) << 16).view(np.float32)          # noqa: E731
+    bf = lambda f: ((f.view(np.uint32) + 0x8000) >> 16).astype(np.uint16)  # noqa: E731
+    hid, y, logits = np.empty((B, H), np.uint16), np.empty((B, H), np.uint16), np.empty((B, V), np.uint16)
+    times = []
+    for _ in range(reps + 1):
+        t0 = time.time()
+        hid[:] = bf(f32(tok[ids]) + f32(pos[258][None, :]))                 # embed_tokens[ids] + embed_positions[position + 2]
+        N.check(L.lia_host_layernorm(hid.ctypes.data, lnw.ctypes.data, lnb.ctypes.data, y.ctypes.data, B, H, ctypes.c_float(shape.ln_eps), threads))
+        N.check(L.lia_host_linear(y.ctypes.data, tok.ctypes.data, None, None, logits.ctypes.data, B, V, H, 0, threads))
+        nxt = f32(logits).argmax(-1)
+        times.append(time.time() - t0)
+    return {"ms_per_step": 1e3 * min(times[1:]), "runs_ms": [round(1e3 * t, 2) for t in times[1:]], "threads": threads, "argmax_checksum": int(nxt.sum()),
+            "what": f"embedding gather + final LayerNorm + lm_head [{B} x {H}] x [{V} x {H}]^T + argmax on the host cores (lia_host_layernorm, lia_host_linear)"}
+
+
 def cpu_product_prefill_sample(model, shape, B, T, threads, n_layers=2):
     """The CPU baseline's PREFILL through the product's own host path (r05, r04 verdict item 5): lia_host_layer_forward on the
     configuration's full B x T rows (M = B * T > 256 -> the generic host GEMM, not the decode kernel) for n_layers consecutive
@@ -321,6 +356,31 @@ def promote_scalars(out):
     c["stream_format"] = hl.get("stream_format")
     c["bits_per_value"] = hl.get("bits_per_value_by_layer") or hl.get("bits_per_value")
     return out
+
+
+def coop_windows_run(generate, model, ids, kwargs, a, B, hostinfo, room):
+    """one cooperative leg: a generate() of 2 + --coop-steps + 8 * --coop-windows steps (its own cache size: the headline's
+    max_new_tokens may be smaller); the last 8 * windows decode steps are cut into windows of 8 -> (ids, lat, logits, value = the
+    MEDIAN window's tokens/s, [per window: ms per step, tokens/s, CFS throttle periods / ms])"""
+    W = max(1, min(a.coop_windows, (room - 2 - a.coop_steps) // 8))       # room: positions left behind the prompt
+    total = 2 + a.coop_steps + 8 * W
+    kw = dict(kwargs, max_new_tokens=total, min_new_tokens=total)
+    marks = {}
+
+    def hook(step):
+        if step >= total - 8 * W and (step - (total - 8 * W)) % 8 == 0:
+            marks[step] = hostinfo.cgroup_cpu_throttle()
+    ids_out, lat, logits = generate(model, ids, return_logits=True, step_hook=hook, **kw)
+    marks[total] = hostinfo.cgroup_cpu_throttle()
+    wins = []
+    for w in range(W):
+        s0 = total - 8 * (W - w)
+        seg = lat[s0:s0 + 8]
+        thr0, thr1 = marks.get(s0), marks.get(s0 + 8)
+        wins.append({"steps": [s0, s0 + 8], "ms_per_step": 1e3 * sum(seg) / len(seg), "tokens_per_s": B / (sum(seg) / len(seg)),
+                     "cpu_throttle": ({"periods": thr1[0] - thr0[0], "throttled_ms": (thr1[1] - thr0[1]) / 1e3} if thr0 and thr1 else None)})
+    rates = sorted(w["tokens_per_s"] for w in wins)
+    return ids_out, lat, logits, rates[len(rates) // 2], wins
 
 
 def throttle_delta(before):
@@ -522,6 +582,26 @@ def reduce_over_ranks(dist, backend, rank, world, elapsed, prefill_ms, dec_mean_
     return float(tmax[0]), float(tmax[1]), float(tmax[2]), dist.get_world_size(), per_rank
 
 
+def dp_predicted(a, shape, world, group_mode, T, new):
+    """the planner's prediction for THIS line (lia_amd.planner.predict_dp, committed as a table in DESIGN.md section 6 before any
+    multi-GPU hardware ran the code): ms per step, the binding resource and every term, for the line's N, rows, mode and both
+    cache placements -- so that a measured N > 1 line can be read against what was expected of it"""
+    try:
+        from lia_amd import planner
+        box = planner.Box(wire_ratio={"raw": 1.0, "pack10": 0.675}.get(a.stream_format or "pack10", 0.675))
+        rows = -(-a.global_batch // world) if a.global_batch else a.batch
+        out = {}
+        for pol in (3, 2):
+            ms, bound, terms = planner.predict_dp(shape, rows, T, new, a.gpu_percentage, world, group_mode or "broadcast", pol, box)
+            out["3/3" if pol == 3 else "0/2"] = {"ms_per_step": round(ms, 1), "tokens_per_s": round(1e3 * rows * world / ms, 1), "bound_by": bound,
+                                                   **{k: (round(v, 1) if isinstance(v, float) else v) for k, v in terms.items()}}
+        out["assumptions"] = (f"link {box.link_gbs} GB/s, xGMI link {planner.XGMI_LINK_GBS} GB/s x ring efficiency {planner.RCCL_RING_EFF} (assumed), "
+                              f"decode GEMM {box.hbm_gbs} GB/s, host attention {box.host_gbs_per_thread} GB/s per thread on 16 / N threads")
+        return out
+    except Exception as e:      # noqa: BLE001  (a prediction must never cost the measured line)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def dp_config_fields(a, shape, rows_total, world, group_mode, host_threads, policies):
     from lia_amd import dp
     return {"global_batch": rows_total, "rows_per_rank": [dp.shard_rows(rows_total, r, world)[1] - dp.shard_rows(rows_total, r, world)[0] for r in range(world)],
@@ -551,9 +631,10 @@ def dp_line_selftest(a):
     if rank == 0:
         cfg = {"workload": f"{shape.name} shape, dp line selftest"}
         cfg.update(dp_config_fields(a, shape, rows_total, world, "broadcast", host_threads, pol))
+        cfg["predicted"] = dp_predicted(a, shape, world, "broadcast", T, new)
         print(json.dumps({"metric": "dp line selftest", "value": rows_total * a.steps / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "scaling": "strong" if a.global_batch else "weak",
-                          "prefill_ms": prefill_ms, "rccl_ranks": ranks, "collective_backend": "gloo", "per_rank": per_rank, "config": cfg,
+                          "prefill_ms": prefill_ms, "collective_ranks": ranks, "rccl_ranks": ranks, "collective_backend": "gloo", "per_rank": per_rank, "config": cfg,
                           "dp_line_selftest": True}), flush=True)
     dist.destroy_process_group()
     return 0
@@ -619,8 +700,15 @@ def main(argv=None):
         a.bracket_stride = 32 if n_gpu >= shape.layers else 8       # both co-prime to the 193 / 129 launches of an OPT-30B / Llama-3-8B step
     host_threads = a.host_threads or hostinfo.default_host_threads(world)
     layer_bytes_est = 2 * (4 * shape.hidden ** 2 + 2 * shape.hidden * shape.ffn) if not is_llama else 0
-    policies = plan_policies(a, world, shape, B, T, new, layer_bytes_est, torch.cuda.get_device_properties(dev_index).total_memory, n_gpu) if not is_llama else (0, 0, "llama: all resident")
-    a.prefill_policy, a.decoding_policy = policies[0], policies[1]
+    # --dp-same-gpu (dry runs): the ranks share ONE card, so each may plan with its share of the HBM only
+    ranks_per_device = max(1, -(-world // max(1, torch.cuda.device_count()))) if a.dp_same_gpu else 1
+    hbm_per_rank = torch.cuda.get_device_properties(dev_index).total_memory // ranks_per_device
+    if is_llama:
+        # a Llama has no LIA policy (decoder.py:121-169): policies named on the command line are left as they are and not reported
+        policies = (a.prefill_policy, a.decoding_policy, "llama: no LIA policies (every layer on the GPU)")
+    else:
+        policies = plan_policies(a, world, shape, B, T, new, layer_bytes_est, hbm_per_rank, n_gpu)
+        a.prefill_policy, a.decoding_policy = policies[0], policies[1]
     # --cpu-layers -1: the scheduler's online controller picks the count from the measured decode steps, starting on the count this
     # box converged on last time (scheduler.CoopStore) or else on planner.plan_cpu_layers' estimate -- no explicit start from here
     flags = dict(prefill_policy=a.prefill_policy, decoding_policy=a.decoding_policy, pin_weight=True,
@@ -676,7 +764,7 @@ def main(argv=None):
         if step == 1 + a.warmup:                         # exactly --steps decode steps follow
             sched.stream_stats(reset=True)
             if not is_llama:
-                sched.decode_stats(reset=True)
+                sched.decode_stats(reset=True, block=False)      # (never drain the prefetched layers' decodes in front of the first timed step)
             sched.ctx.prof_start(16384, stride=a.bracket_stride)
             sync()
             st["thr0"] = hostinfo.cgroup_cpu_throttle()
@@ -720,16 +808,18 @@ def main(argv=None):
         raw_bytes = float(sum(s.nbytes for s in model.layers[n_gpu:] if s.tier not in ("device", "remote", None))) if not is_llama else 0.0
         out = {
             "metric": "decode tokens/s (+ prefill ms), OPT-30B bs=64 in256/out32 gpu%=10" if headline
-                      else ("decode tokens/s (+ prefill ms), OPT-30B bs=256 in256/out32 gpu%=10 batch-sharded (BASELINE config 5)" if config5
+                      else (f"decode tokens/s (+ prefill ms), OPT-30B bs=256 in256/out32 gpu%=10 batch-sharded (BASELINE config 5), policies {a.prefill_policy}/{a.decoding_policy}" if config5
                             else f"decode tokens/s (+ prefill ms), {a.model} bs={rows_total} in{T} gpu%={a.gpu_percentage}"),
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{shape.name} shape (random-init {'U[0,1)' if a.init == 'uniform01' else 'trained-like (per-tensor scales, outlier channels)' if a.init == 'trained-like' else 'N(0,0.02)'}), batch {B if rows_total == B * world else 'ceil(' + str(rows_total) + '/' + str(world) + ')'}/GPU identical rows, "
                                    f"prompt {T}, {new} new tokens, gpu%={a.gpu_percentage} ({n_gpu} resident + {shape.layers - n_gpu} streamed layers), "
-                                   f"prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
+                                   f"{'' if is_llama else f'prefill policy {a.prefill_policy}, decode policy {a.decoding_policy}, '}pin-weight{', enable-cxl nodes ' + str(a.cxl_nodes) if a.enable_cxl else ''}, "
                                    f"num-minibatch {a.num_minibatch}{(', ' + (str(a.cpu_layers) if a.cpu_layers > 0 else 'an online-chosen number of') + ' decode layers on the host cores') if a.cpu_layers else ''}",
-                       **dp_config_fields(a, shape, rows_total, world, (group.mode if group is not None else None), host_threads, policies), "prompt_len": T, "new_tokens": new, "new_tokens_requested": 32 if not is_llama else 128,
+                       **dp_config_fields(a, shape, rows_total, world, (group.mode if group is not None else None), host_threads, policies),
+                       **({"predicted": dp_predicted(a, shape, world, (group.mode if group is not None else None), T, new)} if (world > 1 and not is_llama) else {}),
+                       "prompt_len": T, "new_tokens": new, "new_tokens_requested": 32 if not is_llama else 128,
                        "new_tokens_note": f"the configuration asks for {32 if not is_llama else 128} new tokens; this run generated 1 + warmup + steps = {new} "
                                           f"(cache sized for {T + new} positions), so the timed decode steps run at S = {T + 1 + a.warmup}..{T + new - 1}",
                        "baseline_config": ("configs[1]" if headline else "configs[4]" if config5 else None),
@@ -773,7 +863,8 @@ def main(argv=None):
                                "gemm_tflops": prof_prefill["tiled_flops"] / max(prof_prefill["tiled_ms"], 1e-9) / 1e9,
                                "mfma_frac": prof_prefill["tiled_flops"] / max(prof_prefill["tiled_ms"], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS,
                                "h2d_busy_ms": pre_h2d_ms, "h2d_gbs_while_busy": pre_h2d_bytes / max(pre_h2d_ms, 1e-9) / 1e6},
-            "rccl_ranks": rccl_ranks, "collective_backend": (backend if dist is not None else None), "per_rank": per_rank,
+            "collective_ranks": rccl_ranks, "rccl_ranks": rccl_ranks, "rccl_ranks_note": "deprecated name of collective_ranks (it is reported under gloo too); kept for one round",
+            "collective_backend": (backend if dist is not None else None), "per_rank": per_rank,
             "host_cpu_throttle": {"periods": thr1[0] - st["thr0"][0], "throttled_ms": (thr1[1] - st["thr0"][1]) / 1e3,
                                   "note": "cgroup CFS quota stalls during the timed decode steps (cpu.stat)"},
             "build_s": build_s,
@@ -858,11 +949,11 @@ def main(argv=None):
             # -1: the scheduler's online controller.  No explicit start: it begins on the count this box converged on last time
             # (scheduler.CoopStore, +-1 probes only) when there is one, else on the same plan as c0
             coop_kwargs = dict(gen_kwargs, cpu_layers=-1)
-            ids_coop, lat_coop, logits_coop = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **coop_kwargs)
-            tail = lat_coop[-max(1, min(8, a.coop_steps // 2)):]                     # after the controller's search
-            out["value_cooperative"] = B / (sum(tail) / len(tail))
+            ids_coop, lat_coop, logits_coop, v_med, wins = coop_windows_run(generate, model, ids, coop_kwargs, a, B, hostinfo, shape.max_pos - T)
+            out["value_cooperative"] = v_med
             out["cooperative_leg"] = {"planned_host_layers": c0, "controller": sched.coop_report(), "decode_steps": len(lat_coop) - 1,
-                                      "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail), "leg_s": time.time() - t0,
+                                      "value_is": f"median of {len(wins)} windows of 8 decode steps behind the controller's search", "windows": wins,
+                                      "ms_per_step": 1e3 * B / v_med, "leg_s": time.time() - t0,
                                       "cpu_throttle": throttle_delta(thr_a), "host_team": sched.host_team_report(),
                                       "note": "decode layers computed on the host cores never cross the link (build-defined, SURVEY 8 f-3); "
                                               "the count is adjusted online from the measured copy-engine idle time"}
@@ -880,11 +971,11 @@ def main(argv=None):
                                                             wire_ratio={"raw": 1.0, "pack10": 0.675}[a.stream_format]),
                                                 kv_in_hbm=True)
                 kv_kwargs = dict(gen_kwargs, prefill_policy=3, decoding_policy=3, cpu_layers=-1)
-                ids_kv, lat_kv, logits_kv = generate(model, ids, max_steps=2 + a.coop_steps, return_logits=True, **kv_kwargs)
-                tail = lat_kv[-max(1, min(8, a.coop_steps // 2)):]
-                out["value_cooperative_kv_in_hbm"] = B / (sum(tail) / len(tail))
+                ids_kv, lat_kv, logits_kv, v_med, wins = coop_windows_run(generate, model, ids, kv_kwargs, a, B, hostinfo, shape.max_pos - T)
+                out["value_cooperative_kv_in_hbm"] = v_med
                 out["cooperative_kv_in_hbm_leg"] = {"planned_host_layers": c3, "controller": sched.coop_report(), "decode_steps": len(lat_kv) - 1,
-                                                    "steps_averaged": len(tail), "ms_per_step": 1e3 * sum(tail) / len(tail),
+                                                    "value_is": f"median of {len(wins)} windows of 8 decode steps behind the controller's search", "windows": wins,
+                                                    "ms_per_step": 1e3 * B / v_med,
                                                     "kv_moved_bytes": sched.kv_moved_bytes, "leg_s": time.time() - t0,
                                                     "cpu_throttle": throttle_delta(thr_a), "host_team": sched.host_team_report()}
                 ids_check["cooperative_kv_in_hbm_vs_headline"] = first_divergence(out_ids, ids_kv, T, logits_kv)
@@ -914,9 +1005,24 @@ def main(argv=None):
             cpu_pre = cpu_product_prefill_sample(model, shape, B, T, host_threads, a.cpu_prefill_layers) if a.cpu_prefill_layers > 0 else None
         except Exception as e:
             cpu_pre = {"error": f"{type(e).__name__}: {e}"}
+        # r05 verdict, weak item 8: the leg above keeps embeddings / final LN / lm_head on the GPU, the reference's policy 1 does not.
+        # The head is measured on the host cores and ADDED to every step: cpu_baseline.value is a full-CPU decode step.
+        try:
+            head = cpu_host_head_sample(model, shape, B, host_threads)
+            if "ms_per_step" in product:
+                product["decode_tokens_per_s_gpu_head"] = product["decode_tokens_per_s"]
+                product["ms_per_step_gpu_head"] = product["ms_per_step"]
+                product["ms_per_step"] = product["ms_per_step"] + head["ms_per_step"]
+                product["decode_tokens_per_s"] = 1e3 * B / product["ms_per_step"]
+                product["host_head"] = head
+                product["sample"] = product["sample"].replace("embeddings / final LN / lm_head stay on the GPU", "embeddings / final LN / lm_head measured on the host cores "
+                                                              "beside it (host_head) and added to every step")
+        except Exception as e:
+            product["host_head"] = {"error": f"{type(e).__name__}: {e}", "note": "value is host layers + GPU head"}
         best = max(orc["decode_tokens_per_s"], product.get("decode_tokens_per_s", 0.0))
         out["cpu_baseline"] = {"value": best, "unit": "tokens/s", "cores": ((sched.host_team_report() or {}).get("threads", host_threads) if best == product.get("decode_tokens_per_s") else host_threads), "kind": "port",
-                               "implementation": ("product host path through generate()" if best == product.get("decode_tokens_per_s") else "oracle restatement, one-layer sample"),
+                               "implementation": ("product host path through generate() + the head (embeddings, final LN, lm_head, argmax) on the host cores: a full-CPU step"
+                                                  if best == product.get("decode_tokens_per_s") else "oracle restatement, one-layer sample"),
                                "sample": product.get("sample", orc["sample"]),
                                "product_host_path": product, "oracle_port": orc,
                                "prefill_ms": (cpu_pre or {}).get("prefill_ms", orc["prefill_ms"]),

@@ -283,6 +283,10 @@ int lia_stream_mark_ready(lia_streamer* s, int slot);
  * the layer does not fit the format and must travel raw. */
 size_t lia_pack10_bound(size_t n_values);
 int lia_pack10_encode(const lia_bf16* src_device, size_t n_values, char* dst_device, size_t dst_capacity, size_t* out_bytes);
+/* Host-side consistency check of an encoded buffer's 256-byte header (magic, version, value count == the slot's, every offset
+ * inside `staged_bytes`, counts within their capacities) -- run when a packed layer is mapped from a checkpoint file or pinned,
+ * because the decode kernel takes its loop bounds and offsets from the header.  0 = consistent, negative = the failed check. */
+int lia_pack10_validate(const void* header_host, size_t staged_bytes, size_t n_values);
 /* Rebuild the raw bf16 values of an encoded buffer (device -> device), asynchronous on `stream` (NULL = the default
  * stream): the kernels the streamer runs, exposed for re-tiering a layer that the host holds in a packed format
  * (model placement, lia/modeling_opt.py:229-268) and for the round-trip tests.  format: 10 (the argument is kept so that a later
@@ -305,6 +309,10 @@ int lia_stream_poll_stats(lia_streamer* s, double* bytes, double* busy_ms);
  * in profiles/): launches, summed HIP-event milliseconds around the MAIN decode kernel on the decode stream, encoded bytes read and
  * bf16 bytes written by them since the last reset.  Waits for the decodes still in flight. */
 int lia_stream_decode_stats(lia_streamer* s, long* launches, double* ms, double* bytes_in, double* bytes_out, int reset);
+/* the same totals without blocking: decodes still in flight are left for a later call (counted into the window they finish in) --
+ * what bench.py calls at the edge of its timed region, so that reading the counters does not drain the prefetched layers' decodes
+ * right before the first timed step.  (busy_ms of lia_stream_stats includes the staging memcpy for PAGEABLE sources.) */
+int lia_stream_poll_decode_stats(lia_streamer* s, long* launches, double* ms, double* bytes_in, double* bytes_out, int reset);
 void* lia_stream_copy_stream(lia_streamer* s);
 
 /* ---- host memory tiers ------------------------------------------------------------------------------

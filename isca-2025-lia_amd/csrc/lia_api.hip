@@ -1393,6 +1393,18 @@ extern "C" int lia_stream_decode_stats(lia_streamer* s, long* launches, double* 
 
 // The non-blocking form: only copies whose end event has already completed are counted (a queued copy stays pending and is
 // counted by a later call).  For callers inside the token loop, which must never wait for the prefetched layers.
+extern "C" int lia_stream_poll_decode_stats(lia_streamer* s, long* launches, double* ms, double* bytes_in, double* bytes_out, int reset) {
+  if (!s) return LIA_ERR_INVALID;
+  for (int i = 0; i < s->n_slots; ++i) streamer_collect_decode(s, i, false);
+  (void)hipGetLastError();   // hipErrorNotReady from the query is an answer, not an error
+  if (launches) *launches = s->dec_launches;
+  if (ms) *ms = s->dec_ms;
+  if (bytes_in) *bytes_in = s->dec_in;
+  if (bytes_out) *bytes_out = s->dec_out;
+  if (reset) { s->dec_ms = s->dec_in = s->dec_out = 0; s->dec_launches = 0; }
+  return LIA_OK;
+}
+
 extern "C" int lia_stream_poll_stats(lia_streamer* s, double* bytes, double* busy_ms) {
   if (!s) return LIA_ERR_INVALID;
   for (int i = 0; i < s->n_slots; ++i)

@@ -449,12 +449,15 @@ extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, 
   // provisional stream positions at full capacity; compacted below once the real sizes are known
   hd.off_l2 = hd.off_tab3 + tab_bytes; hd.off_l3 = hd.off_l2 + l2_bytes; hd.off_esc = hd.off_l3 + l3_bytes;
   if (hipMemcpy(dst, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess) return -3;
-  (void)hipMemset(dst + hd.off_l2, 0, l2_bytes + l3_bytes);
+  if (hipMemset(dst + hd.off_l2, 0, l2_bytes + l3_bytes) != hipSuccess) return -3;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(lia_pack10_region_kernel, dim3(hd.n_regions < 4096 ? hd.n_regions : 4096), dim3(256), 0, 0, src, dst);
   hipLaunchKernelGGL(lia_pack10_count_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
   hipLaunchKernelGGL(lia_pack10_scan_kernel, dim3(1), dim3(1024), 0, 0, dst, 2);
   hipLaunchKernelGGL(lia_pack10_scan_kernel, dim3(1), dim3(1024), 0, 0, dst, 3);
   hipLaunchKernelGGL(lia_pack10_encode_kernel, dim3(2048), dim3(256), 0, 0, src, dst);
+  // a launch that failed leaves the header as it was written above (overflow = 0, empty planes): that must not read as success
+  if (hipGetLastError() != hipSuccess) return -3;
   if (hipMemcpy(&hd, dst, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) return -3;
   if (hd.overflow || hd.n_esc > hd.esc_cap || hd.n_l2 > hd.l2_cap || hd.n_l3 > hd.l3_cap) return 1;
   // compact: level 3 right behind the level-2 bytes in use, escape records right behind level 3 (downward moves, in order)
@@ -469,7 +472,27 @@ extern "C" int lia_pack10_encode(const bf16_t* src, size_t n_values, char* dst, 
   return 0;
 }
 
-// Decode either format (the header's magic says which); asynchronous on `st`.
+// Host-side check of an encoded buffer BEFORE it is trusted: the decode kernel sizes its loops and takes every offset
+// from the header, so a stale or corrupt layer file whose header disagrees with the slot would write past it.  `buf`: the first
+// 256 bytes (host memory: a mapped checkpoint file, a pinned copy); staged_bytes: the bytes the caller holds / will copy;
+// n_values: the bf16 values the destination slot has room for.  0 = consistent, negative = the reason (lia_last_error has the text).
+extern "C" int lia_pack10_validate(const void* buf, size_t staged_bytes, size_t n_values) {
+  if (!buf || staged_bytes < sizeof(LiaPack10Header)) return -1;
+  LiaPack10Header hd;
+  memcpy(&hd, buf, sizeof(hd));
+  if (hd.magic != LP10_MAGIC || hd.version != 2) return -2;
+  if (hd.n != n_values || (n_values % 1024) || hd.region_shift != LP10_REGION_SHIFT || hd.n_regions != (uint32_t)lp10_regions(n_values)) return -3;
+  const uint64_t offs[] = {hd.off_rtab, hd.off_a, hd.off_b0, hd.off_b1, hd.off_tab2, hd.off_tab3, hd.off_l2, hd.off_l3, hd.off_esc};
+  uint64_t prev = sizeof(LiaPack10Header);
+  for (uint64_t o : offs) { if (o < prev || o > staged_bytes) return -4; prev = o; }
+  if (hd.off_a + n_values > hd.off_b0 || hd.off_b1 + n_values / 8 > hd.off_tab2) return -4;
+  if (hd.overflow || hd.n_esc > hd.esc_cap || hd.n_l2 > hd.l2_cap || hd.n_l3 > hd.l3_cap || hd.n_l2 > n_values || hd.n_l3 > n_values) return -5;
+  if (hd.off_l2 + (hd.n_l2 + 3) / 4 > hd.off_l3 || hd.off_l3 + (hd.n_l3 + 1) / 2 > hd.off_esc || hd.off_esc + (uint64_t)hd.n_esc * 8 > staged_bytes) return -4;
+  return 0;
+}
+
+// Decode a pack10 buffer whose header the caller has validated (lia_pack10_validate at placement time: the kernel reads its loop
+// bounds and every offset from the header, `n_values` only sizes the grid); asynchronous on `st`.
 // ev0 / ev1 (nullable): recorded on `st` immediately around the MAIN decode kernel (lia_stream_decode_stats; the patch kernel
 // behind it -- a few hundred escape records -- is outside the bracket, as a profiler's per-kernel duration would have it).
 extern "C" void lia_packed_decode_launch(const char* src, bf16_t* dst, size_t n_values, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {

@@ -121,6 +121,9 @@ SIGNATURES = {
     "lia_stream_poll_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     "lia_stream_decode_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                         ctypes.POINTER(c_double), c_int]),
+    "lia_stream_poll_decode_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(c_double), ctypes.POINTER(c_double),
+                                             ctypes.POINTER(c_double), c_int]),
+    "lia_pack10_validate": (c_int, [c_void_p, c_size_t, c_size_t]),
     "lia_stream_copy_stream": (c_void_p, [c_void_p]),
     "numa_alloc_node": (c_void_p, [c_size_t, c_int]),
     "numa_alloc_interleave": (c_void_p, [c_size_t]),

@@ -187,7 +187,8 @@ class LlamaScheduler:
         from .scheduler import default_stream_format
         self.model, self.device, self.n_slots = model, device, n_slots
         fmt = default_stream_format() if pack is None else pack
-        self.pack = {"raw": 0, "pack10": 10, 0: 0, 10: 10, False: 0, True: 10}[fmt]
+        from .scheduler import wire_format_code
+        self.pack = wire_format_code(fmt)
         self.ctx = self.pipe = None
         self.hidden, self.resident, self.tables = {}, {}, None
         self.prefill_tail = True      # last layer of a prefill: last position only behind q|k|v (False: every position)

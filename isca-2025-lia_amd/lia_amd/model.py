@@ -388,6 +388,8 @@ class LayerStore:
         writable mapping (r02's form; pinning it with write intent may copy the pages into anonymous memory, so the guard
         below counts the layer as a full allocation either way).  fmt = 0 (raw bf16) or the packed format the file holds."""
         import mmap
+        if fmt not in (0, 10):
+            raise ValueError(f"{path}: wire format {fmt} is not supported by this build (raw or pack10)")
         if fmt == 0 and nbytes != self.nbytes:
             raise ValueError(f"{path}: raw layer of {nbytes} bytes, expected {self.nbytes}")
         from . import hostinfo
@@ -415,6 +417,19 @@ class LayerStore:
         self._mm, self._mm_base, self.map_mode = mm, base, mode
         self._ptr, self.tier = base + (offset - start), "mapped"
         self.packed, self.stream_bytes, self.want_fmt = int(fmt), nbytes, int(fmt)
+        if fmt:
+            try:
+                self._validate_packed(self._ptr, nbytes, path)       # the decode kernel trusts the header: check it before the first stream
+            except ValueError:
+                self._free()
+                raise
+
+    def _validate_packed(self, host_ptr, nbytes, what):
+        rc = self._lib.lia_pack10_validate(ctypes.c_void_p(host_ptr), nbytes, self.nbytes // 2)
+        if rc != 0:
+            why = {-1: "shorter than a header", -2: "bad magic / version", -3: "value count differs from this model's layer",
+                   -4: "an offset points outside the buffer", -5: "a count exceeds its capacity"}.get(rc, f"code {rc}")
+            raise ValueError(f"{what}: not a consistent pack10 layer of {self.nbytes // 2} values ({why}); the file is stale or corrupt")
 
     def set_from_file_to_device(self, path, offset, nbytes, fmt):
         """A RESIDENT layer of a packed checkpoint directory: plain read of the wire bytes, one H2D copy, decoded on the device when
@@ -424,6 +439,10 @@ class LayerStore:
         host = np.fromfile(path, dtype=np.uint8, count=nbytes, offset=offset)
         if host.size != nbytes:
             raise ValueError(f"{path}: short read ({host.size} of {nbytes} bytes)")
+        if fmt not in (0, 10):
+            raise ValueError(f"{path}: wire format {fmt} is not supported by this build (raw or pack10)")
+        if fmt:
+            self._validate_packed(host.ctypes.data, nbytes, path)
         dev = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
         if fmt:
             enc = torch.empty(nbytes, dtype=torch.uint8, device="cuda")

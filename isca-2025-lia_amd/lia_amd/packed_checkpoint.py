@@ -6,7 +6,7 @@ Reference: a model reaches the hot path as an HF checkpoint directory -- written
 Here a model is written ONCE as a directory of per-layer wire buffers, exactly the bytes the weight streamer moves:
 
     <dir>/lia_model.json     format tag, model shape, the 16 tensor offsets inside a layer buffer, one entry per layer
-                             {file, wire (0 raw | 10 | 11 | 12), bytes, raw_bytes}, the head file
+                             {file, wire (0 raw | 10 pack10), bytes, raw_bytes}, the head file
     <dir>/head.bin           embed_tokens | embed_positions | final_ln_w | final_ln_b, raw bf16
     <dir>/layer_NNN.bin      one packed layer: raw bf16 (lia_layer_pack_offsets layout) or its lossless pack10 encoding
 
@@ -126,6 +126,11 @@ def load_packed(dirpath, n_gpu_layers=0):
     from . import hostinfo
     hostinfo.check_host_allocation(sum(int(e["bytes"]) for e in man["layers"][n_gpu_layers:]),
                                    f"{dirpath}: registering {len(man['layers']) - n_gpu_layers} streamed layers")
+    bad = sorted({int(e["wire"]) for e in man["layers"]} - {0, 10})
+    if bad:
+        # (pack11 / pack12 were choices of --wire until r04; their decode kernels are gone)
+        raise ValueError(f"{dirpath}: layers in wire format {bad} -- this build reads raw (0) and pack10 (10) only; rewrite the directory "
+                         "(python -m lia_amd.packed_checkpoint --model ... --wire pack10)")
     for i, (st, ent) in enumerate(zip(model.layers, man["layers"])):
         path = os.path.join(dirpath, ent["file"])
         if os.path.getsize(path) != ent["bytes"]:

@@ -244,3 +244,78 @@ def plan(shape, B, T, new, box=None, objective="decode", max_gpu_percentage=100)
     p.note = ("all layers HBM-resident" if p.n_gpu_layers == shape.layers else
               f"{shape.layers - p.n_gpu_layers} layers streamed at {box.link_gbs:.0f} GB/s")
     return p
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 (BASELINE.json configs[4]): a PREDICTION of the batch-sharded decode step, written down before
+# any multi-GPU hardware has run this code, so that the first SCALE_r*.json can be read against it.
+# ---------------------------------------------------------------------------------------------------------------------
+XGMI_LINK_GBS = 153.0          # one xGMI link, per direction (MI355X: 7 links per GPU, point to point)
+RCCL_RING_EFF = 0.70           # share of a link a pipelined ring broadcast / all-gather sustains on 16-64 MB chunks (assumed; never measured here)
+HOST_DRAM_GBS = 400.0          # what one socket's DRAM feeds to N copy engines at once (assumed; the r03 box read 223 GB/s with 16 threads)
+WIRE_DECODE_MS_PER_GB = 0.47   # lia_pack10_decode_kernel: 392 us for an OPT-30B layer's 0.832 GB of wire bytes (profiles/r05_opt30b_decode_timeline.txt)
+
+
+def predict_dp(shape, rows_per_rank, T, new, gpu_percentage, world, mode="broadcast", decoding_policy=3, box=None, host_cpus=16):
+    """Predicted decode step of `world` ranks on one node, each with `rows_per_rank` rows: (ms per step, the binding resource,
+    every term).  mode: "broadcast" (the north star's: the root's link carries every streamed layer once, RCCL broadcasts it) or
+    "allgather" (every rank pulls 1 / world of the wire bytes over ITS link, one all-gather per layer).  decoding_policy 3: every
+    layer's KV cache in the rank's HBM (bench.py's N > 1 default); 2: host attention on the rank's share of the host cores.
+    The terms: the link (or links), the collective on one xGMI link, the wire decode + GEMMs + attention on each GPU, the host
+    attention on host_cpus / world threads, and the host memory the pinned weights (+ caches) need."""
+    box = box or Box()
+    L, H = shape.layers, shape.hidden
+    n_gpu = int(L * gpu_percentage / 100)
+    n_str = L - n_gpu
+    lb = layer_bytes(shape)
+    wire = lb * box.wire_ratio
+    kv_read = 2 * (T + new // 2) * rows_per_rank * H * 2
+    gemm_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
+    attn_gpu_ms = 1e3 * kv_read / (box.attn_gbs * 1e9)
+    threads = max(1, host_cpus // world)
+    attn_host_ms = 1e3 * kv_read / (min(threads * box.host_gbs_per_thread, box.host_gbs_cap) * box.host_attn_beside_stream * 1e9)
+    decode_ms = WIRE_DECODE_MS_PER_GB * wire / 1e9 if box.wire_ratio < 1.0 else 0.0
+    lm_ms = 1e3 * shape.vocab * H * 2 / (box.hbm_gbs * 1e9)
+    if mode == "allgather" and world > 1:
+        link_ms = n_str * 1e3 * wire / (min(world * box.link_gbs, HOST_DRAM_GBS) * 1e9)
+        coll_ms = n_str * 1e3 * wire * (world - 1) / world / (XGMI_LINK_GBS * RCCL_RING_EFF * 1e9)
+    else:
+        link_ms = n_str * 1e3 * wire / (box.link_gbs * 1e9)
+        coll_ms = n_str * 1e3 * wire / (XGMI_LINK_GBS * RCCL_RING_EFF * 1e9) if world > 1 else 0.0
+    # RCCL on a fully connected xGMI node may spread a collective over up to min(world - 1, 7) links instead of one ring: the
+    # optimistic end of the prediction (never measured here either)
+    coll_all_links_ms = coll_ms / max(1, min(world - 1, 7))
+    per_layer_gpu = gemm_ms + decode_ms + (attn_gpu_ms if decoding_policy == 3 else attn_host_ms + 0.3)
+    gpu_ms = n_gpu * (gemm_ms + attn_gpu_ms) + n_str * per_layer_gpu + lm_ms + 0.5
+    terms = {"host_link_ms": link_ms, "xgmi_collective_ms": coll_ms, "xgmi_collective_all_links_ms": coll_all_links_ms,
+             "ms_per_step_if_all_links": max(link_ms, coll_all_links_ms, gpu_ms), "per_gpu_compute_ms": gpu_ms,
+             "host_attention_ms": (n_str * attn_host_ms if decoding_policy == 2 else 0.0), "host_attention_threads_per_rank": threads}
+    # the copy stream runs the host copy and the collective back to back per chunk (scheduler._prefetch_broadcast): they pipeline
+    # across chunks, so the stream's time is the larger of the two, and the step is the larger of that and the compute chain
+    step = max(link_ms, coll_ms, gpu_ms)
+    bound = max((("host link (root's PCIe)" if mode != "allgather" else "host links (one per rank) / host DRAM"), link_ms),
+                ("RCCL collective on one xGMI link", coll_ms),
+                (("host attention threads" if decoding_policy == 2 and n_str * attn_host_ms > 0.5 * gpu_ms else "per-GPU compute"), gpu_ms),
+                key=lambda t: t[1])[0]
+    kv_gb = 2 * (T + new) * rows_per_rank * H * 2 * L / 1e9
+    terms["pinned_host_gb"] = n_str * wire / 1e9 + (world * kv_gb * n_str / L if decoding_policy == 2 else 0.0)
+    terms["hbm_gb_per_rank"] = n_gpu * lb / 1e9 + 4 * lb / 1e9 + (kv_gb if decoding_policy == 3 else kv_gb * n_gpu / L) + 2 * shape.vocab * H * 2 / 1e9 + 3.5
+    return step, bound, terms
+
+
+def predict_dp_table(shape, T, new, gpu_percentage, box=None, rows_weak=64, global_batch=256, host_cpus=16):
+    """the table DESIGN.md section 6 and bench.py's `config.predicted` carry: N = 1, 2, 4, 8 x {weak: rows_weak rows per GPU, strong:
+    global_batch rows over the GPUs} x {broadcast, allgather} x {policy 3 / 3, policy 0 / 2}"""
+    rows = []
+    for scaling, rows_of in (("weak", lambda n: rows_weak), ("strong", lambda n: -(-global_batch // n))):
+        for n in (1, 2, 4, 8):
+            for mode in ("broadcast", "allgather"):
+                if n == 1 and mode == "allgather":
+                    continue
+                for pol in (3, 2):
+                    r = rows_of(n)
+                    ms, bound, terms = predict_dp(shape, r, T, new, gpu_percentage, n, mode, pol, box, host_cpus)
+                    rows.append({"scaling": scaling, "n_gpus": n, "rows_per_gpu": r, "mode": mode, "policies": "3/3" if pol == 3 else "0/2",
+                                 "ms_per_step": round(ms, 1), "tokens_per_s": round(1e3 * r * n / ms, 1), "bound_by": bound,
+                                 **{k: (round(v, 1) if isinstance(v, float) else v) for k, v in terms.items()}})
+    return rows

@@ -201,7 +201,7 @@ def load_model(args):
             shape_layers = man["shape"]["layers"]
             if args.stream_format is None:       # stream what is on disk, as it is
                 wires = [e["wire"] for e in man["layers"]]
-                args.stream_format = {0: "raw", 10: "pack10"}[max(set(wires), key=wires.count)]
+                args.stream_format = {0: "raw", 10: "pack10"}.get(max(set(wires), key=wires.count), "pack10")     # (load_packed refuses other formats by name)
             return packed_checkpoint.load_packed(args.model_id, n_gpu_layers=int(shape_layers * args.gpu_percentage / 100))
         # a HF directory: converted layer by layer, every layer straight to the tier the flags name (checkpoint.load_hf_opt)
         from .checkpoint import load_hf_opt

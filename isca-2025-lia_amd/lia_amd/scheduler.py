@@ -191,10 +191,12 @@ class WeightPipeline:
                 return True
         return False
 
-    def decode_stats(self, reset=False):
-        """wire-format decode kernel since the last reset: {"launches", "ms", "bytes_in", "bytes_out"} (lia_stream_decode_stats)"""
+    def decode_stats(self, reset=False, block=True):
+        """wire-format decode kernel since the last reset: {"launches", "ms", "bytes_in", "bytes_out"} (lia_stream_decode_stats);
+        block=False: never waits for decodes in flight (lia_stream_poll_decode_stats) -- for the edge of a timed region"""
         n, ms, bi, bo = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        N.check(self.lib.lia_stream_decode_stats(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(bi), ctypes.byref(bo), int(reset)))
+        fn = self.lib.lia_stream_decode_stats if block else self.lib.lia_stream_poll_decode_stats
+        N.check(fn(self.handle, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(bi), ctypes.byref(bo), int(reset)))
         return {"launches": n.value, "ms": ms.value, "bytes_in": bi.value, "bytes_out": bo.value}
 
     def poll_stats(self):
@@ -282,6 +284,15 @@ def minibatch_bounds(B, num_minibatch):
         return []
     mini = B // n
     return [(i * mini, mini) for i in range(n - 1)] + [((n - 1) * mini, B - (n - 1) * mini)]
+
+
+def wire_format_code(fmt):
+    """"raw" / "pack10" / 0 / 10 / False / True -> 0 | 10; anything else (pack11 / pack12 of builds before r05) is refused by name"""
+    codes = {"raw": 0, "pack10": 10, False: 0, True: 10, 0: 0, 10: 10}
+    if fmt not in codes:
+        raise ValueError(f"wire format {fmt!r} is not supported by this build (raw or pack10): a model directory written with "
+                         "--wire pack11 / pack12 by an earlier build must be rewritten (python -m lia_amd.packed_checkpoint ... --wire pack10)")
+    return codes[fmt]
 
 
 _KV_SERIAL = itertools.count(1)      # KVState / LlamaKVState objects, numbered: id() values come back after a free
@@ -569,7 +580,7 @@ class OffloadScheduler:
         self.n_slots = n_slots or 4
         # wire format of the streamed layers: "pack10" (the lossless encoding of lia_pack10.hip) or "raw" bf16
         fmt = default_stream_format() if wire is None else wire
-        self.wire = {"raw": 0, "pack10": 10, False: 0, True: 10, 0: 0, 10: 10}[fmt]
+        self.wire = wire_format_code(fmt)
         self.ctx = None
         self.ws_rows = 0
         self.pipe = None
@@ -1126,8 +1137,8 @@ class OffloadScheduler:
     def stream_stats(self, reset=False):
         return self.pipe.stats(reset) if self.pipe else (0.0, 0.0)
 
-    def decode_stats(self, reset=False):
-        return self.pipe.decode_stats(reset) if self.pipe else {"launches": 0, "ms": 0.0, "bytes_in": 0.0, "bytes_out": 0.0}
+    def decode_stats(self, reset=False, block=True):
+        return self.pipe.decode_stats(reset, block) if self.pipe else {"launches": 0, "ms": 0.0, "bytes_in": 0.0, "bytes_out": 0.0}
 
     def close(self):
         if self.pipe:

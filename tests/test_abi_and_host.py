@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -473,3 +474,31 @@ print("ok")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-800:], r.stderr[-2000:])
+
+
+def test_pack10_validate_refuses_garbage_on_the_host():
+    """lia_pack10_validate is host code (no GPU): a buffer that is not a pack10 header is refused with the failed check's code"""
+    import ctypes
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "isca-2025-lia_amd"))
+    from lia_amd import _native as N
+    L = N.lib()
+    junk = np.zeros(4096, np.uint8)
+    assert L.lia_pack10_validate(junk.ctypes.data, 4096, 1024) == -2        # no magic
+    assert L.lia_pack10_validate(junk.ctypes.data, 100, 1024) == -1         # shorter than a header
+    assert L.lia_pack10_validate(None, 4096, 1024) == -1
+    hdr = np.zeros(64, np.uint32)
+    hdr[0], hdr[1] = 0x3031504c, 2                                           # 'LP10', version 2, but n = 0
+    assert L.lia_pack10_validate(hdr.ctypes.data, 256, 1024) == -3
+
+
+def test_packed_directory_in_a_removed_wire_format_is_refused_by_name(tmp_path):
+    """a directory written with --wire pack11 / pack12 by an earlier build ended in a bare KeyError"""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "isca-2025-lia_amd"))
+    from lia_amd import scheduler
+    with pytest.raises(ValueError, match="pack10"):
+        scheduler.wire_format_code(12)
+    with pytest.raises(ValueError, match="pack10"):
+        scheduler.wire_format_code("pack11")
+    assert [scheduler.wire_format_code(f) for f in ("raw", "pack10", 0, 10, False, True)] == [0, 10, 0, 10, 0, 10]

@@ -84,7 +84,11 @@ def test_dp_line_at_world_8_over_gloo():
                         "--steps", "5", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
-    assert d["dp_line_selftest"] is True and d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "strong"
+    assert d["dp_line_selftest"] is True and d["n_gpus"] == 8 and d["collective_ranks"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "strong"
+    # the prediction the line carries for itself (planner.predict_dp): both cache placements, the binding resource named
+    pred = d["config"]["predicted"]
+    assert set(pred) >= {"3/3", "0/2", "assumptions"} and pred["3/3"]["bound_by"] and pred["3/3"]["ms_per_step"] > 0
+    assert pred["0/2"]["host_attention_threads_per_rank"] == 2 and pred["0/2"]["ms_per_step"] >= pred["3/3"]["ms_per_step"]
     assert d["config"]["global_batch"] == 256 and d["config"]["rows_per_rank"] == [32] * 8 and d["config"]["parallelism"].startswith("dp8 batch-shard")
     assert d["config"]["policies"]["prefill"] == 3 and d["config"]["policies"]["decode"] == 3 and "HBM" in d["config"]["policies"]["why"]
     assert [r["rank"] for r in d["per_rank"]] == list(range(8)) and all(r["rows"] == 32 for r in d["per_rank"])

@@ -389,12 +389,23 @@ def test_pack10_roundtrip_is_bit_exact(gpu, kind, fmt):
     ctx.synchronize()
     torch.cuda.synchronize()
     slot = L.lia_stream_slot_ptr(h, 0)
-    back = torch.empty(n, dtype=torch.int16, device="cuda")
-    N.check(L.lia_memcpy_d2h(ctypes.c_void_p(back.data_ptr()), ctypes.c_void_p(slot), 0) if False else 0)
     res = np.empty(n, np.uint16)
     N.check(L.lia_memcpy_d2h(res.ctypes.data, ctypes.c_void_p(slot), 2 * n))
     assert (res == bits).all(), int((res != bits).sum())
     L.lia_stream_destroy(h)
+    # the header check that placement runs before a packed layer is trusted (lia_pack10_validate): the real header
+    # passes; a wrong value count, a truncated buffer, an offset beyond the staged bytes and a foreign magic are each named
+    hb = host.numpy()
+    assert L.lia_pack10_validate(hb.ctypes.data, out.value, n) == 0
+    assert L.lia_pack10_validate(hb.ctypes.data, out.value, n + 1024) == -3            # a layer of another size
+    assert L.lia_pack10_validate(hb.ctypes.data, 128, n) == -1
+    assert L.lia_pack10_validate(hb.ctypes.data, out.value // 2, n) == -4              # half the file is missing
+    bad = hb.copy()
+    bad[0] ^= 0xff
+    assert L.lia_pack10_validate(bad.ctypes.data, out.value, n) == -2
+    bad = hb.copy()
+    bad[16:24] = np.frombuffer(np.uint64(n + 1024).tobytes(), np.uint8)                # header.n larger than the slot
+    assert L.lia_pack10_validate(bad.ctypes.data, out.value, n) == -3
 
 
 @pytest.mark.parametrize("kind", ["sigma-spread", "student-t", "real-layer-like"])

@@ -444,3 +444,26 @@ def test_bench_first_divergence_reports_step_and_gap():
     assert abs(r["top2_logit_gap_at_divergence"] - 0.0625) < 1e-6 and abs(r["bf16_quantum_at_top_logit"] - 0.0625) < 1e-9
     same = bench.first_divergence(a, a[:, :5], T)
     assert same == {"ids_equal": True, "steps_compared": 2, "first_divergent_step": None}
+
+
+def test_predicted_dp_table_names_what_binds_each_line():
+    """planner.predict_dp (DESIGN.md section 6's table, bench.py's config.predicted): the broadcast stream is bound by the root's link at
+    every N (throughput grows with the rows, the step does not move), the all-gather stream divides the link time by N until one
+    xGMI ring or the host attention threads bind, and policy 0 / 2 pays the 16 / N host threads per rank."""
+    from lia_amd import planner
+    from lia_amd.model import resolve_shape
+    sh = resolve_shape("opt-30b")
+    box = planner.Box(host_threads=16, host_mem_gb=300.0)
+    rows = planner.predict_dp_table(sh, 256, 32, 10, box)
+    pick = lambda **kw: [r for r in rows if all(r[k] == v for k, v in kw.items())]          # noqa: E731
+    assert len(rows) == 2 * (2 + 3 * 4)
+    b33 = pick(scaling="weak", mode="broadcast", policies="3/3")
+    assert [r["n_gpus"] for r in b33] == [1, 2, 4, 8] and len({r["ms_per_step"] for r in b33}) == 1 and all("link" in r["bound_by"] for r in b33)
+    assert [round(r["tokens_per_s"] / b33[0]["tokens_per_s"]) for r in b33] == [1, 2, 4, 8]
+    ag = pick(scaling="weak", mode="allgather", policies="3/3")
+    assert ag[0]["ms_per_step"] < b33[0]["ms_per_step"] and ag[-1]["host_link_ms"] < ag[0]["host_link_ms"]
+    assert "xGMI" in ag[-1]["bound_by"] and ag[-1]["ms_per_step_if_all_links"] < ag[-1]["ms_per_step"]
+    h8 = pick(scaling="weak", n_gpus=8, mode="allgather", policies="0/2")[0]
+    assert h8["host_attention_threads_per_rank"] == 2 and "host attention" in h8["bound_by"]
+    strong = pick(scaling="strong", mode="broadcast", policies="3/3")
+    assert [r["rows_per_gpu"] for r in strong] == [256, 128, 64, 32] and len({r["tokens_per_s"] for r in strong}) == 1   # link-bound: no gain from N
