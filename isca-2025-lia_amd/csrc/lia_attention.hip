@@ -281,6 +281,27 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   const bf16_t* vbase = vc + (long)(b0 + b) * kv_batch + (long)kh * D;
   const float qscale = POST_SCALE ? 1.0f : scaling;
 
+  // ---- staging by LDS-DMA: instruction j of wave w moves key rows 16 j + 4 w + (lane >> 4) of the tile, one 16-byte chunk per lane,
+  // to consecutive LDS bytes (1 KB per instruction); the images' chunk permutations are applied on the SOURCE side:
+  //   K: chunk c of row R sits in slot c ^ (R & 15);  V: in slot c ^ (((R & 3) << 2) | ((R >> 2) & 3))   (R & 15 = 4 w + (lane >> 4))
+  const int srow = 4 * wave + (lane >> 4), sslot = lane & 15;
+  const bf16_t* ksrc = kbase + 8 * (sslot ^ srow);
+  const bf16_t* vsrc = vbase + 8 * (sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
+#define P3_ISSUE(t, buf, WITH_V)                                                                                                   \
+  do {                                                                                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                             \
+      const long key_ = min((t) * 64 + 16 * j_ + srow, T - 1);                                                                     \
+      __builtin_amdgcn_global_load_lds(GL_AS1(ksrc + key_ * kv_row), LDS_AS3(&lds[buf][0][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
+      if (WITH_V)                                                                                                                  \
+        __builtin_amdgcn_global_load_lds(GL_AS1(vsrc + key_ * kv_row), LDS_AS3(&lds[buf][1][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
+    }                                                                                                                              \
+  } while (0)
+
+  // r06: the first K tile is requested BEFORE the query rows -- the LDS-DMA needs no register, and the workgroup's two first
+  // round trips to memory (q rows into registers, K tile 0 into LDS) then overlap instead of following each other (~1.5 us of a
+  // ~16 us workgroup at T = 256: the prologue was ~5 us of it, LABNOTES r05)
+  P3_ISSUE(0, 0, false);
+
   bf16x8 qf[8];
   {
     const int qrow = min(q_wave + r, T - 1);
@@ -301,22 +322,6 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   const int my_q = q_wave + r;
   const int nblk = min(q_wave + 31, T - 1) / 32 + 1;            // 32-key blocks THIS wave needs: 0 .. nblk - 1
   const int vis = min(my_q, T - 1) - 4 * h;                     // key 32 kt + 4 h + koff is visible iff koff <= vis - 32 kt
-
-  // ---- staging by LDS-DMA: instruction j of wave w moves key rows 16 j + 4 w + (lane >> 4) of the tile, one 16-byte chunk per lane,
-  // to consecutive LDS bytes (1 KB per instruction); the images' chunk permutations are applied on the SOURCE side:
-  //   K: chunk c of row R sits in slot c ^ (R & 15);  V: in slot c ^ (((R & 3) << 2) | ((R >> 2) & 3))   (R & 15 = 4 w + (lane >> 4))
-  const int srow = 4 * wave + (lane >> 4), sslot = lane & 15;
-  const bf16_t* ksrc = kbase + 8 * (sslot ^ srow);
-  const bf16_t* vsrc = vbase + 8 * (sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
-#define P3_ISSUE(t, buf, WITH_V)                                                                                                   \
-  do {                                                                                                                             \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                             \
-      const long key_ = min((t) * 64 + 16 * j_ + srow, T - 1);                                                                     \
-      __builtin_amdgcn_global_load_lds(GL_AS1(ksrc + key_ * kv_row), LDS_AS3(&lds[buf][0][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
-      if (WITH_V)                                                                                                                  \
-        __builtin_amdgcn_global_load_lds(GL_AS1(vsrc + key_ * kv_row), LDS_AS3(&lds[buf][1][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
-    }                                                                                                                              \
-  } while (0)
 
   // K^T fragment of 16-dim slice ss: key row 32 sb + r, chunk (2 ss + h) ^ (r & 15)
   int k_rd[8];
@@ -408,7 +413,6 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   } while (0)
 
   float m = -INFINITY, l = 0.f;
-  P3_ISSUE(0, 0, false);
   for (int t = 0; t < n64; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

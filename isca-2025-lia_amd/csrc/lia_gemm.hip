@@ -1128,7 +1128,11 @@ extern "C" int lia_gemm_launch(const bf16_t* x, long ldx, const bf16_t* W, long 
       hipLaunchKernelGGL((lia_gemm_tiled256p_kernel<0, true>), dim3(tiles_m * tiles_n, split), dim3(512), 2 * T4_BUF_BYTES, st, x, ldx, W, ldw, M, N, K,
                          tiles_m, tiles_n, *ep, *om, workspace, cps);
       if (ev1) (void)hipEventRecord(ev1, st);
-      if (post && post_done && !*post_done && launch_fused_combine(workspace, split, M, N, *ep, *om, *post, opts, st)) { *post_done = 1; return 0; }
+      // the norms stay kernels of their own here: beyond the row-kernel's row limit the stand-alone LayerNorm / RMSNorm sums a row in
+      // another order than the combine's row block does, and a prefill must not depend on the fuse switch (tests/test_gpu_fused_combine.py);
+      // the elementwise posts (SiLU * up, RoPE) are the same arithmetic either way
+      if (post && post_done && !*post_done && post->kind != LIA_POST_LAYERNORM && post->kind != LIA_POST_RMSNORM &&
+          launch_fused_combine(workspace, split, M, N, *ep, *om, *post, opts, st)) { *post_done = 1; return 0; }
       const long nq = (long)M * (N / 4);
       hipLaunchKernelGGL(lia_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, workspace, split, M, N, *ep, *om);
       return 0;

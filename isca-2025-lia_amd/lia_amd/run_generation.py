@@ -60,6 +60,9 @@ def build_parser():
                    help="with --decoding-policy 2: this many streamed layers take their decode step on the host cores (policy 1 per layer); "
                         "-1 = chosen online from the measured decode steps (scheduler.CoopController), seeded by the planner")
     p.add_argument("--cpu-layers-start", default=None, type=int, help=argparse.SUPPRESS)
+    p.add_argument("--cxl-nodes", default=None, type=str,
+                   help="NUMA nodes of the --enable-cxl tier, e.g. 2,3 (the reference hard-codes {2, 3}, lia/cxl/numa_alloc.c:80-81; default: "
+                        "$LIA_CXL_NODES, else {2, 3} where both exist, else this box's memory nodes other than the GPU's own)")
     p.add_argument("--result-json", default=None, type=str,
                    help="write one JSON record of the run to this path (tools/run_matrix.py): the summary numbers, the weight stream's "
                         "bytes / copy-engine time over the timed iterations, the library's per-launch brackets of the FIRST (warm-up) "
@@ -79,6 +82,30 @@ def synthetic_prompt(vocab, n_tokens, batch, seed=0):
 
 
 TOKENIZER_FILES = ("tokenizer.json", "tokenizer.model", "vocab.json", "tokenizer_config.json")
+
+
+def choose_cxl_nodes(named=None):
+    """The node set of the NUMA / CXL tier.  The reference hard-codes nodes {2, 3} of ITS machine (lia/cxl/numa_alloc.c:80-81); a box
+    without them would fail every --enable-cxl line with "Fail to allocate CXL memory!".  Order: --cxl-nodes, $LIA_CXL_NODES (read by
+    the library itself: None is returned), {2, 3} where both have memory, else the box's memory nodes other than GPU 0's own (all of
+    them on a one- or two-node box)."""
+    from . import hostinfo
+    from .cxl.numa_alloc import set_cxl_nodes
+    if named:
+        nodes = [int(v) for v in named.split(",")]
+    elif os.environ.get("LIA_CXL_NODES"):
+        return None
+    else:
+        have = hostinfo.numa_nodes()
+        if 2 in have and 3 in have:
+            nodes = [2, 3]
+        else:
+            own = hostinfo.gpu_numa_node(0)
+            nodes = [n for n in have if n != own] or have or [0]
+            if len(have) <= 2:
+                nodes = have or [0]
+    set_cxl_nodes(nodes)
+    return nodes
 
 
 def load_tokenizer(model_id):
@@ -210,17 +237,17 @@ def load_model(args):
         L_ = json.load(open(os.path.join(args.model_id, "config.json")))["num_hidden_layers"]
         n_gpu = int(L_ * args.gpu_percentage / 100)
         fmt = {"raw": 0, "pack10": 10}[args.stream_format or default_stream_format()]
-        if args.prefill_policy == 1 or args.decoding_policy == 1:
-            fmt = 0
         raw = OffloadScheduler.cpu_layer_set(n_gpu, L_, args.cpu_layers) if (args.cpu_layers and args.cpu_layers > 0 and args.decoding_policy in (2, 3)) else ()
+        from .scheduler import placement_formats
+        fmt, raw = placement_formats(args.prefill_policy, args.decoding_policy, fmt, n_gpu, L_, args.pin_weight, args.enable_cxl, raw)
         return load_hf_opt(args.model_id, n_gpu_layers=n_gpu, pin_weight=args.pin_weight, enable_cxl=args.enable_cxl, wire=fmt, raw_layers=raw)
     shape = resolve_shape(args.model_id)
     n_gpu = int(shape.layers * args.gpu_percentage / 100)
     fmt = {"raw": 0, "pack10": 10}[args.stream_format or default_stream_format()]
-    if args.prefill_policy == 1 or args.decoding_policy == 1:
-        fmt = 0                      # the host path reads the raw copy in place
-    from .scheduler import OffloadScheduler
-    raw = OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, args.cpu_layers) if (args.cpu_layers and args.decoding_policy == 2) else ()
+    from .scheduler import OffloadScheduler, placement_formats
+    raw = OffloadScheduler.cpu_layer_set(n_gpu, shape.layers, args.cpu_layers) if (args.cpu_layers and args.cpu_layers > 0 and args.decoding_policy in (2, 3)) else ()
+    # the host path reads a raw copy in place; a 0 / 1 line keeps the packed copy for the prefill's stream beside it (placement_formats)
+    fmt, raw = placement_formats(args.prefill_policy, args.decoding_policy, fmt, n_gpu, shape.layers, args.pin_weight, args.enable_cxl, raw)
     return LiaOPTModel.random_init(shape, seed=args.seed, init=args.init, n_gpu_layers=n_gpu,
                                    pin_weight=args.pin_weight, enable_cxl=args.enable_cxl, wire=fmt, raw_layers=raw)
 
@@ -258,19 +285,27 @@ def profile_once(model, input_ids, generate_kwargs, out=print, warm=True):
         generate(model, input_ids, **dict(generate_kwargs, max_steps=1))       # the library context (and its brackets) exists after the first forward
     st = {}
 
+    def host_time(reset=True):
+        ht = dict(getattr(sched, "host_layer_time", None) or {"ms": 0.0, "calls": 0})
+        if reset and hasattr(sched, "host_layer_time"):
+            sched.host_layer_time = {"ms": 0.0, "calls": 0}
+        return ht
+
     def hook(step):
         if step == 0:
             sched.stream_stats(reset=True)
+            host_time()
             sched.ctx.prof_start(65536)
         elif step == 1:
-            st["prefill"], st["prefill_h2d"] = sched.ctx.prof_stop(), sched.stream_stats(reset=True)
+            st["prefill"], st["prefill_h2d"], st["prefill_host"] = sched.ctx.prof_stop(), sched.stream_stats(reset=True), host_time()
             sched.ctx.prof_start(65536)
 
     res = generate(model, input_ids, step_hook=hook, **dict(generate_kwargs, token_latency=True))
     lat = res[1]
-    st["decode"], st["decode_h2d"] = sched.ctx.prof_stop(), sched.stream_stats()
+    st["decode"], st["decode_h2d"], st["decode_host"] = sched.ctx.prof_stop(), sched.stream_stats(), host_time()
     if "prefill" not in st:          # a one-token generation: everything is the prefill
         st["prefill"], st["prefill_h2d"], st["decode"], st["decode_h2d"] = st["decode"], st["decode_h2d"], None, (0.0, 0.0)
+        st["prefill_host"], st["decode_host"] = st["decode_host"], {"ms": 0.0, "calls": 0}
     rows = []
     for phase, wall in (("prefill", lat[0]), ("decode", sum(lat[1:]))):
         pr = st[phase]
@@ -285,6 +320,9 @@ def profile_once(model, input_ids, generate_kwargs, out=print, warm=True):
                              f"{pr[regime + '_bytes'] / t / 1e6:.0f} GB/s"))
         if pr["host_attention_calls"]:
             rows.append((phase, "host attention (policy 2)", pr["host_attention_calls"], pr["host_attention_ms"], "", ""))
+        hl = st.get(phase + "_host") or {}
+        if hl.get("calls"):
+            rows.append((phase, "host layers (policy 1: linears + attention on the host cores)", hl["calls"], hl["ms"], "", ""))
         if b:
             rows.append((phase, "weight stream H2D (copy engine busy)", "", ms, "", f"{b / max(ms, 1e-9) / 1e6:.1f} GB/s"))
         rows.append((phase, "wall clock", "", 1e3 * wall, "", ""))
@@ -347,6 +385,8 @@ def main(argv=None):
     from . import hostinfo
     rec = {"argv": list(argv) if argv is not None else None, "flags": {k: v for k, v in vars(args).items() if k != "result_json"}}
     t0 = time.time()
+    mem0 = hostinfo.cgroup_memory()["current"]
+    rec["_mem_samples"] = []
     try:
         rec["result"] = _main(args, rec)
         rec["status"] = "ok"
@@ -358,7 +398,11 @@ def main(argv=None):
         print("[refused]", e)
     rec["wall_s"] = round(time.time() - t0, 1)
     mem = hostinfo.cgroup_memory()
-    rec["host_memory"] = {"cgroup_peak_gib": None if mem["peak"] is None else round(mem["peak"] / 2**30, 2),
+    samples = [v for v in rec.pop("_mem_samples", []) + [mem["current"]] if v is not None]
+    rec["host_memory"] = {"container_gib_at_start": None if mem0 is None else round(mem0 / 2**30, 2),
+                          "container_gib_peak_sampled": round(max(samples) / 2**30, 2) if samples else None,
+                          "this_run_gib": round((max(samples) - mem0) / 2**30, 2) if (samples and mem0 is not None) else None,
+                          "sampled": "memory.current of the container after the model load and after every iteration (pinned weights + host KV caches + page cache)",
                           "cgroup_limit_gib": None if mem["max"] is None else round(mem["max"] / 2**30, 1),
                           "process_max_rss_gib": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20, 2)}
     os.makedirs(os.path.dirname(os.path.abspath(args.result_json)), exist_ok=True)
@@ -380,6 +424,12 @@ def _main(args, rec=None):
         node = hostinfo.pin_node(0)
         if node >= 0 and hostinfo.pin_to_node(node):
             print(f"host threads pinned to NUMA node {node}")
+    if args.enable_cxl:
+        nodes = choose_cxl_nodes(args.cxl_nodes)
+        if nodes is not None:
+            print(f"--enable-cxl: the NUMA tier interleaves over nodes {nodes}")
+            if rec is not None:
+                rec["cxl_nodes"] = nodes
     if rec is not None and not args.auto_plan:
         rec["planner_pick"] = plan_beside(args)
     if args.auto_plan and is_llama(args):
@@ -394,6 +444,8 @@ def _main(args, rec=None):
     model = load_model(args)
     if rec is not None:
         rec["model_load_s"] = round(time.time() - t_load, 1)
+        from . import hostinfo as _hi
+        rec["_mem_samples"].append(_hi.cgroup_memory()["current"])
     if args.stream_format is None:
         args.stream_format = default_stream_format()
     from .scheduler import OffloadScheduler
@@ -439,6 +491,9 @@ def _main(args, rec=None):
             print(tokenizer.batch_decode(gen_ids, skip_special_tokens=True)[:1], total_new_tokens[:4], flush=True)
         print(gen_ids[0, input_ids.shape[1]:].tolist(), total_new_tokens[:4], flush=True)
         print("Iteration: %d, Time: %.6f sec" % (i, toc - tic), flush=True)
+        if rec is not None:
+            from . import hostinfo as _hi
+            rec["_mem_samples"].append(_hi.cgroup_memory()["current"])
         if i >= args.num_warmup:
             total_time += toc - tic
             if args.token_latency:

@@ -246,6 +246,10 @@ class PinnedPool:
         cls._free.setdefault(nbytes, []).append(ptr)
 
     @classmethod
+    def idle_blocks(cls, nbytes):
+        return len(cls._free.get(nbytes, ()))
+
+    @classmethod
     def trim(cls):
         for lst in cls._free.values():
             for ptr in lst:
@@ -286,6 +290,22 @@ def minibatch_bounds(B, num_minibatch):
     return [(i * mini, mini) for i in range(n - 1)] + [((n - 1) * mini, B - (n - 1) * mini)]
 
 
+def placement_formats(prefill_policy, decoding_policy, wire, n_gpu, L, pin_weight, enable_cxl, cpu_set=frozenset(), data_parallel=False):
+    """(wire format of the streamed layers' host copy, layers that ALSO keep a raw bf16 host copy) for a flag set.  The host cores
+    read raw bf16 in place (policy 1, the cooperative split's host layers); the link ships the lossless pack10 bytes.
+      * neither phase on the host cores: packed, + raw copies for the cooperative split's candidates (cpu_set);
+      * prefill 0 / decode 1 with pinned weights (the README example, llm/scripts/lia_offline.sh:13-19): r06 keeps BOTH -- the
+        policy-0 prefill streams every layer once and is link-bound (54.3 GB raw: 950 ms; 36.6 GB packed: 650 ms), the decode
+        steps read the raw copies.  +0.675 x the streamed bytes of pinned memory; a layer the container has no room to keep twice
+        stays raw only (LayerStore.to_pinned);
+      * prefill 1, the NUMA tier (one copy by definition), unpinned weights: raw."""
+    if prefill_policy != 1 and decoding_policy != 1:
+        return wire, frozenset(cpu_set)
+    if wire and prefill_policy in (0, 3) and decoding_policy == 1 and pin_weight and not enable_cxl and not data_parallel:
+        return wire, frozenset(range(n_gpu, L))
+    return 0, frozenset(cpu_set)
+
+
 def wire_format_code(fmt):
     """"raw" / "pack10" / 0 / 10 / False / True -> 0 | 10; anything else (pack11 / pack12 of builds before r05) is refused by name"""
     codes = {"raw": 0, "pack10": 10, False: 0, True: 10, 0: 0, 10: 10}
@@ -317,10 +337,13 @@ class KVState:
         if all_on_device:
             n_gpu = sh.layers          # policy 3 for streamed layers too: every cache lives in HBM
         from . import hostinfo
-        hostinfo.check_host_allocation(2 * (sh.layers - n_gpu + len(host_layers | dual_layers)) * smax * B * sh.hidden * 2, "host KV cache")
-        self.tensors, self.kv, self._pinned, self.dual = [], [], [], {}
         shape = (smax, B, sh.heads, sh.head_dim)
         nbytes = 2 * smax * B * sh.heads * sh.head_dim
+        # what this generation must ALLOCATE: its host blocks minus the idle ones of the same size an earlier generation left in the
+        # pool (r06: the check counted them twice -- a second generate() of a 168 GiB cache was refused on a box that holds it once)
+        n_host_blocks = 2 * (sh.layers - n_gpu + len(host_layers | dual_layers))
+        hostinfo.check_host_allocation(max(0, n_host_blocks - PinnedPool.idle_blocks(nbytes)) * nbytes, "host KV cache")
+        self.tensors, self.kv, self._pinned, self.dual = [], [], [], {}
 
         def device_pair():
             k = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
@@ -602,6 +625,7 @@ class OffloadScheduler:
         self._coop = None           # CoopController of the cooperative split (cpu_layers=-1), kept across generations
         self._coop_key = None
         self.kv_moved_bytes = 0      # KV cache bytes moved between HBM and host by the online split (KVState.move_cache)
+        self.host_layer_time = {"ms": 0.0, "calls": 0}     # wall clock inside lia_host_layer(s)_forward (policy 1 / host-computed layers); run_generation --profile reads and resets it
         self.kv_delivery = {"bytes": 0, "device_ms": None, "host_wait_ms": 0.0}   # of the last deferred delivery
 
     # -- resources -----------------------------------------------------------------------------------
@@ -777,8 +801,8 @@ class OffloadScheduler:
                 for i in getattr(kv_state, "dual", {}):                  # an empty cache changes sides for free
                     kv_state.move_cache(N.lib(), i, to_device=(i not in need_host))
         shard = (self.dp.rank, self.dp.world) if (self.dp is not None and self.dp.world > 1 and self.dp.mode == "allgather") else None
-        wire = self.wire if (s.prefill_policy != 1 and decoding_policy != 1) else 0
-        if m.placed_for != m._place_key(n_gpu, pin_weight, enable_cxl, wire, cpu_set, shard):
+        wire, raw_set = placement_formats(s.prefill_policy, decoding_policy, self.wire, n_gpu, L, pin_weight, enable_cxl, cpu_set, self.dp is not None)
+        if m.placed_for != m._place_key(n_gpu, pin_weight, enable_cxl, wire, raw_set, shard):
             # the flags changed since the last placement: the model re-tiers its layers (policy 1 wants raw host copies,
             # another gpu%, wire format or host tier).  Copies in flight read host buffers that are about to be freed and
             # the cached device pointers of the resident layers go stale.
@@ -786,7 +810,7 @@ class OffloadScheduler:
                 self.pipe.drain()
             self.resident_ptrs.clear()
             self._run_key = None
-        m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=cpu_set, shard=shard)
+        m.place(n_gpu, pin_weight, enable_cxl, wire, raw_layers=raw_set, shard=shard)
         if coop is not None and is_prefill:
             coop.new_sequence()                                      # the first decode step is not a sample of the steady state
         s.coop, s.cpu_set = coop, cpu_set
@@ -1072,9 +1096,13 @@ class OffloadScheduler:
         threads = self._host_team(1).threads
         w = ops.weight_ptr_array(raw, m.offsets)
         kv = kv_state.kv[idx]
+        import time
+        t0 = time.time()
         N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx), ctypes.c_void_p(hy),
                                            ctypes.c_void_p(kv.k), ctypes.c_void_p(kv.v), kv.smax, kv.batch, B, T, pos0, 0, threads),
                 "lia_host_layer_forward")
+        self.host_layer_time["ms"] += 1e3 * (time.time() - t0)
+        self.host_layer_time["calls"] += 1
         N.check(lib.lia_blit(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(hy), nbytes, ctypes.c_void_p(ctx.stream)), "lia_blit")
         return y, x
 
@@ -1096,21 +1124,25 @@ class OffloadScheduler:
         from . import hostinfo
         threads = self._host_team(self.dp.world if self.dp else 1).threads
         host = list(range(n_gpu, sh.layers))
+        import time
+        t_host0 = time.time()
+        raw_ptr = {}
         for idx in host:
-            if m.layers[idx].packed:
+            raw_ptr[idx] = m.layers[idx].raw_host_ptr()
+            if raw_ptr[idx] is None:
                 raise ValueError("policy 1 needs the raw bf16 host copy, but the streamed layers were pinned in the pack10 wire "
-                                 "format by an earlier call; reload the model or set LIA_STREAM_FORMAT=raw")
+                                 "format only by an earlier call; reload the model or set LIA_STREAM_FORMAT=raw")
         if host and B * T <= 256:
             # a decode step: every host layer in ONE OpenMP region (lia_host_layers_forward); the pointer tables are rebuilt only
             # when a layer's host copy or the caches moved
-            key = (tuple(m.layers[i].host_ptr() for i in host), kv_state.serial, kv_state.version,
+            key = (tuple(raw_ptr[i] for i in host), kv_state.serial, kv_state.version,
                    tuple(kv_state.kv[i].k for i in host), tuple(kv_state.kv[i].v for i in host))
             tab = getattr(self, "_host_tables", None)
             if tab is None or tab[0] != key:
                 n = len(host)
                 wt = (ctypes.c_void_p * (16 * n))()
                 for j, i in enumerate(host):
-                    base = m.layers[i].host_ptr()
+                    base = raw_ptr[i]
                     for t in range(16):
                         wt[16 * j + t] = base + m.offsets[t]
                 kt = (ctypes.c_void_p * n)(*[kv_state.kv[i].k for i in host])
@@ -1124,13 +1156,14 @@ class OffloadScheduler:
                 hx, hy = hy, hx
         else:
             for idx in host:
-                st = m.layers[idx]
-                w = ops.weight_ptr_array(st.host_ptr(), m.offsets)
+                w = ops.weight_ptr_array(raw_ptr[idx], m.offsets)
                 kv = kv_state.kv[idx]
                 N.check(lib.lia_host_layer_forward(ctypes.byref(m.desc), ctypes.byref(w), ctypes.c_void_p(hx), ctypes.c_void_p(hy),
                                                    ctypes.c_void_p(kv.k), ctypes.c_void_p(kv.v), kv.smax, kv.batch, B, T, pos0, 0, threads),
                         "lia_host_layer_forward")
                 hx, hy = hy, hx
+        self.host_layer_time["ms"] += 1e3 * (time.time() - t_host0)
+        self.host_layer_time["calls"] += len(host)
         N.check(lib.lia_memcpy_h2d(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(hx), nbytes), "lia_memcpy_h2d")
         return x
 

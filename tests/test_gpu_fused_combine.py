@@ -197,9 +197,11 @@ def test_two_contexts_of_one_process_keep_their_own_switches():
 
 
 def test_phased_256_tiles_equal_the_128_tiles_bit_for_bit():
-    """the prefill GEMM's two tile shapes add the same products in the same order: M = 1024 rows in one call run the phased 256 x 256
-    kernel (lia_gemm_tiled256p_kernel), the same rows as two calls of 512 run the 128 x 128 kernel -- same bits; and both within
-    bf16 rounding of an fp32 reference"""
+    """the prefill GEMM's two tile shapes add the same products in the same order: M = 1024 rows x N = 1536 in one call run the phased
+    256 x 256 kernel (lia_gemm_tiled256p_kernel; split_k = 1: one K slice), the first 256 output columns computed on their own
+    (N = 256 < 512) run the 128 x 128 kernel -- same bits; both within bf16 rounding of an fp32 reference.  r06: with 24 tiles on 256
+    CUs the launcher's own choice splits K over fp32 slabs (lia_gemm_tiled256p_kernel<0, true> + the combine kernel): another
+    summation order, so >= 99.9 % of the outputs identical to the one-slice result and none further than one quantum."""
     import torch
     from lia_amd import ops
     M, N, K = 1024, 1536, 1024
@@ -208,14 +210,21 @@ def test_phased_256_tiles_equal_the_128_tiles_bit_for_bit():
     w = (0.03 * torch.randn((N, K), generator=g, device="cuda")).to(torch.bfloat16)
     bias = (0.1 * torch.randn((N,), generator=g, device="cuda")).to(torch.bfloat16)
     torch.cuda.synchronize()
-    ctx = ops.Context(0, 1 << 24)
+    ctx = ops.Context(0, 1 << 26)
     try:
-        y = ctx.linear(x, w, bias=bias, relu=True)
-        halves = [ctx.linear(x[i * 512:(i + 1) * 512].contiguous(), w, bias=bias, relu=True) for i in range(2)]
+        y = ctx.linear(x, w, bias=bias, relu=True, split_k=1)
+        small = ctx.linear(x, w[:256].contiguous(), bias=bias[:256].contiguous(), relu=True, split_k=1)
+        halves = [ctx.linear(x[i * 512:(i + 1) * 512].contiguous(), w, bias=bias, relu=True, split_k=1) for i in range(2)]
+        ysplit = ctx.linear(x, w, bias=bias, relu=True)                   # the launcher's own slice count
         ctx.synchronize()
         want = torch.relu((x.float() @ w.float().T + bias.float()).to(torch.bfloat16).float())
         assert float((y.float() - want).abs().max()) <= 0.02 * float(want.abs().max())
-        got, ref = to_bits(y), np.concatenate([to_bits(h) for h in halves], 0)
-        assert (got == ref).all(), f"{(got != ref).sum()} of {ref.size} values differ between the 256^2 and the 128^2 tiles"
+        got = to_bits(y)
+        assert (got[:, :256] == to_bits(small)).all(), "the 256^2 and the 128^2 tiles differ"
+        assert (got == np.concatenate([to_bits(h) for h in halves], 0)).all(), "one call of 1024 rows and two of 512 differ"
+        gs = to_bits(ysplit)
+        err = (ysplit.float() - y.float()).abs()
+        q = 2.0 ** (np.floor(np.log2(float(want.abs().max()))) - 7)
+        assert float((gs == got).mean()) >= 0.999 and float(err.max()) <= q, (float((gs == got).mean()), float(err.max()), q)
     finally:
         ctx.close()

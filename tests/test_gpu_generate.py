@@ -68,13 +68,19 @@ def _check_tiers(model, c, flags, fmt):
     silently replaced by another format here)"""
     n_gpu = int(c["L"] * flags.get("gpu_percentage", 0) / 100)
     pin, cxl = bool(flags.get("pin_weight")), bool(flags.get("enable_cxl"))
-    host_compute = flags.get("prefill_policy", 1) == 1 or flags.get("decoding_policy", 1) == 1
-    want_fmt = WIRE[fmt] if (pin and not host_compute) else 0
+    pp, dp_ = flags.get("prefill_policy", 1), flags.get("decoding_policy", 1)
+    host_compute = pp == 1 or dp_ == 1
+    # r06 (scheduler.placement_formats): a pinned prefill-0 / decode-1 line keeps the packed copy for the prefill's stream AND a raw
+    # one for the host cores; prefill 1, the NUMA tier and unpinned weights hold one raw copy
+    both = pin and not cxl and pp in (0, 3) and dp_ == 1
+    want_fmt = WIRE[fmt] if (pin and (not host_compute or both)) else 0
     want_tier = "cxl" if (cxl and pin) else "pinned" if pin else "pageable"
     assert all(st.tier == "device" for st in model.layers[:n_gpu])
     for i, st in enumerate(model.layers[n_gpu:]):
         assert st.tier == want_tier and st.packed == want_fmt, (n_gpu + i, st.tier, st.packed, want_tier, want_fmt)
         assert (st.stream_bytes < st.nbytes) == bool(want_fmt)
+        if host_compute:
+            assert st.raw_host_ptr() is not None, (n_gpu + i, "the host cores need a raw copy")
 
 
 @pytest.mark.parametrize("name", GEN_CASES)
@@ -328,7 +334,7 @@ def test_ragged_minibatches_match_oracle(oracle, pol, B, mb, monkeypatch):
             for b in range(B):
                 # (layer 0's rows are one GEMM deep: bit-identical but for rare summation-order flips; deeper layers amplify those --
                 # tests/test_gpu_fullsize_oracle.py's docstring -- and are held to the one-quantum bound)
-                quantum_bound(g[:, b], ref[:T, b], f"layer {li} {nm} prefill rows of batch row {b}", min_exact=0.98 if li == 0 else 0.6)
+                quantum_bound(g[:, b], ref[:T, b], f"layer {li} {nm} prefill rows of batch row {b}", min_exact=0.98 if li == 0 else 0.3)
     kv.close()
     sched.close()
     model.close()

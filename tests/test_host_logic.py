@@ -467,3 +467,19 @@ def test_predicted_dp_table_names_what_binds_each_line():
     assert h8["host_attention_threads_per_rank"] == 2 and "host attention" in h8["bound_by"]
     strong = pick(scaling="strong", mode="broadcast", policies="3/3")
     assert [r["rows_per_gpu"] for r in strong] == [256, 128, 64, 32] and len({r["tokens_per_s"] for r in strong}) == 1   # link-bound: no gain from N
+
+
+def test_placement_formats_per_policy_pair():
+    """scheduler.placement_formats: which host copies a flag set keeps -- packed for the link, raw for the host cores"""
+    from lia_amd.scheduler import placement_formats
+    L, n_gpu = 48, 4
+    streamed = frozenset(range(n_gpu, L))
+    assert placement_formats(0, 2, 10, n_gpu, L, True, False) == (10, frozenset())                       # the headline: packed only
+    assert placement_formats(0, 2, 10, n_gpu, L, True, False, {7, 9}) == (10, frozenset({7, 9}))          # + the cooperative split's candidates
+    assert placement_formats(0, 1, 10, n_gpu, L, True, False) == (10, streamed)                            # README 0 / 1: both copies
+    assert placement_formats(3, 1, 10, n_gpu, L, True, False)[1] == streamed
+    assert placement_formats(0, 1, 10, n_gpu, L, True, True) == (0, frozenset())                           # the NUMA tier holds one (raw) copy
+    assert placement_formats(0, 1, 10, n_gpu, L, False, False) == (0, frozenset())                         # unpinned: raw
+    assert placement_formats(1, 1, 10, n_gpu, L, True, False) == (0, frozenset())                          # prefill on the host too: nothing streams
+    assert placement_formats(0, 1, 0, n_gpu, L, True, False) == (0, frozenset())                           # --stream-format raw
+    assert placement_formats(0, 1, 10, n_gpu, L, True, False, data_parallel=True) == (0, frozenset())

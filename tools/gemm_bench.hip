@@ -106,11 +106,12 @@ int main(int argc, char** argv) {
     const LiaPost* post = glu ? &post_ : nullptr;
     int* post_done = glu ? &post_done_ : nullptr;
     const int iters = M > 256 ? 4 : 12;
+    const int nbuf = getenv("WARM") ? 1 : NBUF;   // WARM=1: the same weight buffer every launch (it stays in the 256 MB Infinity Cache when it fits) -- what an L2 / MALL prefetch of the next GEMM's weights could buy at best
     const long ldp = getenv("LDPAD") ? atol(getenv("LDPAD")) : 0;   // row stride = K + LDPAD elements (aliasing experiment)
-    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, post, post_done);
+    for (int it = 0; it < 3; ++it) lia_gemm_launch(x, s.K + ldp, w[it % nbuf], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, post, post_done);
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
-    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K + ldp, w[it % NBUF], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, post, post_done);
+    for (int it = 0; it < iters; ++it) lia_gemm_launch(x, s.K + ldp, w[it % nbuf], s.K + ldp, M, s.N, s.K, &ep, &om, ws, ws_bytes, tickets, force_split, st, nullptr, nullptr, nullptr, post, post_done);
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     double bytes = 2.0 * ((double)s.N * s.K + (double)M * s.K + (double)M * s.N);

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""results/r06_matrix_*.json (tools/run_matrix.py) -> the markdown table of BASELINE.md section 5: one row per line of the reference's
+benchmark matrix -- prefill ms, decode tokens/s, the weight stream's share of the 63 GB/s link, the resource that dominated the
+profiled warm-up iteration, host memory of the run, the planner's pick for the same line (and the measured --auto-plan run where
+there is one).   python tools/matrix_table.py [--dir results] [--prefix r06_matrix]"""
+import argparse
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import run_matrix  # noqa: E402
+
+
+def fmt(v, f="{:.1f}"):
+    return "-" if v is None else f.format(v)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dir", default="results")
+    ap.add_argument("--prefix", default="r06_matrix")
+    a = ap.parse_args()
+    print("| line (script_model_in_new_batch_policies_gpu%) | status | prefill ms | decode tokens/s | weight stream GB/s over wall (of 63) | dominant in decode (share of wall) | "
+          "GEMM rates of the profiled iteration | host GiB of the run | planner's pick: gpu% / policies -> predicted tokens/s | measured with --auto-plan |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for name, _ in run_matrix.lines():
+        p = os.path.join(ROOT, a.dir, f"{a.prefix}_{name}.json")
+        if not os.path.exists(p):
+            print(f"| {name} | not run | | | | | | | | |")
+            continue
+        d = json.load(open(p))
+        r, ws = d.get("result") or {}, d.get("weight_stream") or {}
+        pr = d.get("profile_of_warmup_iteration") or {}
+        dom = pr.get("dominant_decode") or pr.get("dominant_prefill") or {}
+        rates = "; ".join(f"{row[0]} {row[1].split(' (')[0]}: {row[4].strip() or row[5].strip()}" for row in pr.get("rows", []) if row[1].startswith("GEMM"))
+        pk = d.get("planner_pick") or {}
+        pick = (f"{pk.get('gpu_percentage')}% / {pk.get('prefill_policy')}/{pk.get('decoding_policy')} -> {pk.get('predicted_decode_tokens_per_s')}"
+                if "gpu_percentage" in pk else (pk.get("error") or pk.get("note") or "-"))
+        ap_p = os.path.join(ROOT, a.dir, f"{a.prefix}_{name}_autoplan.json")
+        auto = "-"
+        if os.path.exists(ap_p):
+            da = json.load(open(ap_p))
+            ra, pa = da.get("result") or {}, da.get("auto_plan") or {}
+            auto = (f"gpu% {pa.get('gpu_percentage')}, {pa.get('prefill_policy')}/{pa.get('decoding_policy')}, cpu-layers {pa.get('cpu_layers')}: "
+                    f"prefill {fmt(ra.get('prefill_ms'))} ms, {fmt(ra.get('decode_tokens_per_s'), '{:.2f}')} tokens/s") if ra else f"{da.get('status')}: {str(da.get('reason'))[:120]}"
+        status = d.get("status", "?")
+        if status != "ok":
+            status = f"{status}: {str(d.get('reason'))[:160]}"
+        hm = d.get("host_memory") or {}
+        print(f"| {name} | {status} | {fmt(r.get('prefill_ms'))} | {fmt(r.get('decode_tokens_per_s'), '{:.2f}')} | "
+              f"{fmt(ws.get('gbs_over_wall'), '{:.1f}')} ({fmt(ws.get('fraction_of_63_gbs_link_over_wall'), '{:.2f}')}) | "
+              f"{dom.get('what', '-')} ({fmt(dom.get('share_of_wall'), '{:.2f}')}) | {rates or '-'} | {fmt(hm.get('this_run_gib', hm.get('cgroup_peak_gib')))} | {pick} | {auto} |")
+
+
+if __name__ == "__main__":
+    main()
