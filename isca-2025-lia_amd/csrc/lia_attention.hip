@@ -260,19 +260,43 @@ __device__ __forceinline__ uint32_t p3_prob2(f32x2 r, float m, float l, float rl
 template <int POST_SCALE>
 __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
                                                                   const bf16_t* __restrict__ vc, bf16_t* __restrict__ out, long ldo, int T,
-                                                                  int heads, int kv_heads, long kv_row, long kv_batch, int b0, float scaling) {
+                                                                  int heads, int kv_heads, long kv_row, long kv_batch, int b0, float scaling,
+                                                                  int nqb, int n_groups) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(16))) char lds[2][2][64 * 256];   // [buffer][0 = K, 1 = V][key row of 256 bytes]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  int bx = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+  // r06: XCD-aware order (n_groups > 0).  The workgroups that read the same K / V -- every query block of the G query heads of one
+  // (batch row, KV head) -- form a group of nqb * G members; group g runs on XCD g % 8 (workgroup ids are dealt round-robin over
+  // the XCDs: id % 8), its members in consecutive slots of that XCD.  A K / V tile is then fetched into ONE L2 and found there by
+  // the other members (and by the second sweep) instead of crossing the fabric once per XCD: the per-tile wait is an L2 hit, which
+  // the one-tile-deep LDS-DMA prefetch covers; a miss (2-3 us under load) it does not (a tile's arithmetic is ~1.2 us).
+  // OPT-30B T 2016: 1872 -> 1512 us per 8-row minibatch, bit-identical (tools/attn_prefill_bench, -DLIA_ATTN_LEGACY_GRID for r05's).
+  // n_groups <= 0: r05's order -- consecutive ids = the query blocks of one head -- kept for launches whose groups do not spread
+  // evenly over the 8 XCDs (the launcher decides).
+  int bx, hh, b;
+  if (n_groups > 0) {
+    const int Gq = heads / kv_heads;
+    const int nmem = nqb * Gq;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int grp = (slot / nmem) * 8 + (int)(blockIdx.x & 7);
+    if (grp >= n_groups) return;                      // (the grid is padded to a multiple of 8 groups)
+    const int mem = slot % nmem;
+    bx = mem % nqb;
+    b = grp / kv_heads;
+    hh = (grp % kv_heads) * Gq + mem / nqb;
+  } else {
+    bx = (int)(blockIdx.x % nqb);
+    hh = (int)((blockIdx.x / nqb) % heads);
+    b = (int)(blockIdx.x / ((unsigned)nqb * heads));
+  }
   // every other (batch row, head) takes its query blocks -- and, below, the four row blocks of a workgroup -- in reverse order:
-  // consecutive workgroup ids go to consecutive XCDs and wave w of a workgroup to SIMD w, and late rows have more keys to visit, so
-  // without it XCD 7 / SIMD 3 would get every heavy piece and XCD 0 / SIMD 0 every light one
+  // wave w of a workgroup goes to SIMD w, and late rows have more keys to visit, so without it SIMD 3 would get every heavy piece
+  // and SIMD 0 every light one (with r05's grid: XCD 7 / XCD 0 as well)
   const int rev = (hh + b) & 1;
-  if (rev) bx = gridDim.x - 1 - bx;
+  if (rev) bx = nqb - 1 - bx;
   const int q_wg = bx * 128;
   const int wsub = rev ? 3 - wave : wave;
   const int q_wave = q_wg + wsub * 32;
@@ -741,8 +765,19 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
     case 128: {
       const long hd = (long)kv_heads * 128;
       // (a token-major [B][T][h][d] K/V -- strides (hd, T hd) -- was measured: same time, so the cache layout stays)
-      if (post_scale) hipLaunchKernelGGL(lia_attn_prefill128_kernel<1>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling);
-      else hipLaunchKernelGGL(lia_attn_prefill128_kernel<0>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling);
+      const int nqb = (T + 127) / 128;
+      int n_groups = B * kv_heads;
+      // the XCD-aware order when the groups spread evenly over the 8 XCDs (a multiple of 8, or so many that the remainder does not
+      // matter); otherwise r05's order, which deals single workgroups round-robin (2 rows x 2 KV heads would use 4 XCDs of 8)
+      bool xcd_order = (n_groups % 8 == 0) || n_groups >= 64;
+#ifdef LIA_ATTN_LEGACY_GRID
+      xcd_order = false;
+#endif
+      const unsigned nwg = xcd_order ? (unsigned)(((n_groups + 7) / 8) * 8 * nqb * (heads / kv_heads)) : (unsigned)(nqb * heads * B);
+      if (!xcd_order) n_groups = 0;
+      const dim3 grid128(nwg);
+      if (post_scale) hipLaunchKernelGGL(lia_attn_prefill128_kernel<1>, grid128, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, nqb, n_groups);
+      else hipLaunchKernelGGL(lia_attn_prefill128_kernel<0>, grid128, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, (long)Bc * hd, hd, b0, scaling, nqb, n_groups);
       break;
     }
     case 64: hipLaunchKernelGGL(lia_attn_prefill_kernel<64>, grid, dim3(256), 0, st, q, ldq, kc, vc, out, ldo, T, heads, kv_heads, Bc, b0, scaling, post_scale); break;

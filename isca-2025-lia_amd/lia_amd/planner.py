@@ -159,6 +159,16 @@ def layer_bytes(shape):
     return shape.layer_param_bytes()
 
 
+def decode_gemm_ms(shape, B, box):
+    """the four linears of one decode step of one layer: weight-read-bound up to M = 256 (the skinny kernels), MFMA-bound beyond
+    (r06: the tiled kernel at 256 < M < 1024 does ~0.65 of the large-M rate, tools/gemm_bench -- M = 900: 0.9 of 1.45 PFLOP/s)"""
+    lb = layer_bytes(shape)
+    bw_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
+    if B <= 256:
+        return bw_ms
+    return max(bw_ms, 1e3 * 2.0 * B * (lb / 2) / (0.65 * box.mfma_tflops * 1e12))
+
+
 def estimate(shape, B, T, new, gpu_percentage, decoding_policy, box=None, kv_in_hbm=None):
     """Predicted prefill ms / decode ms per step of one configuration (prefill policy 0 on streamed layers)."""
     box = box or Box()
@@ -171,7 +181,7 @@ def estimate(shape, B, T, new, gpu_percentage, decoding_policy, box=None, kv_in_
     kv_in_hbm = (decoding_policy == 3) if kv_in_hbm is None else kv_in_hbm
     copy_ms = 1e3 * lb * box.wire_ratio / (box.link_gbs * 1e9)   # bytes shipped per layer in the box's wire format
     # decode
-    gemm_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
+    gemm_ms = decode_gemm_ms(shape, B, box)
     attn_gpu_ms = 1e3 * (2 * (T + new // 2) * B * H * 2) / (box.attn_gbs * 1e9)
     attn_host_ms = 1e3 * (2 * (T + new // 2) * B * H * 2) / (min(box.host_threads * box.host_gbs_per_thread, box.host_gbs_cap) * 1e9)
     resident_ms = gemm_ms + attn_gpu_ms
@@ -188,7 +198,15 @@ def estimate(shape, B, T, new, gpu_percentage, decoding_policy, box=None, kv_in_
     if n_str and n_gpu:
         prefill_ms += max(0.0, (n_gpu + 1) * pre_layer_ms - 2 * copy_ms)      # head bubble with two slots
     emb_gb = 2 * shape.vocab * H * 2 / 1e9
-    hbm = n_gpu * lb / 1e9 + emb_gb + 2 * lb / 1e9 + (L if kv_in_hbm else n_gpu) * kv_layer / 1e9 + 3.5
+    # HBM beside the resident layers and the caches: four streamer slots + their wire-format staging areas, the context's workspace
+    # for the prefill's B x T rows (lia_api.hip ws_layout: 6 row buffers of H, one of F, two K/V slabs of 2 H), the two hidden-state
+    # buffers, lm_head's logits.  (r06: the estimate carried two slots and a constant; at --batch-size 900 the planner's pick ran
+    # out of HBM in lia_ctx_create -- results/r06_matrix_offline_opt30b_32_256_b900_p02_g0_autoplan.json of the first attempt)
+    rows = B * T
+    ws_gb = (rows * (10 * H + F) * 2 + 8 * min(rows, 256) * max(3 * H, F) * 4) / 1e9
+    stream_gb = 4 * lb * (1.0 + (box.wire_ratio if box.wire_ratio < 1.0 else 0.0)) / 1e9 if n_str else 0.0
+    hbm = (n_gpu * lb / 1e9 + emb_gb + stream_gb + (L if kv_in_hbm else n_gpu) * kv_layer / 1e9 + ws_gb + 2 * rows * H * 2 / 1e9 +
+           B * shape.vocab * 6 / 1e9 + 3.5)
     host = n_str * lb / 1e9 + (0 if kv_in_hbm else n_str * kv_layer / 1e9)
     return prefill_ms, decode_ms, hbm, host, n_gpu
 
@@ -207,7 +225,7 @@ def plan_cpu_layers(shape, B, T, new, gpu_percentage, box=None, kv_in_hbm=False)
     n_str = L - n_gpu
     lb = layer_bytes(shape)
     copy_ms = 1e3 * lb * box.wire_ratio / (box.link_gbs * 1e9)
-    gemm_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
+    gemm_ms = decode_gemm_ms(shape, B, box)
     kv_read = 2 * (T + new // 2) * B * H * 2
     attn_gpu_ms = 1e3 * kv_read / (box.attn_gbs * 1e9)
     attn_host_ms = 1e3 * kv_read / (min(box.host_threads * box.host_gbs_per_thread, box.host_gbs_cap) * box.host_attn_beside_stream * 1e9)
@@ -232,7 +250,7 @@ def plan(shape, B, T, new, box=None, objective="decode", max_gpu_percentage=100)
             continue
         for pol in (2, 3):
             pre, dec, hbm, host, n_gpu = estimate(shape, B, T, new, pct, pol, box)
-            if hbm > 0.92 * box.hbm_gb or host > 0.85 * box.host_mem_gb:
+            if hbm > 0.90 * box.hbm_gb or host > 0.85 * box.host_mem_gb:
                 continue
             score = dec if objective == "decode" else pre + new * dec
             if best is None or score < best[0] - 1e-9:
@@ -270,7 +288,7 @@ def predict_dp(shape, rows_per_rank, T, new, gpu_percentage, world, mode="broadc
     lb = layer_bytes(shape)
     wire = lb * box.wire_ratio
     kv_read = 2 * (T + new // 2) * rows_per_rank * H * 2
-    gemm_ms = 1e3 * lb / (box.hbm_gbs * 1e9)
+    gemm_ms = decode_gemm_ms(shape, rows_per_rank, box)
     attn_gpu_ms = 1e3 * kv_read / (box.attn_gbs * 1e9)
     threads = max(1, host_cpus // world)
     attn_host_ms = 1e3 * kv_read / (min(threads * box.host_gbs_per_thread, box.host_gbs_cap) * box.host_attn_beside_stream * 1e9)

@@ -644,6 +644,9 @@ class OffloadScheduler:
             if self.ctx is not None:
                 self._await_all_deliveries()      # their tickets die with the context
                 self.ctx.close()
+            # (the library allocates with hipMalloc: blocks torch's caching allocator keeps from the model's placement -- the drawn
+            # layers, the wire encoder's buffers -- are handed back first; at batch 1050 the planner's pick ran out of HBM here)
+            torch.cuda.empty_cache()
             self.ctx = ops.Context(self.device, need)
             # the policy-2 host attention team: usable CPUs (affinity mask AND cgroup quota) split over the ranks, never
             # omp_get_max_threads() -- a team larger than the quota stalls every layer's round trip (hostinfo.py)
@@ -653,6 +656,7 @@ class OffloadScheduler:
             self.ctx.set_host_threads(self.host_threads)
             hostinfo.cap_torch_threads(self.host_threads)     # torch's own CPU ops of the token loop obey the same bound
         if self.pipe is None and n_gpu < sh.layers:
+            torch.cuda.empty_cache()
             self.pipe = WeightPipeline(self.ctx, self.model, self.n_slots, self.dp)
         key = (B, T)
         if key not in self.hidden:

@@ -108,7 +108,10 @@ def test_linear_no_bias_and_errors(gpu, oracle):
 
 
 @pytest.mark.parametrize("B,T,heads,d", [(2, 8, 4, 32), (1, 17, 4, 64), (3, 40, 2, 128), (2, 256, 2, 128), (1, 300, 3, 64),
-                                         (2, 129, 2, 32)])
+                                         (2, 129, 2, 32),
+                                         # r06, d = 128: B x heads a multiple of 8 (or >= 64) takes the XCD-aware workgroup order, the
+                                         # others r05's; a padded grid (65 groups -> 72), ragged T on both
+                                         (4, 300, 2, 128), (8, 129, 1, 128), (1, 200, 8, 128), (13, 70, 5, 128)])
 def test_attention_prefill(gpu, oracle, B, T, heads, d):
     ctx, ops, torch = gpu
     H = heads * d

@@ -13,11 +13,12 @@ int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipFuncSetAttribute((const void*)lia_attn_prefill128_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   for (int extra : {0, 32 * 1024}) {       // 64 KB static + 32 KB dynamic = 96 KB: one workgroup per CU
-    dim3 grid((T + 127) / 128, heads, B);
+    const int nqb = (T + 127) / 128, n_groups = B * heads;
+    dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * nqb));          // r06: the XCD-aware 1-D grid of lia_attn_prefill_launch
     const long hd = (long)heads * 128;
     for (int it = 0; it < 22; ++it) {
       if (it == 2) CK(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(lia_attn_prefill128_kernel<0>, grid, dim3(256), extra, st, q, (long)H, k, v, o, (long)H, T, heads, heads, (long)B * hd, hd, 0, 0.0883883f);
+      hipLaunchKernelGGL(lia_attn_prefill128_kernel<0>, grid, dim3(256), extra, st, q, (long)H, k, v, o, (long)H, T, heads, heads, (long)B * hd, hd, 0, 0.0883883f, nqb, n_groups);
     }
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -66,6 +66,8 @@ int main(int argc, char** argv) {
   run_case("OPT-30B prefill", 64, 256, 56, 56, 0, reps);
   run_case("Llama-3-8B prefill (B/4)", 32, 1024, 32, 8, 1, reps);
   run_case("OPT-30B, 2 minibatches", 32, 256, 56, 56, 0, reps);
+  run_case("OPT-30B T 2016 (mb 8 of B 64)", 8, 2016, 56, 56, 0, reps > 5 ? 5 : reps);        // llm/scripts/lia_offline.sh:15: --input-tokens 2016 --num-minibatch 8
+  run_case("OPT-30B T 1792 B 1", 1, 1792, 56, 56, 0, reps > 5 ? 5 : reps);
   if (getenv("QUICK")) return 0;
   const int ts[] = {1, 2, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 255, 257, 300, 511, 513, 700, 1023, 2047, 2048};
   for (int t : ts) { run_case("ragged", 3, t, 5, 5, 0, 2); run_case("ragged gqa", 2, t, 8, 2, 1, 2); }

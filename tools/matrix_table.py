@@ -44,11 +44,16 @@ def main():
         if os.path.exists(ap_p):
             da = json.load(open(ap_p))
             ra, pa = da.get("result") or {}, da.get("auto_plan") or {}
-            auto = (f"gpu% {pa.get('gpu_percentage')}, {pa.get('prefill_policy')}/{pa.get('decoding_policy')}, cpu-layers {pa.get('cpu_layers')}: "
-                    f"prefill {fmt(ra.get('prefill_ms'))} ms, {fmt(ra.get('decode_tokens_per_s'), '{:.2f}')} tokens/s") if ra else f"{da.get('status')}: {str(da.get('reason'))[:120]}"
+            cl = pa.get("cpu_layers")
+            auto = (f"gpu% {pa.get('gpu_percentage')}, {pa.get('prefill_policy')}/{pa.get('decoding_policy')}" + (f", host layers online from {pa.get('cpu_layers_start')}" if cl == -1 else "") +
+                    f": prefill {fmt(ra.get('prefill_ms'))} ms, **{fmt(ra.get('decode_tokens_per_s'), '{:.2f}')}** tokens/s") if ra else f"{da.get('status')}: {str(da.get('reason'))[:120]}"
         status = d.get("status", "?")
         if status != "ok":
-            status = f"{status}: {str(d.get('reason'))[:160]}"
+            import re as _re
+            why = str(d.get("reason"))
+            m = _re.search(r"needs ([0-9.]+) GiB of host memory but only ([0-9.]+) GiB", why)
+            status = (f"refused: {why.split(':')[0]} needs {m.group(1)} GiB of host memory, {m.group(2)} GiB left in the 300 GiB container" if m
+                      else f"{status}: {why[:140]}")
         hm = d.get("host_memory") or {}
         print(f"| {name} | {status} | {fmt(r.get('prefill_ms'))} | {fmt(r.get('decode_tokens_per_s'), '{:.2f}')} | "
               f"{fmt(ws.get('gbs_over_wall'), '{:.1f}')} ({fmt(ws.get('fraction_of_63_gbs_link_over_wall'), '{:.2f}')}) | "
