@@ -58,3 +58,28 @@ def test_prompt_goes_through_the_checkpoint_directorys_tokenizer(tmp_path, capsy
         rg.prompt_input_ids(args, 8, t)                            # the model's embedding table is smaller than the tokenizer's ids
     plain = rg.build_parser().parse_args(["-m", str(d), "--batch-size", "2", "--input-tokens", "16"])
     assert plain.prompt is None and torch.equal(rg.prompt_input_ids(plain, 64, t), rg.synthetic_prompt(64, 16, 2))
+
+
+def test_matrix_lines_parse_through_the_harness_flag_surface():
+    """tools/run_matrix.py: 33 lines (README example + lia_offline.sh 8 + lia_online.sh 12 + cxl_offloading.sh 12), every one a flag
+    list the harness's own parser accepts; the two ragged ones (1150 / 3, 1 / 2) are there"""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_matrix", os.path.join(root, "tools", "run_matrix.py"))
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    sys.path.insert(0, os.path.join(root, "isca-2025-lia_amd"))
+    from lia_amd.run_generation import build_parser
+    lines = rm.lines()
+    assert len(lines) == 33 and len({n for n, _ in lines}) == 33
+    by = {n: build_parser().parse_args(f) for n, f in lines}
+    assert sum(n.startswith("offline_") for n in by) == 8 and sum(n.startswith("online_") for n in by) == 12 and sum(n.startswith("cxl_") for n in by) == 12
+    a = by["cxl_opt30b_32_128_b1150_p02_g0_cxl"]
+    assert (a.batch_size, a.num_minibatch, a.enable_cxl, a.pin_weight, a.prefill_policy, a.decoding_policy) == (1150, 3, True, True, 0, 2)
+    b = by["offline_opt175b_32_32_b1_p01_g9"]
+    assert (b.batch_size, b.num_minibatch, b.pin_weight, b.gpu_percentage, b.init, b.model_id) == (1, 2, False, 9, "uniform01", "opt-175b")
+    r = by["readme_opt30b_256_32_b64_p01_g10_cxl"]
+    assert (r.num_iter, r.num_warmup, r.input_tokens, r.max_new_tokens, r.gpu_percentage, r.num_minibatch) == (10, 2, "256", 32, 10, 2)
+    assert all(v.benchmark and v.token_latency and v.greedy and v.ipex and v.dtype == "bfloat16" for v in by.values())
