@@ -204,7 +204,7 @@ def estimate(shape, B, T, new, gpu_percentage, decoding_policy, box=None, kv_in_
     # out of HBM in lia_ctx_create -- results/r06_matrix_offline_opt30b_32_256_b900_p02_g0_autoplan.json of the first attempt)
     rows = B * T
     ws_gb = (rows * (10 * H + F) * 2 + 8 * min(rows, 256) * max(3 * H, F) * 4) / 1e9
-    stream_gb = 4 * lb * (1.0 + (box.wire_ratio if box.wire_ratio < 1.0 else 0.0)) / 1e9 if n_str else 0.0
+    stream_gb = 4 * lb * (1.0 + (1.13 if box.wire_ratio < 1.0 else 0.0)) / 1e9 if n_str else 0.0      # (staging = lia_pack10_bound: 1.13 x the raw layer)
     hbm = (n_gpu * lb / 1e9 + emb_gb + stream_gb + (L if kv_in_hbm else n_gpu) * kv_layer / 1e9 + ws_gb + 2 * rows * H * 2 / 1e9 +
            B * shape.vocab * 6 / 1e9 + 3.5)
     host = n_str * lb / 1e9 + (0 if kv_in_hbm else n_str * kv_layer / 1e9)

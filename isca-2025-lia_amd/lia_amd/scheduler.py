@@ -827,8 +827,11 @@ class OffloadScheduler:
             import time
             s.t_fwd0, s.busy0 = time.time(), (self.pipe.poll_stats()[1] if self.pipe else 0.0)
         rows = B * T if n_gpu > 0 else s.mini * T                  # resident layers take the whole batch
-        if s.policy == 0 and n_gpu < L:
-            rows = max(rows, s.mini * kv_state.smax)               # policy-0 decode parks the cached prefix in a slab
+        if s.decoding_policy == 0 and n_gpu < L:
+            # policy-0 DECODE parks the cached prefix in a slab.  (Until r06 the test was on the PHASE's policy, so every policy-0
+            # prefill sized the workspace for batch x max positions rows: 60 GB of HBM at batch 1050 x 288 positions, which is
+            # what ran the planner's batch-1050 pick out of memory; the reference's scripts never use decode policy 0.)
+            rows = max(rows, s.mini * kv_state.smax)
         s.x, s.y = self._ensure(rows, B, T, n_gpu)
         if is_prefill and s.policy == 0 and n_gpu < L and self.defer_kv and s.pos0 == 0:
             self._await_all_deliveries()          # (host-blocking: afterwards nothing on the D2H stream reads the holding caches)

@@ -403,9 +403,11 @@ def test_dummy_checkpoint_directory_streams_like_the_generator(tmp_path, wire):
                               gpu_percentage=25, pin_weight=True)
     assert [st.tier for st in model.layers] == ["device", "mapped", "mapped", "mapped"]      # streamed straight from the files
     assert torch.equal(out, ref) and all(torch.equal(a, b) for a, b in zip(logits, ref_logits))
-    # the mapped layers re-tier like any others: policy 1 wants raw host copies
+    # the mapped layers re-tier like any others: policy 1 wants raw host copies (r06: beside the packed one, which keeps serving the
+    # link-bound policy-0 prefill -- scheduler.placement_formats)
     out1 = generate(model, ids, max_new_tokens=2, min_new_tokens=2, prefill_policy=0, decoding_policy=1, gpu_percentage=25, pin_weight=True)
-    assert out1.shape == (4, 14) and all(st.packed == 0 for st in model.layers[1:])
+    assert out1.shape == (4, 14) and all(st.raw_host_ptr() is not None and st.tier == "pinned" for st in model.layers[1:])
+    assert all(st.packed == {"pack10": 10, "raw": 0}[wire] for st in model.layers[1:])
     model._lia_scheduler.close()
     model.close()
     ref_model.close()
