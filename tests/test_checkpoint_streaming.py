@@ -139,3 +139,50 @@ def test_llama_directory_detection(tmp_path):
     o.mkdir()
     json.dump(dict(model_type="opt", architectures=["OPTForCausalLM"]), open(o / "config.json", "w"))
     assert not checkpoint.is_llama_dir(str(o)) and not checkpoint.is_llama_dir(str(tmp_path / "nothing"))
+
+
+def test_llama_layer_of_a_hf_directory_lands_in_the_packed_layout(tmp_path):
+    """checkpoint.llama_layer_numpy + LiaLlamaModel._pack_numpy without a GPU: the nine tensors of a HF Llama layer (safetensors, two
+    shards) end up at lia_llama_pack_offsets' positions, gate.w / up.w interleaved in blocks of 32 rows (lia_llama_desc.gu_block)"""
+    import torch
+    from safetensors.torch import save_file
+    sys.path.insert(0, PKG)
+    from lia_amd import checkpoint
+    from lia_amd.llama import GU_BLOCK, LLAMA_TENSORS, LiaLlamaModel
+    H, heads, kvh, F, L, vocab = 256, 4, 2, 512, 2, 64
+    d = tmp_path / "tiny-llama"
+    d.mkdir()
+    json.dump(dict(architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=H, num_attention_heads=heads, num_key_value_heads=kvh,
+                   intermediate_size=F, num_hidden_layers=L, vocab_size=vocab, max_position_embeddings=64, rope_theta=10000.0), open(d / "config.json", "w"))
+    g = torch.Generator().manual_seed(3)
+    KD = kvh * (H // heads)
+    dims = {"input_layernorm": (H,), "self_attn.q_proj": (H, H), "self_attn.k_proj": (KD, H), "self_attn.v_proj": (KD, H), "self_attn.o_proj": (H, H),
+            "post_attention_layernorm": (H,), "mlp.gate_proj": (F, H), "mlp.up_proj": (F, H), "mlp.down_proj": (H, F)}
+    sd = [{}, {}]
+    for i in range(L):
+        for name, shp in dims.items():
+            sd[i][f"model.layers.{i}.{name}.weight"] = torch.randn(*shp, generator=g).to(torch.bfloat16)
+    sd[0]["model.embed_tokens.weight"] = torch.randn(vocab, H, generator=g).to(torch.bfloat16)
+    sd[1]["model.norm.weight"] = torch.ones(H, dtype=torch.bfloat16)
+    for n, part in enumerate(sd):
+        save_file(part, str(d / f"model-{n + 1:05d}-of-00002.safetensors"))
+    shape = checkpoint.llama_shape_of(str(d))
+    src = checkpoint.TensorSource(str(d))
+    assert "lm_head.weight" not in src                                   # a tied checkpoint: load_hf_llama falls back to the embedding
+    model = LiaLlamaModel(shape)
+    bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)      # noqa: E731
+    for i, st in enumerate(model.layers):
+        lw = checkpoint.llama_layer_numpy(src, i)
+        assert set(lw) == set(LLAMA_TENSORS)
+        model._pack_numpy(st, lw)
+        flat = st._np.view(np.uint16)
+        off = {n: model.offsets[k] // 2 for k, n in enumerate(LLAMA_TENSORS)}
+        hf = {"in_norm_w": "input_layernorm", "q_w": "self_attn.q_proj", "k_w": "self_attn.k_proj", "v_w": "self_attn.v_proj", "o_w": "self_attn.o_proj",
+              "post_norm_w": "post_attention_layernorm", "down_w": "mlp.down_proj"}
+        for short, name in hf.items():
+            want = bits(sd[i][f"model.layers.{i}.{name}.weight"]).reshape(-1)
+            assert (flat[off[short]: off[short] + want.size] == want).all(), (i, short)
+        gate, up = bits(sd[i][f"model.layers.{i}.mlp.gate_proj.weight"]), bits(sd[i][f"model.layers.{i}.mlp.up_proj.weight"])
+        gu = flat[off["gate_w"]: off["gate_w"] + 2 * F * H].reshape(F // GU_BLOCK, 2, GU_BLOCK, H)
+        assert (gu[:, 0].reshape(F, H) == gate).all() and (gu[:, 1].reshape(F, H) == up).all()
+    src.close()
