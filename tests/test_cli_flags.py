@@ -61,8 +61,9 @@ def test_prompt_goes_through_the_checkpoint_directorys_tokenizer(tmp_path, capsy
 
 
 def test_matrix_lines_parse_through_the_harness_flag_surface():
-    """tools/run_matrix.py: 33 lines (README example + lia_offline.sh 8 + lia_online.sh 12 + cxl_offloading.sh 12), every one a flag
-    list the harness's own parser accepts; the two ragged ones (1150 / 3, 1 / 2) are there"""
+    """tools/run_matrix.py: 53 lines (README example + lia_offline.sh 8 + lia_online.sh 12 + cxl_offloading.sh 12 + the CPU-only baseline
+    of ipex_offline.sh 8 / ipex_online.sh 12), every one a flag list the harness's own parser accepts; the two ragged ones (1150 / 3,
+    1 / 2) are there"""
     import importlib.util
     import os
     import sys
@@ -73,7 +74,7 @@ def test_matrix_lines_parse_through_the_harness_flag_surface():
     sys.path.insert(0, os.path.join(root, "isca-2025-lia_amd"))
     from lia_amd.run_generation import build_parser
     lines = rm.lines()
-    assert len(lines) == 33 and len({n for n, _ in lines}) == 33
+    assert len(lines) == 53 and len({n for n, _ in lines}) == 53
     by = {n: build_parser().parse_args(f) for n, f in lines}
     assert sum(n.startswith("offline_") for n in by) == 8 and sum(n.startswith("online_") for n in by) == 12 and sum(n.startswith("cxl_") for n in by) == 12
     a = by["cxl_opt30b_32_128_b1150_p02_g0_cxl"]
@@ -82,4 +83,6 @@ def test_matrix_lines_parse_through_the_harness_flag_surface():
     assert (b.batch_size, b.num_minibatch, b.pin_weight, b.gpu_percentage, b.init, b.model_id) == (1, 2, False, 9, "uniform01", "opt-175b")
     r = by["readme_opt30b_256_32_b64_p01_g10_cxl"]
     assert (r.num_iter, r.num_warmup, r.input_tokens, r.max_new_tokens, r.gpu_percentage, r.num_minibatch) == (10, 2, "256", 32, 10, 2)
+    assert sum(n.startswith("ipexoffline_") for n in by) == 8 and sum(n.startswith("ipexonline_") for n in by) == 12
+    assert all((v.prefill_policy, v.decoding_policy, v.gpu_percentage, v.pin_weight) == (1, 1, 0, False) for n, v in by.items() if n.startswith("ipex"))
     assert all(v.benchmark and v.token_latency and v.greedy and v.ipex and v.dtype == "bfloat16" for v in by.values())

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The reference's benchmark matrix through this build's run.py -- one `python run.py <flags>` process per line, the
 reference's LIA flags unchanged (README.md:78,101-112; llm/scripts/lia_offline.sh:13-29, lia_online.sh:13-37,
-cxl_offloading.sh:13-39).  The reference's deliverable is the set of log files those scripts leave; here every line leaves
+cxl_offloading.sh:13-39) and, as run_performance.sh does, the CPU-only baseline of the same shapes (ipex_offline.sh / ipex_online.sh:
+policies 1 / 1, gpu% 0 -- here this build's host path on the box's cores, `ipexoffline_*` / `ipexonline_*`).  The reference's deliverable is the set of log files those scripts leave; here every line leaves
 results/<prefix>_<name>.json (lia_amd.run_generation --result-json: prefill ms, decode tokens/s, the weight stream's share of the
 link, which resource dominated the profiled warm-up iteration, the host-memory peak, the planner's pick for the same line) and
 results/<prefix>_<name>.log (the harness output the reference's scripts redirect to their .log files).  A line this box cannot
@@ -64,6 +65,28 @@ TABLE = [
     ("cxl", M30, 32, 64, 1350, 0, 2, 3, 0, True, True, 2, 1),
     ("cxl", M30, 32, 128, 1150, 0, 2, 3, 0, True, True, 2, 1),
     ("cxl", M30, 32, 256, 1050, 0, 2, 3, 0, True, True, 2, 1),
+    # the CPU-only baseline of the same shapes: llm/scripts/ipex_offline.sh:13-29 and ipex_online.sh:13-37 (run_performance.sh runs
+    # them beside the LIA lines): policies 1 / 1, gpu% 0, no --pin-weight -- every layer on the host cores
+    ("ipexoffline", M30, 32, 32, 64, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexoffline", M30, 2016, 32, 64, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexoffline", M30, 32, 256, 64, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexoffline", M30, 1792, 256, 64, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexoffline", M30, 32, 32, 900, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexoffline", M30, 32, 256, 900, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexoffline", M175, 32, 32, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexoffline", M175, 32, 256, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M30, 32, 32, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M30, 256, 32, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M30, 2016, 32, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M30, 32, 256, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M30, 256, 256, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M30, 1792, 256, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M175, 32, 32, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M175, 256, 32, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M175, 2016, 32, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M175, 32, 256, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M175, 256, 256, 1, 1, 1, 1, 0, False, False, 2, 1),
+    ("ipexonline", M175, 1792, 256, 1, 1, 1, 1, 0, False, False, 2, 1),
 ]
 
 
@@ -81,10 +104,35 @@ def lines():
     return out
 
 
+HOST_FLOPS = 8.0e12          # what 16 Zen 5 cores sustain with vdpbf16ps in lia_host_linear at M = 64 (128 GB/s of weights: LABNOTES r06)
+HOST_PREFILL_FLOPS = 4.5e12  # ... and in a policy-1 prefill (M = 2048: 27.7 s for 48 layers, results/r06_matrix_ipexoffline_opt30b_32_32_b64_p11_g0.json)
+HOST_STREAM = 435e9          # bytes/s of weights a batch-1 host layer reads (7.36 tokens/s over 59 GB, ipexonline_opt30b_32_32_b1)
+
+
+def host_time_estimate(flags):
+    """seconds a line with the PREFILL on the host cores (policy 1) would take here: iterations x (prefill flops + new tokens x the
+    larger of the decode step's flops and its weight bytes).  The reference ran these lines on 40 Sapphire Rapids cores with AMX."""
+    a = dict(zip(flags[::1], flags[1::1]))
+    if a.get("--prefill-policy") != "1":
+        return 0.0
+    params = {"facebook/opt-30b": 29.6e9, "opt-175b": 174e9}[a["-m"]] * (1.0 - int(a["--gpu-percentage"]) / 100.0)
+    B, T, new, iters = int(a["--batch-size"]), int(a["--input-tokens"]), int(a["--max-new-tokens"]), int(a["--num-iter"])
+    return iters * (2.0 * B * T * params / HOST_PREFILL_FLOPS + new * max(2.0 * B * params / HOST_FLOPS, 2.0 * params / HOST_STREAM))
+
+
 def run_line(name, flags, prefix, timeout, extra=(), suffix=""):
     js = os.path.join(ROOT, OUTDIR[0], f"{prefix}_{name}{suffix}.json")
     log = os.path.join(ROOT, OUTDIR[0], f"{prefix}_{name}{suffix}.log")
     os.makedirs(os.path.dirname(js), exist_ok=True)
+    est = host_time_estimate(flags) if not extra else 0.0
+    if est > 0.8 * timeout:
+        # not started: the box's 16 cores would need longer than the line's time limit for the host-side prefill / decode alone
+        rec = {"status": "not run: time", "flags_cmdline": flags, "estimated_s": round(est),
+               "reason": f"policy-1 prefill and decode on this box's 16 host cores: ~{est:.0f} s estimated (prefill {HOST_PREFILL_FLOPS / 1e12:.1f} TFLOP/s, "
+                         f"decode {HOST_FLOPS / 1e12:.0f} TFLOP/s or {HOST_STREAM / 1e9:.0f} GB/s: measured on the lines that ran), limit {timeout} s per line"}
+        json.dump(rec, open(js, "w"), indent=1)
+        print(f"{name}{suffix}: not run -- {rec['reason']}", flush=True)
+        return rec
     cmd = [sys.executable, os.path.join(ROOT, "run.py")] + flags + list(extra) + ["--result-json", js]
     t0 = time.time()
     if os.path.exists(js):
