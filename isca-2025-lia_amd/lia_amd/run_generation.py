@@ -505,7 +505,8 @@ def _main(args, rec=None):
         rec["weight_stream"] = {"bytes_per_timed_iteration": b / n_t, "copy_engine_busy_ms_per_timed_iteration": round(ms / n_t, 1),
                                 "gbs_while_busy": round(b / max(ms, 1e-9) / 1e6, 2), "gbs_over_wall": round(b / max(total_time, 1e-9) / 1e9, 2),
                                 "fraction_of_63_gbs_link_over_wall": round(b / max(total_time, 1e-9) / 63e9, 3),
-                                "wire_format": args.stream_format}
+                                "wire_format": ("pack10" if any(getattr(st, "packed", 0) for st in model.layers) else "raw"),
+                                "wire_format_note": "the format of the host copies that streamed (a policy-1 / NUMA-tier / unpinned placement ships raw: scheduler.placement_formats)"}
     if "decode_tokens_per_s" in res:
         print("Decode throughput: %.2f tokens/s, prefill %.1f ms" % (res["decode_tokens_per_s"], res["prefill_ms"]))
     coop = getattr(model._lia_scheduler, "coop_report", lambda: None)()
