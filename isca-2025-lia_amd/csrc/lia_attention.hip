@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   __builtin_amdgcn_sched_barrier(0)
   // two visible blocks: chain 1 runs under the statistics of block 0 (never masked here) -- MFMAs 0..3 beside the rounding and the
   // maximum, 4..7 beside the sum of exp; then block 1, always through the mask (it may hold the diagonal or the end of the sequence)
-#define P3_S1_TILE2()                                                                                                      \
+#define P3_S1_TILE2(MASKED)                                                                                                \
   do {                                                                                                                     \
     uint4 kf0[8], kf1[8];                                                                                                  \
     f32x16 s0 = f32x16{0}, s1 = f32x16{0};                                                                                 \
@@ -431,34 +431,60 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
     m = mn;                                                                                                                \
     _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                        \
       rp[c] = p3_round2<POST_SCALE>(s1[2 * c], s1[2 * c + 1], scaling);                                                    \
-      rp[c] = p3_mask2(rp[c], lim1, c);                                                                                    \
+      if (MASKED) rp[c] = p3_mask2(rp[c], lim1, c);                                                                        \
     }                                                                                                                      \
     P3_STATS(rp);                                                                                                          \
   } while (0)
 
   float m = -INFINITY, l = 0.f;
-  for (int t = 0; t < n64; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // (the stage after sweep 1's last tile is sweep 2's first: its K and V ride under this tile's arithmetic)
-    if (t + 1 < n64) P3_ISSUE(t + 1, (t + 1) & 1, false);
-    else P3_ISSUE(0, n64 & 1, true);
-    const char* kb = &lds[t & 1][0][0];
-    const int nb = nblk - 2 * t;
-    const int lim1 = vis - 32 * (2 * t + 1);
-    if (nb >= 2) {
-      P3_S1_TILE2();
-    } else if (nb == 1) {
-      uint4 kf0[8];
-      f32x16 s0;
-      f32x2 rp[8];
-      P3_KFRAGS(kf0, kb, 0);
-      P3_QK(kf0, s0);
+  // r06: both sweeps are FOUR loops instead of one loop with three cases.  A wave has two visible key blocks in tiles 0 .. nfull - 1
+  // (nfull = nblk / 2), one in tile nfull when nblk is odd (the diagonal / the end of the sequence), none behind it -- but every
+  // wave meets every barrier and issues its share of every stage; and in tiles 0 .. nfree - 1 the LAST key of the tile is visible
+  // to the wave's FIRST query (64 t + 63 <= min(q_wave, T - 1)), so block 1's mask selects nothing there and is left out (two
+  // v_cmp + two v_cndmask per pair: 12-14 % of a tile's vector instructions).  As ONE loop (`if (nb >= 2) ... else if (nb == 1)`)
+  // hipcc also merged sweep 2's 64 accumulator registers at the latch: 64 v_mov out of the two-block body and 64 back on the
+  // back-edge, 128 of ~400 vector instructions per iteration (found in the ISA).  Same operations on the same values in the same order.
+  const int nfull = nblk >> 1;                                     // (<= n64: nblk <= n32 <= 2 n64)
+  const int nfree = min((min(q_wave, T - 1) + 1) >> 6, nfull);
+#define P3_S1_STEP()                                                                                                       \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                         \
+  __syncthreads();                                                                                                         \
+  /* (the stage after sweep 1's last tile is sweep 2's first: its K and V ride under this tile's arithmetic) */           \
+  if (t + 1 < n64) P3_ISSUE(t + 1, (t + 1) & 1, false);                                                                    \
+  else P3_ISSUE(0, n64 & 1, true);                                                                                         \
+  const char* kb = &lds[t & 1][0][0];                                                                                      \
+  const int lim1 = vis - 32 * (2 * t + 1)
+  {
+    int t = 0;
+    for (; t < nfree; ++t) {
+      P3_S1_STEP();
+      P3_S1_TILE2(0);
+      (void)lim1;
+    }
+    for (; t < nfull; ++t) {
+      P3_S1_STEP();
+      P3_S1_TILE2(1);
+    }
+    if (t < n64) {
+      P3_S1_STEP();
+      if (nblk & 1) {
+        uint4 kf0[8];
+        f32x16 s0;
+        f32x2 rp[8];
+        P3_KFRAGS(kf0, kb, 0);
+        P3_QK(kf0, s0);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) rp[c] = p3_mask2(p3_round2<POST_SCALE>(s0[2 * c], s0[2 * c + 1], scaling), lim1 + 32, c);
-      P3_STATS(rp);
+        for (int c = 0; c < 8; ++c) rp[c] = p3_mask2(p3_round2<POST_SCALE>(s0[2 * c], s0[2 * c + 1], scaling), lim1 + 32, c);
+        P3_STATS(rp);
+      }
+      ++t;
+    }
+    for (; t < n64; ++t) {
+      P3_S1_STEP();
+      (void)kb; (void)lim1;
     }
   }
+#undef P3_S1_STEP
 
   // ---- sweep 2: P = bf16(exp(s - m) / l), O^T += V^T . P^T ----
   const float rl0 = __builtin_amdgcn_rcpf(l);
@@ -478,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
 #define P3_PF(pk, c) __builtin_bit_cast(bf16x8, uint4{pk[4 * ((c) >> 2)], pk[4 * ((c) >> 2) + 1], pk[4 * ((c) >> 2) + 2], pk[4 * ((c) >> 2) + 3]})
   // two visible blocks: chain 1 under the softmax of block 0, P.V of block 0 under the softmax of block 1, then P.V of block 1; the
   // V^T pieces are fetched one phase ahead.  Every oacc[d] takes its four products in the order (block 0, ks 0), (0, 1), (1, 0), (1, 1).
-#define P3_S2_TILE2()                                                                                                      \
+#define P3_S2_TILE2(MASKED)                                                                                                \
   do {                                                                                                                     \
     uint4 kf0[8], kf1[8];                                                                                                  \
     f32x16 s0 = f32x16{0}, s1 = f32x16{0};                                                                                 \
@@ -498,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
         oacc[c & 3] = P3_MFMA(vfa[c], P3_PF(pk0, c), oacc[c & 3]);                                                         \
         P3_VFRAG(vfb[c], vb, 1, c);                                                                                        \
         f32x2 r_ = p3_round2<POST_SCALE>(s1[2 * c], s1[2 * c + 1], scaling);                                               \
-        r_ = p3_mask2(r_, lim1, c);                                                                                        \
+        if (MASKED) r_ = p3_mask2(r_, lim1, c);                                                                            \
         pk1[c] = p3_prob2(r_, m, l, rl);                                                                                   \
       }                                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                                   \
@@ -506,17 +532,27 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
     _Pragma("unroll") for (int c = 0; c < 8; ++c) oacc[c & 3] = P3_MFMA(vfb[c], P3_PF(pk1, c), oacc[c & 3]);               \
   } while (0)
 
-  for (int t = 0; t < n64; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < n64) P3_ISSUE(t + 1, (n64 + t + 1) & 1, true);
-    const char* kb = &lds[(n64 + t) & 1][0][0];
-    const char* vb = &lds[(n64 + t) & 1][1][0];
-    const int nb = nblk - 2 * t;
-    const int lim1 = vis - 32 * (2 * t + 1);
-    if (nb >= 2) {
-      P3_S2_TILE2();
-    } else if (nb == 1) {
+  // (four loops, as sweep 1)
+#define P3_S2_STEP()                                                                                                       \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                         \
+  __syncthreads();                                                                                                         \
+  if (t + 1 < n64) P3_ISSUE(t + 1, (n64 + t + 1) & 1, true);                                                               \
+  const char* kb = &lds[(n64 + t) & 1][0][0];                                                                              \
+  const char* vb = &lds[(n64 + t) & 1][1][0];                                                                              \
+  const int lim1 = vis - 32 * (2 * t + 1)
+  int t = 0;
+  for (; t < nfree; ++t) {
+    P3_S2_STEP();
+    P3_S2_TILE2(0);
+    (void)lim1;
+  }
+  for (; t < nfull; ++t) {
+    P3_S2_STEP();
+    P3_S2_TILE2(1);
+  }
+  if (t < n64) {
+    P3_S2_STEP();
+    if (nblk & 1) {
       uint4 kf0[8];
       f32x16 s0;
       uint32_t pk0[8];
@@ -531,7 +567,14 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
 #pragma unroll
       for (int c = 0; c < 8; ++c) oacc[c & 3] = P3_MFMA(vfa[c], P3_PF(pk0, c), oacc[c & 3]);
     }
+    (void)vb;
+    ++t;
   }
+  for (; t < n64; ++t) {
+    P3_S2_STEP();
+    (void)kb; (void)vb; (void)lim1;
+  }
+#undef P3_S2_STEP
 #undef P3_S2_TILE2
 #undef P3_S1_TILE2
 #undef P3_CHAIN0
