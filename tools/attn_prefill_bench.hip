@@ -1,6 +1,6 @@
 // A/B of the d = 128 prefill attention: the kernel in csrc/lia_attention.hip (third generation) against the second generation kept in
 // tools/attn_prefill_gen2.inc ("candidate" below), same inputs, outputs compared bit for bit, both timed.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I isca-2025-lia_amd/csrc -I include tools/attn_prefill_bench.hip -o tools/attn_prefill_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-honor-nans -I isca-2025-lia_amd/csrc -I include tools/attn_prefill_bench.hip -o tools/attn_prefill_bench   (-fno-honor-nans: as csrc/Makefile builds lia_attention.o)
 //   tools/attn_prefill_bench            (OPT-30B's B 64 x T 256 x 56 heads, Llama-3-8B's B 32 x T 1024 x 32 / 8 heads, ragged T)
 #include "../isca-2025-lia_amd/csrc/lia_attention.hip"
 #include <vector>
