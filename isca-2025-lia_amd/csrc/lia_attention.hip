@@ -308,16 +308,26 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   // ---- staging by LDS-DMA: instruction j of wave w moves key rows 16 j + 4 w + (lane >> 4) of the tile, one 16-byte chunk per lane,
   // to consecutive LDS bytes (1 KB per instruction); the images' chunk permutations are applied on the SOURCE side:
   //   K: chunk c of row R sits in slot c ^ (R & 15);  V: in slot c ^ (((R & 3) << 2) | ((R >> 2) & 3))   (R & 15 = 4 w + (lane >> 4))
+  // r06: the address of a row is a UNIFORM base (first row of the instruction's 16, scalar 64-bit arithmetic) plus a 32-bit
+  // per-lane byte offset (row within the 16, clamped to the sequence's last row, + chunk): the global saddr form.  r05 computed
+  // min(key, T - 1) * kv_row per lane in 64 bits -- ~36 of a tile's ~230 vector instructions in a VALU-bound loop (read in the ISA).
   const int srow = 4 * wave + (lane >> 4), sslot = lane & 15;
-  const bf16_t* ksrc = kbase + 8 * (sslot ^ srow);
-  const bf16_t* vsrc = vbase + 8 * (sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
+  const unsigned kvrow_b = (unsigned)kv_row * 2u;                  // bytes per key row (the launcher checks 16 rows fit 32 bits)
+  const unsigned srow_b = (unsigned)srow * kvrow_b;
+  const unsigned kch_b = 16u * (unsigned)(sslot ^ srow);
+  const unsigned vch_b = 16u * (unsigned)(sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
 #define P3_ISSUE(t, buf, WITH_V)                                                                                                   \
   do {                                                                                                                             \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                             \
-      const long key_ = min((t) * 64 + 16 * j_ + srow, T - 1);                                                                     \
-      __builtin_amdgcn_global_load_lds(GL_AS1(ksrc + key_ * kv_row), LDS_AS3(&lds[buf][0][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
+      const int k0_ = min((t) * 64 + 16 * j_, T - 1);                   /* uniform */                                              \
+      const unsigned lim_ = (unsigned)min(T - 1 - k0_, 15) * kvrow_b;   /* uniform: min(k0 + srow, T - 1) = k0 + min(srow, T - 1 - k0) */ \
+      const unsigned ro_ = min(srow_b, lim_);                                                                                      \
+      const long base_ = (long)k0_ * (long)kvrow_b;                                                                                \
+      __builtin_amdgcn_global_load_lds(GL_AS1((const char*)kbase + base_ + (ro_ + kch_b)),                                        \
+                                       LDS_AS3(&lds[buf][0][(16 * j_ + 4 * wave) * 256]), 16, 0, 0);                               \
       if (WITH_V)                                                                                                                  \
-        __builtin_amdgcn_global_load_lds(GL_AS1(vsrc + key_ * kv_row), LDS_AS3(&lds[buf][1][(16 * j_ + 4 * wave) * 256]), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds(GL_AS1((const char*)vbase + base_ + (ro_ + vch_b)),                                      \
+                                         LDS_AS3(&lds[buf][1][(16 * j_ + 4 * wave) * 256]), 16, 0, 0);                             \
     }                                                                                                                              \
   } while (0)
 
