@@ -316,9 +316,16 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   const unsigned srow_b = (unsigned)srow * kvrow_b;
   const unsigned kch_b = 16u * (unsigned)(sslot ^ srow);
   const unsigned vch_b = 16u * (unsigned)(sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
+  // (measurement switches of tools/attn_prefill_bench, never defined in the library build: -DP3X_NO_LOADS leaves the K / V stages
+  // out, -DP3X_NO_MATH the tiles' arithmetic -- where a tile step's time goes, LABNOTES r06)
+#ifdef P3X_NO_LOADS
+#define P3X_NJ 0
+#else
+#define P3X_NJ 4
+#endif
 #define P3_ISSUE(t, buf, WITH_V)                                                                                                   \
   do {                                                                                                                             \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < P3X_NJ; ++j_) {                                                                             \
       const int k0_ = min((t) * 64 + 16 * j_, T - 1);                   /* uniform */                                              \
       const unsigned lim_ = (unsigned)min(T - 1 - k0_, 15) * kvrow_b;   /* uniform: min(k0 + srow, T - 1) = k0 + min(srow, T - 1 - k0) */ \
       const unsigned ro_ = min(srow_b, lim_);                                                                                      \
@@ -413,8 +420,13 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   __builtin_amdgcn_sched_barrier(0)
   // two visible blocks: chain 1 runs under the statistics of block 0 (never masked here) -- MFMAs 0..3 beside the rounding and the
   // maximum, 4..7 beside the sum of exp; then block 1, always through the mask (it may hold the diagonal or the end of the sequence)
+#ifdef P3X_NO_MATH
+#define P3X_MATH 0
+#else
+#define P3X_MATH 1
+#endif
 #define P3_S1_TILE2(MASKED)                                                                                                \
-  do {                                                                                                                     \
+  if (P3X_MATH) do {                                                                                                                     \
     uint4 kf0[8], kf1[8];                                                                                                  \
     f32x16 s0 = f32x16{0}, s1 = f32x16{0};                                                                                 \
     f32x2 rp[8];                                                                                                           \
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   // two visible blocks: chain 1 under the softmax of block 0, P.V of block 0 under the softmax of block 1, then P.V of block 1; the
   // V^T pieces are fetched one phase ahead.  Every oacc[d] takes its four products in the order (block 0, ks 0), (0, 1), (1, 0), (1, 1).
 #define P3_S2_TILE2(MASKED)                                                                                                \
-  do {                                                                                                                     \
+  if (P3X_MATH) do {                                                                                                                     \
     uint4 kf0[8], kf1[8];                                                                                                  \
     f32x16 s0 = f32x16{0}, s1 = f32x16{0};                                                                                 \
     uint32_t pk0[8], pk1[8];                                                                                               \
@@ -819,6 +831,9 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
       const long hd = (long)kv_heads * 128;
       // (a token-major [B][T][h][d] K/V -- strides (hd, T hd) -- was measured: same time, so the cache layout stays)
       const int nqb = (T + 127) / 128;
+      // the staging addresses hold (row within 16) x (bytes per key row) + chunk in 32 bits: 16 Bc hd 2 < 2^32, i.e. a cache
+      // batch x hidden of < 1.3e8 elements per key row (OPT-175B at Bc = 2048 is 2.5e7)
+      if ((long)Bc * hd * 2 * 16 + 256 >= (1L << 32)) return -1;
       int n_groups = B * kv_heads;
       // the XCD-aware order when the groups spread evenly over the 8 XCDs (a multiple of 8, or so many that the remainder does not
       // matter); otherwise r05's order, which deals single workgroups round-robin (2 rows x 2 KV heads would use 4 XCDs of 8)
