@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void lia_attn_prefill_kernel(const bf16_t* __r
     const bf16_t* qp = q + ((long)b * T + qrow) * ldq + (long)hh * D;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
+#ifdef P3X_NO_QLOAD
+      uint4 v = uint4{(unsigned)lane, (unsigned)s, 0x3c003c00u, 0x3c003c00u};
+#else
       uint4 v = *(const uint4*)(qp + 16 * s + 8 * h);
+#endif
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
       uint32_t o[4];
 #pragma unroll
@@ -317,7 +321,12 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   const unsigned kch_b = 16u * (unsigned)(sslot ^ srow);
   const unsigned vch_b = 16u * (unsigned)(sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
   // (measurement switches of tools/attn_prefill_bench, never defined in the library build: -DP3X_NO_LOADS leaves the K / V stages
-  // out, -DP3X_NO_MATH the tiles' arithmetic -- where a tile step's time goes, LABNOTES r06)
+  // out, -DP3X_NO_MATH the tiles' arithmetic, -DP3X_NO_WAIT the wait for a stage (wrong results) -- where a tile step's time goes, LABNOTES r06)
+#ifdef P3X_NO_WAIT
+#define P3X_WAIT() do {} while (0)
+#else
+#define P3X_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 #ifdef P3X_NO_LOADS
 #define P3X_NJ 0
 #else
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   const int nfull = nblk >> 1;                                     // (<= n64: nblk <= n32 <= 2 n64)
   const int nfree = min((min(q_wave, T - 1) + 1) >> 6, nfull);
 #define P3_S1_STEP()                                                                                                       \
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                         \
+  P3X_WAIT();                                                                                                              \
   __syncthreads();                                                                                                         \
   /* (the stage after sweep 1's last tile is sweep 2's first: its K and V ride under this tile's arithmetic) */           \
   if (t + 1 < n64) P3_ISSUE(t + 1, (t + 1) & 1, false);                                                                    \
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
 
   // (four loops, as sweep 1)
 #define P3_S2_STEP()                                                                                                       \
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                         \
+  P3X_WAIT();                                                                                                              \
   __syncthreads();                                                                                                         \
   if (t + 1 < n64) P3_ISSUE(t + 1, (n64 + t + 1) & 1, true);                                                               \
   const char* kb = &lds[(n64 + t) & 1][0][0];                                                                              \
@@ -608,8 +617,15 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
 #undef P3_KFRAGS
 #undef P3_ISSUE
 
-  if (my_q < T) {
-    bf16_t* op = out + ((long)b * T + my_q) * ldo + (long)hh * D;
+  // ---- output: through the LDS, so that a store instruction writes whole rows ----
+  // A lane holds 4 consecutive dims of ONE query per accumulator register group: stored from the registers, an instruction
+  // writes 16 bytes to each of 32 rows (r05: 16 such instructions per wave, 512 partial-line writes).  Measured with the stores
+  // left out (-DP3X_NO_STORE): 66 of the 330 us of OPT-30B's T = 256 launch, 70 of Llama-3-8B's 901.  r06: each wave parks its
+  // 32 rows x 256 bytes in its own 8 KB of stage buffer 0 -- free since the barrier of the last step: the last tile of sweep 2
+  // lives in buffer (2 n64 - 1) & 1 = 1 and no stage was issued behind it -- 16-byte chunks XOR-swizzled by the row as the K
+  // image, and reads them back row-major: 8 instructions of 4 rows x 256 contiguous bytes.  Wave-private, in order: no barrier.
+  {
+    char* ob = &lds[0][0][0] + wave * 8192;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -617,8 +633,21 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
         uint2 o;
         o.x = pack_bf16x2(oacc[d][4 * g], oacc[d][4 * g + 1]);
         o.y = pack_bf16x2(oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
-        *(uint2*)(op + 32 * d + 8 * g + 4 * h) = o;
+        *(uint2*)(ob + r * 256 + (((4 * d + g) ^ (r & 15)) << 4) + 8 * h) = o;
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int orow = lane >> 4, oc = lane & 15;
+#ifdef P3X_NO_STORE
+    const bool st_on = scaling == 12345.f;
+#else
+    const bool st_on = true;
+#endif
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = 4 * i + orow;
+      const uint4 v = *(const uint4*)(ob + rr * 256 + ((oc ^ (rr & 15)) << 4));
+      if (q_wave + rr < T && st_on) *(uint4*)(out + ((long)b * T + q_wave + rr) * ldo + (long)hh * D + 8 * oc) = v;
+    }
   }
 }
 
