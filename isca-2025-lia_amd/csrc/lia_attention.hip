@@ -271,7 +271,6 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
   // r06: XCD-aware order (n_groups > 0).  The workgroups that read the same K / V -- every query block of the G query heads of one
   // (batch row, KV head) -- form a group of nqb * G members; group g runs on XCD g % 8 (workgroup ids are dealt round-robin over
   // the XCDs: id % 8), its members in consecutive slots of that XCD.  A K / V tile is then fetched into ONE L2 and found there by
@@ -300,10 +299,14 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   // wave w of a workgroup goes to SIMD w, and late rows have more keys to visit, so without it SIMD 3 would get every heavy piece
   // and SIMD 0 every light one (with r05's grid: XCD 7 / XCD 0 as well)
   const int rev = (hh + b) & 1;
-  if (rev) bx = nqb - 1 - bx;
-  const int q_wg = bx * 128;
+  // r06: a workgroup takes TWO query blocks of its head, block bx and its mirror image nqb_all - 1 - bx (the launcher passes
+  // nqb = ceil(nqb_all / 2) then; nqb == nqb_all: one block per workgroup as before).  A light block and a heavy one: every
+  // workgroup of a sequence costs the same (causal: 1 + ... keys), half as many workgroups are launched and drained -- the
+  // launches alone were 75 us of the 313 us of OPT-30B's T = 256 launch (the kernel without loads, arithmetic and stores,
+  // LABNOTES r06) -- and the second block's K / V tiles were just read by the first.
+  const int nqb_all = (T + 127) >> 7;
+  const int npass = (nqb != nqb_all && nqb_all - 1 - bx != bx) ? 2 : 1;
   const int wsub = rev ? 3 - wave : wave;
-  const int q_wave = q_wg + wsub * 32;
   const int kh = hh / (heads / kv_heads);
   const bf16_t* kbase = kc + (long)(b0 + b) * kv_batch + (long)kh * D;
   const bf16_t* vbase = vc + (long)(b0 + b) * kv_batch + (long)kh * D;
@@ -347,6 +350,20 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
     }                                                                                                                              \
   } while (0)
 
+  for (int pass = 0; pass < npass; ++pass) {
+  // (the lane-derived LDS offsets below are the same in both passes; behind this opaque copy hipcc recomputes them per pass
+  // instead of keeping ~20 more registers alive through both sweeps: as a plain loop the kernel needed 256 registers + scratch
+  // and ran 19 % slower than without the loop)
+  int lane_p_ = lane;
+  asm volatile("" : "+v"(lane_p_));
+  const int lane = lane_p_;
+  const int r = lane & 31, h = lane >> 5;
+  // (the blocks in reverse order for every other (batch row, head), as the waves: see `rev`)
+  const int bxp = (nqb != nqb_all) ? (((pass ^ rev) & 1) ? nqb_all - 1 - bx : bx) : (rev ? nqb - 1 - bx : bx);
+  const int q_wg = bxp * 128;
+  const int q_wave = q_wg + wsub * 32;
+  // (the first block's output staging lives in stage buffer 0, where the second block's first K tile goes)
+  if (pass) __syncthreads();
   // r06: the first K tile is requested BEFORE the query rows -- the LDS-DMA needs no register, and the workgroup's two first
   // round trips to memory (q rows into registers, K tile 0 into LDS) then overlap instead of following each other (~1.5 us of a
   // ~16 us workgroup at T = 256: the prologue was ~5 us of it, LABNOTES r05)
@@ -649,6 +666,7 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
       if (q_wave + rr < T && st_on) *(uint4*)(out + ((long)b * T + q_wave + rr) * ldo + (long)hh * D + 8 * oc) = v;
     }
   }
+  }   // pass
 }
 
 
@@ -859,7 +877,12 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
     case 128: {
       const long hd = (long)kv_heads * 128;
       // (a token-major [B][T][h][d] K/V -- strides (hd, T hd) -- was measured: same time, so the cache layout stays)
-      const int nqb = (T + 127) / 128;
+      const int nqb_all = (T + 127) / 128;
+#ifdef LIA_ATTN_NO_PAIRS
+      const int nqb = nqb_all;
+#else
+      const int nqb = (nqb_all + 1) / 2;               // two query blocks per workgroup: bx and its mirror image (see the kernel)
+#endif
       // the staging addresses hold (row within 16) x (bytes per key row) + chunk in 32 bits: 16 Bc hd 2 < 2^32, i.e. a cache
       // batch x hidden of < 1.3e8 elements per key row (OPT-175B at Bc = 2048 is 2.5e7)
       if ((long)Bc * hd * 2 * 16 + 256 >= (1L << 32)) return -1;
