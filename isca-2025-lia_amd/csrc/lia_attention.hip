@@ -261,6 +261,43 @@ __device__ __forceinline__ uint32_t p3_prob2(f32x2 r, float m, float l, float rl
   return p3_cvt_pk(q.x, q.y);
 }
 
+// r06: the same operations on TWO pairs at a time.  A pair's chain -- subtract, scale, exp, e * (1 / l) and the four residual
+// fmas -- is ten dependent instructions, and behind every packed one hipcc must put an s_nop before its consumer: 75-99 s_nop
+// per sweep-2 tile, each a 1.8 ns issue slot of the wave (tools/issue_model).  As 4-wide vector operations every stage
+// legalises into two independent packed instructions side by side, so a stage's consumer is one instruction away and needs no
+// s_nop: 79-85 -> 8-10 per tile (+11 vector instructions).  Same operations on the same values: bit-identical.  Sweep 2 only:
+// in sweep 1 the 4-wide subtraction comes out as 32 single instructions instead of 16 packed ones and the gain is gone.
+template <int POST_SCALE, int MASKED>
+__device__ __forceinline__ f32x4 p3_round4(float a0, float a1, float a2, float a3, float scaling, int lim, int c) {
+  uint32_t p0 = p3_cvt_pk(a0, a1), p1 = p3_cvt_pk(a2, a3);
+  f32x4 r = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+  if (POST_SCALE) {
+    const f32x4 t = r * scaling;
+    p0 = p3_cvt_pk(t.x, t.y);
+    p1 = p3_cvt_pk(t.z, t.w);
+    r = f32x4{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+  }
+  if (MASKED) {      // pairs c and c + 1 (p3_mask2)
+    r.x = (lim >= P3_KOFF(2 * c)) ? r.x : -INFINITY;
+    r.y = (lim >= P3_KOFF(2 * c + 1)) ? r.y : -INFINITY;
+    r.z = (lim >= P3_KOFF(2 * c + 2)) ? r.z : -INFINITY;
+    r.w = (lim >= P3_KOFF(2 * c + 3)) ? r.w : -INFINITY;
+  }
+  return r;
+}
+__device__ __forceinline__ f32x4 p3_exp4(f32x4 r, float m) {
+  const f32x4 t = (r - m) * 0x1.715476p+0f;
+  return f32x4{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
+}
+__device__ __forceinline__ uint2 p3_prob4(f32x4 r, float m, float l, float rl) {
+  const f32x4 e = p3_exp4(r, m);
+  const f32x4 nl = (f32x4)(-l), rr = (f32x4)rl;
+  f32x4 q = e * rl;
+  q = __builtin_elementwise_fma(__builtin_elementwise_fma(nl, q, e), rr, q);
+  q = __builtin_elementwise_fma(__builtin_elementwise_fma(nl, q, e), rr, q);
+  return uint2{p3_cvt_pk(q.x, q.y), p3_cvt_pk(q.z, q.w)};
+}
+
 template <int POST_SCALE>
 __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
                                                                   const bf16_t* __restrict__ vc, bf16_t* __restrict__ out, long ldo, int T,
@@ -319,8 +356,14 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
   // per-lane byte offset (row within the 16, clamped to the sequence's last row, + chunk): the global saddr form.  r05 computed
   // min(key, T - 1) * kv_row per lane in 64 bits -- ~36 of a tile's ~230 vector instructions in a VALU-bound loop (read in the ISA).
   const int srow = 4 * wave + (lane >> 4), sslot = lane & 15;
-  const unsigned kvrow_b = (unsigned)kv_row * 2u;                  // bytes per key row (the launcher checks 16 rows fit 32 bits)
-  const unsigned srow_b = (unsigned)srow * kvrow_b;
+  // Second form (r06): ONE scalar base per tile (its first row) and the lane's row within the 64 clamped against one scalar limit,
+  // min(srow + 16 j, T - 1 - 64 t) rows -- the per-instruction scalar arithmetic of the first form (a 64-bit product, two minima and
+  // two adds, x 4) was 77-84 scalar instructions per tile, and scalar instructions cost 1.8 ns each WITHOUT overlapping between the
+  // two waves of a SIMD (tools/issue_model): now 23-30.
+  const unsigned kvrow_b = (unsigned)kv_row * 2u;                  // bytes per key row (the launcher checks 64 rows fit 32 bits)
+  unsigned rowoff_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rowoff_b[j] = (unsigned)(srow + 16 * j) * kvrow_b;
   const unsigned kch_b = 16u * (unsigned)(sslot ^ srow);
   const unsigned vch_b = 16u * (unsigned)(sslot ^ (((srow & 3) << 2) | ((srow >> 2) & 3)));
   // (measurement switches of tools/attn_prefill_bench, never defined in the library build: -DP3X_NO_LOADS leaves the K / V stages
@@ -337,11 +380,12 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
 #endif
 #define P3_ISSUE(t, buf, WITH_V)                                                                                                   \
   do {                                                                                                                             \
-    _Pragma("unroll") for (int j_ = 0; j_ < P3X_NJ; ++j_) {                                                                             \
-      const int k0_ = min((t) * 64 + 16 * j_, T - 1);                   /* uniform */                                              \
-      const unsigned lim_ = (unsigned)min(T - 1 - k0_, 15) * kvrow_b;   /* uniform: min(k0 + srow, T - 1) = k0 + min(srow, T - 1 - k0) */ \
-      const unsigned ro_ = min(srow_b, lim_);                                                                                      \
-      const long base_ = (long)k0_ * (long)kvrow_b;                                                                                \
+    int t0_ = (t) * 64;                                                 /* uniform; <= T - 1: the tile holds a valid row */        \
+    asm volatile("" : "+s"(t0_));   /* (opaque: or loop strength reduction turns the bases into per-lane 64-bit pointers) */       \
+    const unsigned lim_ = (unsigned)min(T - 1 - t0_, 63) * kvrow_b;     /* min(t0 + row, T - 1) = t0 + min(row, T - 1 - t0) */     \
+    const long base_ = (long)t0_ * (long)kvrow_b;                                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < P3X_NJ; ++j_) {                                                                        \
+      const unsigned ro_ = min(rowoff_b[j_], lim_);                                                                                \
       __builtin_amdgcn_global_load_lds(GL_AS1((const char*)kbase + base_ + (ro_ + kch_b)),                                        \
                                        LDS_AS3(&lds[buf][0][(16 * j_ + 4 * wave) * 256]), 16, 0, 0);                               \
       if (WITH_V)                                                                                                                  \
@@ -563,7 +607,11 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
       _Pragma("unroll") for (int c = 2 * c2; c < 2 * c2 + 2; ++c) {                                                        \
         s1 = P3_MFMA(__builtin_bit_cast(bf16x8, kf1[c]), qf[c], s1);                                                       \
         P3_VFRAG(vfa[c], vb, 0, c);                                                                                        \
-        pk0[c] = p3_prob2(p3_round2<POST_SCALE>(s0[2 * c], s0[2 * c + 1], scaling), m, l, rl);                             \
+      }                                                                                                                    \
+      {                                                                                                                    \
+        const uint2 p_ = p3_prob4(p3_round4<POST_SCALE, 0>(s0[4 * c2], s0[4 * c2 + 1], s0[4 * c2 + 2], s0[4 * c2 + 3], scaling, 0, 0), m, l, rl); \
+        pk0[2 * c2] = p_.x;                                                                                                \
+        pk0[2 * c2 + 1] = p_.y;                                                                                            \
       }                                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                                   \
     }                                                                                                                      \
@@ -571,9 +619,11 @@ __global__ __launch_bounds__(256, 2) void lia_attn_prefill128_kernel(const bf16_
       _Pragma("unroll") for (int c = 2 * c2; c < 2 * c2 + 2; ++c) {                                                        \
         oacc[c & 3] = P3_MFMA(vfa[c], P3_PF(pk0, c), oacc[c & 3]);                                                         \
         P3_VFRAG(vfb[c], vb, 1, c);                                                                                        \
-        f32x2 r_ = p3_round2<POST_SCALE>(s1[2 * c], s1[2 * c + 1], scaling);                                               \
-        if (MASKED) r_ = p3_mask2(r_, lim1, c);                                                                            \
-        pk1[c] = p3_prob2(r_, m, l, rl);                                                                                   \
+      }                                                                                                                    \
+      {                                                                                                                    \
+        const uint2 p_ = p3_prob4(p3_round4<POST_SCALE, MASKED>(s1[4 * c2], s1[4 * c2 + 1], s1[4 * c2 + 2], s1[4 * c2 + 3], scaling, lim1, 2 * c2), m, l, rl); \
+        pk1[2 * c2] = p_.x;                                                                                                \
+        pk1[2 * c2 + 1] = p_.y;                                                                                            \
       }                                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                                   \
     }                                                                                                                      \
@@ -883,9 +933,9 @@ extern "C" int lia_attn_prefill_launch(const bf16_t* q, long ldq, const bf16_t* 
 #else
       const int nqb = (nqb_all + 1) / 2;               // two query blocks per workgroup: bx and its mirror image (see the kernel)
 #endif
-      // the staging addresses hold (row within 16) x (bytes per key row) + chunk in 32 bits: 16 Bc hd 2 < 2^32, i.e. a cache
-      // batch x hidden of < 1.3e8 elements per key row (OPT-175B at Bc = 2048 is 2.5e7)
-      if ((long)Bc * hd * 2 * 16 + 256 >= (1L << 32)) return -1;
+      // the staging addresses hold (row within a 64-key tile) x (bytes per key row) + chunk in 32 bits: 64 Bc hd 2 < 2^32, i.e. a
+      // cache batch x hidden of < 3.3e7 elements per key row (OPT-175B at Bc = 2048 is 2.5e7)
+      if ((long)Bc * hd * 2 * 64 + 256 >= (1L << 32)) return -1;
       int n_groups = B * kv_heads;
       // the XCD-aware order when the groups spread evenly over the 8 XCDs (a multiple of 8, or so many that the remainder does not
       // matter); otherwise r05's order, which deals single workgroups round-robin (2 rows x 2 KV heads would use 4 XCDs of 8)
