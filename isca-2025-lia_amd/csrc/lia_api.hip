@@ -517,7 +517,11 @@ extern "C" int lia_attention(const lia_bf16* q, long ldq, const lia_bf16* kcache
     if (S != T) { lia_set_error("lia_attention: multi-token blocks only as a prefill (S == T), got S=%d T=%d", S, T); return LIA_ERR_INVALID; }
     rc = lia_attn_prefill_launch(q, ldq, kcache, vcache, out, ldo, B, T, heads, heads, head_dim, cache_batch, b0, 0, (hipStream_t)stream);
   }
-  if (rc) { lia_set_error("lia_attention: head_dim %d unsupported (32/64/128) or S=%d too long", head_dim, S); return LIA_ERR_INVALID; }
+  if (rc) {
+    lia_set_error("lia_attention: head_dim %d unsupported (32/64/128), S=%d too long, or a cache of %d batch rows x %d values per key row beyond the d = 128 prefill kernel's 32-bit staging offsets (64 key rows < 4 GiB)",
+                  head_dim, S, cache_batch, heads * head_dim);
+    return LIA_ERR_INVALID;
+  }
   HIP_TRY(hipGetLastError());
   return LIA_OK;
 }

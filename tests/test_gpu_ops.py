@@ -126,6 +126,22 @@ def test_attention_prefill(gpu, oracle, B, T, heads, d):
     assert_close(to_bits(out), ref, atol=0.02, rtol=0.016, min_exact=0.9, what="attention prefill")
 
 
+def test_attention_prefill_refuses_a_cache_whose_key_rows_are_beyond_its_32_bit_staging_offsets(gpu):
+    """The d = 128 prefill kernel addresses a K / V tile as one scalar base + a 32-bit lane offset (row within the 64-key tile x bytes
+    per key row): 64 key rows must stay below 4 GiB.  A cache of 262144 batch rows x 128 values (64 MiB per key row) is refused by
+    the launcher, by name, before anything is launched."""
+    ctx, ops, torch = gpu
+    kc = torch.zeros((3, 262144, 1, 128), dtype=torch.bfloat16, device="cuda")
+    q = torch.zeros((1, 2, 128), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError, match="32-bit staging offsets"):
+        ctx.attention(q, kc, kc, 2, 1)
+    ctx.synchronize()
+    kc2 = torch.zeros((3, 131072, 1, 128), dtype=torch.bfloat16, device="cuda")     # half the row stride: accepted
+    out = ctx.attention(q, kc2, kc2, 2, 1)
+    ctx.synchronize()
+    assert out.shape == q.shape
+
+
 @pytest.mark.parametrize("B,S,heads,d", [(2, 9, 4, 32), (4, 33, 4, 64), (3, 257, 2, 128), (64, 288, 4, 128), (1, 2048, 2, 64)])
 def test_attention_decode(gpu, oracle, B, S, heads, d):
     ctx, ops, torch = gpu
