@@ -161,7 +161,10 @@ int lia_linear(lia_ctx* ctx, const lia_bf16* x, long ldx, const lia_bf16* w, con
 int lia_qkv_project(lia_ctx* ctx, const lia_bf16* x, const lia_bf16* w, const lia_bf16* bias, lia_bf16* qout,
                     lia_bf16* kcache, lia_bf16* vcache, int B, int T, int H, int cache_batch, int b0, int pos0,
                     void* stream);
-/* GPU attention, attentions.py:443-536.  q [B,T,H] (ldq elements per token row); cache [S][cache_batch][h][d]. */
+/* GPU attention, attentions.py:443-536.  q [B,T,H] (ldq elements per token row); cache [S][cache_batch][h][d].
+ * head_dim 32 / 64 / 128.  LIA_ERR_INVALID (by name in lia_last_error) for any other head_dim and, for a head_dim-128 prefill
+ * (T > 1), for a cache whose key row -- cache_batch x heads x head_dim values -- exceeds 3.3e7 values (64 key rows = 4 GiB:
+ * the kernel's 32-bit staging offsets; OPT-175B at a cache batch of 2048 is 2.5e7). */
 int lia_attention(const lia_bf16* q, long ldq, const lia_bf16* kcache, const lia_bf16* vcache, lia_bf16* out, long ldo,
                   int B, int T, int S, int heads, int head_dim, int cache_batch, int b0, void* stream);
 /* embed_tokens + embed_positions, modeling_opt.py:1108,357-378,1142 */
